@@ -1,0 +1,163 @@
+// fluxmi -- C-ABI entry points for the individual operators (include/fluxmi.h).
+// Compiled with hipcc (host-only translation unit; kernels live in the .hip files).
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fluxmi_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void fluxmi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// Tile choice: minimise (#waves of tiles over the 256 CUs) x (per-tile cost).  Relative per-tile
+// efficiencies were measured on MI355X (profiles/r01_gemm_sweep.txt); FLUXMI_GEMM_CFG overrides.
+int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("FLUXMI_GEMM_CFG");
+    forced = e ? atoi(e) : -1;
+  }
+  if (forced >= 0 && fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, forced)) return forced;
+  static const int BM[4] = {256, 256, 128, 128}, BN[4] = {256, 128, 128, 256};
+  static const double eff[4] = {1.00, 0.88, 0.74, 0.88};
+  static const int occ[4] = {1, 1, 2, 1};
+  int best = -1;
+  double best_cost = 1e300;
+  for (int c = 0; c < 4; ++c) {
+    if (!fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, c)) continue;
+    long long tiles = 0;
+    for (int i = 0; i < p.n_groups; ++i) tiles += (p.g[i].M + BM[c] - 1) / BM[c];
+    tiles *= p.N / BN[c];
+    const long long slots = 256LL * occ[c];
+    const long long waves = (tiles + slots - 1) / slots;
+    const double cost = (double)waves * occ[c] * (double)BM[c] * BN[c] / eff[c];
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+extern "C" {
+
+const char* fluxmi_last_error(void) { return g_err; }
+int fluxmi_abi_version(void) { return FLUXMI_ABI_VERSION; }
+
+int fluxmi_gemm_grouped(const fluxmi_gemm_group_t* groups, int n_groups, int N, int K, int is_fp8, int act_fmt, int epilogue,
+                        int tile_cfg, void* stream) {
+  FLUXMI_REQUIRE(groups && n_groups >= 1 && n_groups <= FLUXMI_MAX_GROUPS, "gemm_grouped: n_groups=%d (1..%d)", n_groups, FLUXMI_MAX_GROUPS);
+  FLUXMI_REQUIRE(N > 0 && K > 0, "gemm_grouped: bad N=%d K=%d", N, K);
+  FluxmiGemmParams p;
+  memset(&p, 0, sizeof(p));
+  for (int i = 0; i < n_groups; ++i) {
+    p.g[i] = groups[i];
+    FLUXMI_REQUIRE(groups[i].M >= 0, "gemm_grouped: group %d has M=%d", i, groups[i].M);
+    FLUXMI_REQUIRE(groups[i].M == 0 || (groups[i].A && groups[i].W && groups[i].C), "gemm_grouped: group %d has NULL A/W/C", i);
+  }
+  p.n_groups = n_groups; p.N = N; p.K = K; p.epi = epilogue;
+  if (tile_cfg == 100) return fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, (hipStream_t)stream);
+  if (tile_cfg < 0) tile_cfg = fluxmi_gemm_auto_cfg(p, is_fp8);
+  if (tile_cfg < 0) return fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, (hipStream_t)stream);
+  return fluxmi_launch_gemm(p, is_fp8, act_fmt, tile_cfg, (hipStream_t)stream);
+}
+
+int fluxmi_f8_gemm(const void* a_fp8, const void* w_e4m3, const float* sa_recip, const float* sb_recip, const void* bias, void* out,
+                   int M, int N, int K, int act_fmt, int epilogue, const void* gate, const void* resid, const float* q_scale,
+                   int tile_cfg, void* stream) {
+  fluxmi_gemm_group_t g;
+  memset(&g, 0, sizeof(g));
+  g.A = a_fp8; g.W = w_e4m3; g.bias = bias; g.sa_recip = sa_recip; g.sb_recip = sb_recip;
+  g.C = out; g.gate = gate; g.resid = resid; g.q_scale = q_scale;
+  g.lda = K; g.ldc = N; g.ldr = N; g.M = M;
+  return fluxmi_gemm_grouped(&g, 1, N, K, 1, act_fmt, epilogue, tile_cfg, stream);
+}
+
+int fluxmi_gemv(const void* x, long long ldx, const void* W, const void* bias, const float* in_scale, const float* sa_recip,
+                const float* sb_recip, void* out, long long ld_out, int B, int N, int K, int w_fp8, int act_fmt, int pre_silu,
+                void* stream) {
+  FluxmiGemvLayer L;
+  memset(&L, 0, sizeof(L));
+  L.W = W; L.bias = bias; L.in_scale = in_scale; L.sa_recip = sa_recip; L.sb_recip = sb_recip;
+  L.out = out; L.x = x; L.ld_out = ld_out; L.ldx = ldx; L.N = N; L.K = K;
+  L.w_fp8 = w_fp8; L.pre_silu = pre_silu; L.act_fmt = act_fmt;
+  return fluxmi_launch_gemv(nullptr, &L, 1, B, 0, 0, (hipStream_t)stream);
+}
+
+int fluxmi_quantize_act(const void* x, void* q, const float* scale, int rows, int cols, long long ld_in, long long ld_out, int fmt,
+                        void* stream) {
+  return fluxmi_k_quantize_act(x, q, scale, rows, cols, ld_in, ld_out, fmt, (hipStream_t)stream);
+}
+int fluxmi_amax(const void* x, float* amax, int rows, int cols, long long ld, void* stream) {
+  return fluxmi_k_amax(x, amax, rows, cols, ld, (hipStream_t)stream);
+}
+int fluxmi_calib_update(const float* amax, float* trials, float* scale, float* scale_recip, int trial_index, int num_trials,
+                        float max_val, void* stream) {
+  FLUXMI_REQUIRE(trial_index >= 0 && trial_index <= num_trials, "calib_update: trial_index %d out of range", trial_index);
+  return fluxmi_k_calib_update(amax, trials, scale, scale_recip, trial_index, num_trials, max_val, (hipStream_t)stream);
+}
+int fluxmi_quantize_weight(const void* w_bf16, void* q, float* amax_tmp, float* scale, float* scale_recip, int N, int K, int fmt,
+                           void* stream) {
+  return fluxmi_k_quantize_weight(w_bf16, q, amax_tmp, scale, scale_recip, N, K, fmt, (hipStream_t)stream);
+}
+int fluxmi_dequant(const void* q, float* out, const float* scale_recip, long long n, int fmt, void* stream) {
+  return fluxmi_k_dequant(q, out, scale_recip, n, fmt, (hipStream_t)stream);
+}
+
+// W' = requant( bf16( dequant(W) + sum_c lora_scale * B @ A_chunk_c ) ).  lora_A is [n_chunks*R, K] (already
+// multiplied by alpha/rank on the host as the reference does, lora_loading.py:529-530), lora_B is [N, R].
+int fluxmi_lora_fuse_f8(void* w_fp8, float* w_scale, float* w_scale_recip, const float* lora_B, const float* lora_A, int N, int K,
+                        int R, int n_chunks, float lora_scale, float* work_f32, float* amax_tmp, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)N * K;
+  FLUXMI_REQUIRE(n % 4 == 0 && n_chunks >= 1, "lora_fuse: bad shape N=%d K=%d chunks=%d", N, K, n_chunks);
+  // delta accumulates in work_f32[n .. 2n), dequantised weight in work_f32[0 .. n)
+  float* w32 = work_f32;
+  float* delta = work_f32 + n;
+  FLUXMI_TRY(fluxmi_k_dequant(w_fp8, w32, w_scale_recip, n, FLUXMI_E4M3, s));
+  for (int c = 0; c < n_chunks; ++c)
+    FLUXMI_TRY(fluxmi_k_lora_delta(lora_B, lora_A + (long long)c * R * K, delta, N, K, R, lora_scale, c > 0, s));
+  FLUXMI_TRY(fluxmi_k_axpy_f32(w32, delta, 1.0f, n, s));
+  return fluxmi_k_requantize_f32(w32, w_fp8, amax_tmp, w_scale, w_scale_recip, n, FLUXMI_E4M3, s);
+}
+
+int fluxmi_ln_modulate(const void* x, long long ldx, void* out, long long ldo, const void* shift0, const void* scale0,
+                       const void* shift1, const void* scale1, long long mod_bstride, const float* q_scale0, const float* q_scale1,
+                       int B, int L, int split, int H, int out_fp8, int fmt, void* stream) {
+  return fluxmi_k_ln_modulate(x, ldx, (long long)L * ldx, out, ldo, (long long)L * ldo, shift0, scale0, shift1, scale1, mod_bstride,
+                              q_scale0, q_scale1, B, L, split, H, out_fp8, fmt, (hipStream_t)stream);
+}
+int fluxmi_act(const void* x, void* y, int rows, int cols, long long ld_in, long long ld_out, int mode, void* stream) {
+  return fluxmi_k_act(x, y, rows, cols, ld_in, ld_out, mode, (hipStream_t)stream);
+}
+int fluxmi_gate_residual(const void* x, const void* y, const void* gate, void* out, int B, int L, int H, long long ldx, long long ldy,
+                         long long ldo, long long gate_bstride, void* stream) {
+  return fluxmi_k_gate_residual(x, y, gate, out, B, L, H, ldx, ldy, ldo, gate_bstride, (hipStream_t)stream);
+}
+int fluxmi_add(const void* a, const void* b, void* z, long long n, void* stream) {
+  return fluxmi_k_add(a, b, z, n, (hipStream_t)stream);
+}
+int fluxmi_rope_table(const void* ids, const float* omega, const int* axis, void* pe, long long rows, int n_axes, int pairs,
+                      void* stream) {
+  return fluxmi_k_rope_table(ids, omega, axis, pe, rows, n_axes, pairs, (hipStream_t)stream);
+}
+int fluxmi_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0, const void* q_scale1,
+                    const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H, int split, void* stream) {
+  return fluxmi_k_qkv_rope(qkv, ld, pe, q_scale0, k_scale0, q_scale1, k_scale1, Q, K, VT, B, L, Lp, H, split, (hipStream_t)stream);
+}
+int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
+                     const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream) {
+  return fluxmi_k_attention(Q, K, VT, out, ld_out, col_off, out_fp8, q_scale0, q_scale1, split, B, L, Lp, H, fmt, (hipStream_t)stream);
+}
+int fluxmi_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, void* stream) {
+  return fluxmi_k_timestep_embedding(t, freqs, out, B, half, time_factor, (hipStream_t)stream);
+}
+int fluxmi_euler(void* img, const void* pred, const float* dts, const int* step, long long n, void* stream) {
+  return fluxmi_k_euler(img, pred, dts, step, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

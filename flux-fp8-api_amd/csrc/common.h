@@ -1,0 +1,126 @@
+// fluxmi -- shared device helpers (gfx950 only).
+//
+// Numerics contract (DESIGN.md "rounding points"): the reference runs eager PyTorch, i.e. every
+// elementwise op rounds its result to the flow dtype (bf16).  The fused kernels here keep values in
+// fp32 registers but re-apply a bf16 rounding (rbf) at every point where the reference
+// materialises a bf16 tensor, so fused == unfused == oracle up to reduction order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef unsigned short u16;
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#define FLUXMI_FMT_E4M3 0  // MFMA cbsz/blgp code for OCP e4m3fn ("fp8")
+#define FLUXMI_FMT_E5M2 1  // MFMA cbsz/blgp code for OCP e5m2   ("bf8")
+
+__device__ __forceinline__ float bf2f(u16 u) { return __uint_as_float(((unsigned)u) << 16); }
+// f32 -> bf16 bits, round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ u16 f2bf(float f) {
+  bf16 h = (bf16)f;
+  return __builtin_bit_cast(u16, h);
+}
+// round an fp32 value through bf16 (the reference materialised a bf16 tensor here)
+__device__ __forceinline__ float rbf(float f) { return (float)((bf16)f); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]);
+  v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+  return v;
+}
+
+// ---- fp8 (OCP) conversion --------------------------------------------------------------------
+// float8_quantize.py:217-218 then `.to(fp8)`:  t = bf16(x * scale); clamp(t, +-max); RNE cast.
+// The clamp guarantees the hardware convert never sees an out-of-range value.
+template <int FMT> __device__ __forceinline__ float fp8_max() { return FMT == FLUXMI_FMT_E5M2 ? 57344.0f : 448.0f; }
+
+template <int FMT> __device__ __forceinline__ float q_prepare(float x, float scale) {
+  float t = rbf(x * scale);
+  const float mx = fp8_max<FMT>();
+  // clamp that propagates NaN like torch.clamp
+  t = (t > mx) ? mx : t;
+  t = (t < -mx) ? -mx : t;
+  return t;
+}
+// two prepared floats -> two fp8 bytes in the low half of the result
+template <int FMT> __device__ __forceinline__ unsigned cvt2_fp8(float a, float b) {
+  if (FMT == FLUXMI_FMT_E5M2) return (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffffu;
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+template <int FMT> __device__ __forceinline__ unsigned cvt4_fp8(float a, float b, float c, float d) {
+  int lo = (FMT == FLUXMI_FMT_E5M2) ? __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false)
+                                     : __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  int r = (FMT == FLUXMI_FMT_E5M2) ? __builtin_amdgcn_cvt_pk_bf8_f32(c, d, lo, true)
+                                    : __builtin_amdgcn_cvt_pk_fp8_f32(c, d, lo, true);
+  return (unsigned)r;
+}
+template <int FMT> __device__ __forceinline__ float fp8_to_f32(unsigned word, int byte);
+template <> __device__ __forceinline__ float fp8_to_f32<FLUXMI_FMT_E4M3>(unsigned w, int b) {
+  switch (b) {
+    case 0: return __builtin_amdgcn_cvt_f32_fp8((int)w, 0);
+    case 1: return __builtin_amdgcn_cvt_f32_fp8((int)w, 1);
+    case 2: return __builtin_amdgcn_cvt_f32_fp8((int)w, 2);
+    default: return __builtin_amdgcn_cvt_f32_fp8((int)w, 3);
+  }
+}
+template <> __device__ __forceinline__ float fp8_to_f32<FLUXMI_FMT_E5M2>(unsigned w, int b) {
+  switch (b) {
+    case 0: return __builtin_amdgcn_cvt_f32_bf8((int)w, 0);
+    case 1: return __builtin_amdgcn_cvt_f32_bf8((int)w, 1);
+    case 2: return __builtin_amdgcn_cvt_f32_bf8((int)w, 2);
+    default: return __builtin_amdgcn_cvt_f32_bf8((int)w, 3);
+  }
+}
+
+// ---- activations (fp32 internals exactly as ATen evaluates them on a bf16 tensor) -------------
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // aten GeluKernel (approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+  const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
+  float inner = kBeta * (x + kKappa * (x * x * x));
+  float a = fabsf(inner);
+  float e = __expf(2.0f * a);
+  float t = 1.0f - 2.0f / (e + 1.0f);
+  t = copysignf(t, inner);
+  return (0.5f * x) * (1.0f + t);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- wave-level reductions (wave = 64) ---------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// async global -> LDS copy of 16 bytes per lane (LDS destination = wave-uniform base + lane*16)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware, bijective remap of a 1-D block id: blocks that run on one XCD (bid % 8) get a
+// contiguous range of logical ids so that neighbouring tiles share that XCD's private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

@@ -1,0 +1,504 @@
+// fluxmi -- HBM-bound row / elementwise kernels of the Flux block (gfx950).
+//
+// Every kernel moves 16 B per lane per access (8 bf16), reduces with wave64 shuffles and applies the
+// reference's bf16 rounding points (common.h).  Reference sites are cited per kernel.
+#include "common.h"
+#include "fluxmi_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// activation quantise: q = fp8( clamp( bf16(x * scale) ) )            float8_quantize.py:217-218,274-276
+// x bf16 [rows, cols] (row stride ld_in) -> fp8 bytes [rows, cols] (row stride ld_out)
+// ---------------------------------------------------------------------------------------------
+template <int FMT>
+__global__ void __launch_bounds__(256) quantize_act_kernel(const u16* __restrict__ x, unsigned char* __restrict__ q,
+                                                           const float* __restrict__ scale_p, int rows, int cols,
+                                                           long long ld_in, long long ld_out) {
+  const float scale = *scale_p;
+  const int cpr = cols >> 3;  // 8-element chunks per row
+  const long long total = (long long)rows * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cpr), c = (int)(i % cpr) * 8;
+    float f[8];
+    unpack8(*(const uint4*)(x + r * ld_in + c), f);
+    uint2 o;
+    o.x = cvt4_fp8<FMT>(q_prepare<FMT>(f[0], scale), q_prepare<FMT>(f[1], scale), q_prepare<FMT>(f[2], scale), q_prepare<FMT>(f[3], scale));
+    o.y = cvt4_fp8<FMT>(q_prepare<FMT>(f[4], scale), q_prepare<FMT>(f[5], scale), q_prepare<FMT>(f[6], scale), q_prepare<FMT>(f[7], scale));
+    *(uint2*)(q + r * ld_out + c) = o;
+  }
+}
+
+// dequantise fp8 -> fp32: w32 = float(fp8) * scale_recip                       lora_loading.py:615-631
+template <int FMT>
+__global__ void __launch_bounds__(256) dequant_kernel(const unsigned char* __restrict__ q, float* __restrict__ out,
+                                                      const float* __restrict__ recip_p, long long n) {
+  const float r = *recip_p;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    const unsigned w = *(const unsigned*)(q + i);
+    float4 o;
+    o.x = fp8_to_f32<FMT>(w, 0) * r; o.y = fp8_to_f32<FMT>(w, 1) * r;
+    o.z = fp8_to_f32<FMT>(w, 2) * r; o.w = fp8_to_f32<FMT>(w, 3) * r;
+    *(float4*)(out + i) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// amax = max(|x|) accumulated into *amax (float bits, atomic max valid for non-negative floats)
+//                                                                        float8_quantize.py:198,227
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) amax_kernel(const u16* __restrict__ x, float* __restrict__ amax, int rows, int cols,
+                                                   long long ld) {
+  const int cpr = cols >> 3;
+  const long long total = (long long)rows * cpr;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cpr), c = (int)(i % cpr) * 8;
+    float f[8];
+    unpack8(*(const uint4*)(x + r * ld + c), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(f[j]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)amax, __float_as_uint(m));
+}
+
+// amax of an fp32 tensor after rounding each element to bf16 (LoRA-fused weights: weight.type(dtype))
+__global__ void __launch_bounds__(256) amax_f32_as_bf16_kernel(const float* __restrict__ x, float* __restrict__ amax, long long n) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(rbf(x[i])));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)amax, __float_as_uint(m));
+}
+
+// scale = clamp(max_val / max(amax, 1e-12), max = max_val); recip = 1/scale      float8_quantize.py:214-215
+__device__ __forceinline__ float amax_to_scale(float amax, float max_val) {
+  return fminf(max_val / fmaxf(amax, 1e-12f), max_val);
+}
+
+// Calibration state machine of F8Linear.quantize_input (float8_quantize.py:220-246), for `n_layers`
+// layers that all saw the tensor whose amax is *amax_p.  trial_index < num_trials: record + running max;
+// trial_index == num_trials: freeze from all recorded trials (no new amax is recorded).
+__global__ void calib_update_kernel(const float* __restrict__ amax_p, const FluxmiCalibLayer* __restrict__ layers, int n_layers,
+                                    int trial_index, int num_trials, float max_val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_layers) return;
+  const FluxmiCalibLayer L = layers[i];
+  int upto = num_trials;
+  if (trial_index < num_trials) {
+    L.trials[trial_index] = *amax_p;
+    upto = trial_index + 1;
+  }
+  float m = L.trials[0];
+  for (int t = 1; t < upto; ++t) m = fmaxf(m, L.trials[t]);
+  const float s = amax_to_scale(m, max_val);
+  *L.scale = s;
+  *L.recip = 1.0f / s;
+}
+__global__ void calib_update_single_kernel(const float* amax_p, float* trials, float* scale, float* recip, int trial_index,
+                                           int num_trials, float max_val) {
+  int upto = num_trials;
+  if (trial_index < num_trials) { trials[trial_index] = *amax_p; upto = trial_index + 1; }
+  float m = trials[0];
+  for (int t = 1; t < upto; ++t) m = fmaxf(m, trials[t]);
+  const float s = amax_to_scale(m, max_val);
+  *scale = s;
+  *recip = 1.0f / s;
+}
+// weight scale from amax                                                float8_quantize.py:198-203
+__global__ void weight_scale_kernel(const float* amax_p, float* scale, float* recip, float max_val) {
+  const float s = amax_to_scale(*amax_p, max_val);
+  *scale = s;
+  *recip = 1.0f / s;
+}
+// fp32 -> (round to bf16) -> fp8 with scale (re-quantise a LoRA-fused weight)   float8_quantize.py:199-202
+template <int FMT>
+__global__ void __launch_bounds__(256) quantize_f32_kernel(const float* __restrict__ x, unsigned char* __restrict__ q,
+                                                           const float* __restrict__ scale_p, long long n) {
+  const float scale = *scale_p;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    const float4 v = *(const float4*)(x + i);
+    *(unsigned*)(q + i) = cvt4_fp8<FMT>(q_prepare<FMT>(rbf(v.x), scale), q_prepare<FMT>(rbf(v.y), scale),
+                                        q_prepare<FMT>(rbf(v.z), scale), q_prepare<FMT>(rbf(v.w), scale));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (no affine, eps 1e-6) + modulate (+ optional fp8 quantise), one wave per row
+//   y = bf16( bf16( bf16(1 + scale) * LN(x) ) + shift )                 flux_model.py:367-368,374-375,389,395,469-470,501
+// rows are laid out [B][L]; rows l < split use stream 0's (shift, scale, q_scale), others stream 1's.
+// ---------------------------------------------------------------------------------------------
+struct LnModArgs {
+  const u16* x; long long ldx, x_bstride;      // row (b,l) at x + b*x_bstride + l*ldx
+  void* out; long long ldo, out_bstride;       // bf16 or fp8, same addressing
+  const u16* shift[2]; const u16* scale[2]; long long mod_bstride;  // [B][H] each, batch stride in elements
+  const float* q_scale[2];
+  int B, L, split, H;
+};
+template <int NCH, bool OUT_FP8, int FMT>
+__global__ void __launch_bounds__(256) ln_modulate_kernel(const LnModArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.B * a.L) return;
+  const int b = row / a.L, l = row % a.L, st = (l < a.split) ? 0 : 1;
+  const u16* xr = a.x + (long long)b * a.x_bstride + (long long)l * a.ldx;
+  const long long orow = (long long)b * a.out_bstride + (long long)l * a.ldo;
+  float v[NCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = (lane + 64 * k) * 8;
+    if (c < a.H) {
+      unpack8(*(const uint4*)(xr + c), v[k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[k][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)a.H;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = (lane + 64 * k) * 8;
+    if (c < a.H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; sq += d * d; }
+    }
+  }
+  const float var = wave_sum(sq) / (float)a.H;
+  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  const u16* sh = a.shift[st] + (long long)b * a.mod_bstride;
+  const u16* sc = a.scale[st] + (long long)b * a.mod_bstride;
+  float qs = 1.f;
+  if (OUT_FP8) qs = *a.q_scale[st];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int c = (lane + 64 * k) * 8;
+    if (c < a.H) {
+      float fs[8], fh[8], y[8];
+      unpack8(*(const uint4*)(sc + c), fs);
+      unpack8(*(const uint4*)(sh + c), fh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float n = rbf((v[k][j] - mean) * rstd);
+        const float m1 = rbf(1.0f + fs[j]);
+        y[j] = rbf(rbf(m1 * n) + fh[j]);
+      }
+      if (OUT_FP8) {
+        uint2 o;
+        o.x = cvt4_fp8<FMT>(q_prepare<FMT>(y[0], qs), q_prepare<FMT>(y[1], qs), q_prepare<FMT>(y[2], qs), q_prepare<FMT>(y[3], qs));
+        o.y = cvt4_fp8<FMT>(q_prepare<FMT>(y[4], qs), q_prepare<FMT>(y[5], qs), q_prepare<FMT>(y[6], qs), q_prepare<FMT>(y[7], qs));
+        *(uint2*)((unsigned char*)a.out + orow + c) = o;
+      } else {
+        *(uint4*)((u16*)a.out + orow + c) = pack8(y);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// unfused elementwise ops (calibration / mixed-precision path)
+// ---------------------------------------------------------------------------------------------
+// mode 0: gelu(tanh)  flux_model.py:301,335,455,480     mode 1: silu  flux_model.py:139,249,496
+__global__ void __launch_bounds__(256) act_kernel(const u16* x, u16* y, int rows, int cols,
+                                                  long long ld_in, long long ld_out, int mode) {
+  const int cpr = cols >> 3;
+  const long long total = (long long)rows * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cpr), c = (int)(i % cpr) * 8;
+    float f[8];
+    unpack8(*(const uint4*)(x + r * ld_in + c), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = mode == 0 ? gelu_tanh_f(f[j]) : silu_f(f[j]);
+    *(uint4*)(y + r * ld_out + c) = pack8(f);
+  }
+}
+
+// out = bf16( x + bf16(gate[b] * y) ),  rows [B][L], gate [B][H] (batch stride gate_bstride)   flux_model.py:387-396,484
+__global__ void __launch_bounds__(256) gate_residual_kernel(const u16* __restrict__ x, const u16* __restrict__ y,
+                                                            const u16* __restrict__ gate, u16* __restrict__ out, int B, int L,
+                                                            int H, long long ldx, long long ldy, long long ldo,
+                                                            long long gate_bstride) {
+  const int cpr = H >> 3;
+  const long long total = (long long)B * L * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpr;
+    const int c = (int)(i % cpr) * 8, b = (int)(r / L);
+    float fx[8], fy[8], fg[8];
+    unpack8(*(const uint4*)(x + r * ldx + c), fx);
+    unpack8(*(const uint4*)(y + r * ldy + c), fy);
+    unpack8(*(const uint4*)(gate + b * gate_bstride + c), fg);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fx[j] = fx[j] + rbf(fg[j] * fy[j]);
+    *(uint4*)(out + r * ldo + c) = pack8(fx);
+  }
+}
+
+// z = bf16(a + b) elementwise over n (multiple of 8) elements           flux_model.py:694,697
+__global__ void __launch_bounds__(256) add_kernel(const u16* __restrict__ a, const u16* __restrict__ b, u16* __restrict__ z, long long n) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long long)gridDim.x * blockDim.x * 8) {
+    float fa[8], fb[8];
+    unpack8(*(const uint4*)(a + i), fa);
+    unpack8(*(const uint4*)(b + i), fb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] += fb[j];
+    *(uint4*)(z + i) = pack8(fa);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sinusoidal timestep embedding                                           flux_model.py:95-116
+//   t' = bf16(1000 * t);  out[b, i] = bf16(cos(t' * f_i)),  out[b, half+i] = bf16(sin(t' * f_i))
+// freqs[half] is the fp32 table exp(-ln(1e4) * i / half) computed once by the host.
+// ---------------------------------------------------------------------------------------------
+__global__ void timestep_embedding_kernel(const u16* __restrict__ t, const float* __restrict__ freqs, u16* __restrict__ out,
+                                          int B, int half, float time_factor) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i % half;
+  const float tt = rbf(time_factor * bf2f(t[b]));
+  const float arg = tt * freqs[k];
+  out[(long long)b * 2 * half + k] = f2bf(cosf(arg));
+  out[(long long)b * 2 * half + half + k] = f2bf(sinf(arg));
+}
+
+// RoPE table: pe[b, l, p] = (bf16 cos, bf16 sin) of  float(ids[b,l,axis(p)]) * omega[p]     flux_model.py:49-57,82-92
+__global__ void rope_table_kernel(const u16* __restrict__ ids, const float* __restrict__ omega, const int* __restrict__ axis,
+                                  u16* __restrict__ pe, long long rows, int n_axes, int pairs) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * pairs) return;
+  const long long r = i / pairs;
+  const int p = (int)(i % pairs);
+  const float ang = bf2f(ids[r * n_axes + axis[p]]) * omega[p];
+  pe[i * 2] = f2bf(cosf(ang));
+  pe[i * 2 + 1] = f2bf(sinf(ang));
+}
+
+// Euler step of the flow ODE:  img = bf16( img + bf16(dt * pred) ),  dt = dts[*step]       flux_pipeline.py:651
+__global__ void __launch_bounds__(256) euler_kernel(u16* __restrict__ img, const u16* __restrict__ pred, const float* __restrict__ dts,
+                                                    const int* __restrict__ step, long long n) {
+  const float dt = dts[step ? *step : 0];
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += (long long)gridDim.x * blockDim.x * 8) {
+    float fi[8], fp[8];
+    unpack8(*(const uint4*)(img + i), fi);
+    unpack8(*(const uint4*)(pred + i), fp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fi[j] += rbf(dt * fp[j]);
+    *(uint4*)(img + i) = pack8(fi);
+  }
+}
+// per-step scalars kept on the device so that one captured graph serves every step:
+//   t_vec[b] = bf16(ts[*step]),  then ++*step happens in advance_step_kernel at the end of the step.
+__global__ void set_timestep_kernel(u16* __restrict__ t_vec, const float* __restrict__ ts, const int* __restrict__ step, int B) {
+  const int b = threadIdx.x;
+  if (b < B) t_vec[b] = f2bf(ts[*step]);
+}
+__global__ void advance_step_kernel(int* step) { *step += 1; }
+
+// w += delta (fp32), n multiple of 4                                       lora_loading.py:564-577
+__global__ void __launch_bounds__(256) axpy_f32_kernel(float* __restrict__ w, const float* __restrict__ d, float alpha, long long n) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    float4 a = *(float4*)(w + i);
+    const float4 b = *(const float4*)(d + i);
+    a.x += alpha * b.x; a.y += alpha * b.y; a.z += alpha * b.z; a.w += alpha * b.w;
+    *(float4*)(w + i) = a;
+  }
+}
+// fp32 rank-r update: delta[n,k] = sum_r B[n,r] * A[r,k]   (LoRA, r <= 128)      lora_loading.py:509-544
+__global__ void __launch_bounds__(256) lora_delta_kernel(const float* __restrict__ Bm, const float* __restrict__ A,
+                                                         float* __restrict__ delta, int N, int K, int R, float scale, int accumulate) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y;
+  if (k >= K) return;
+  float acc = 0.f;
+  for (int r = 0; r < R; ++r) acc = fmaf(Bm[(long long)n * R + r], A[(long long)r * K + k], acc);
+  acc *= scale;
+  float* d = delta + (long long)n * K + k;
+  *d = accumulate ? (*d + acc) : acc;
+}
+
+inline int grid_for(long long work_items, int block = 256, int cap = 256 * 16) {
+  long long g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+// ================================== launchers (internal C++ API) ==================================
+int fluxmi_k_quantize_act(const void* x, void* q, const float* scale, int rows, int cols, long long ld_in, long long ld_out,
+                          int fmt, hipStream_t s) {
+  FLUXMI_REQUIRE(cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, "quantize_act: cols/ld must be multiples of 8");
+  if (rows == 0 || cols == 0) return 0;
+  const int g = grid_for((long long)rows * (cols / 8));
+  if (fmt == FLUXMI_FMT_E5M2)
+    hipLaunchKernelGGL(quantize_act_kernel<FLUXMI_FMT_E5M2>, dim3(g), dim3(256), 0, s, (const u16*)x, (unsigned char*)q, scale, rows, cols, ld_in, ld_out);
+  else
+    hipLaunchKernelGGL(quantize_act_kernel<FLUXMI_FMT_E4M3>, dim3(g), dim3(256), 0, s, (const u16*)x, (unsigned char*)q, scale, rows, cols, ld_in, ld_out);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_amax(const void* x, float* amax, int rows, int cols, long long ld, hipStream_t s) {
+  FLUXMI_REQUIRE(cols % 8 == 0 && ld % 8 == 0, "amax: cols/ld must be multiples of 8");
+  if (rows == 0 || cols == 0) return 0;
+  hipLaunchKernelGGL(amax_kernel, dim3(grid_for((long long)rows * (cols / 8))), dim3(256), 0, s, (const u16*)x, amax, rows, cols, ld);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_calib_update(const float* amax, float* trials, float* scale, float* recip, int trial_index, int num_trials,
+                          float max_val, hipStream_t s) {
+  hipLaunchKernelGGL(calib_update_single_kernel, dim3(1), dim3(1), 0, s, amax, trials, scale, recip, trial_index, num_trials, max_val);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+int fluxmi_k_calib_update_many(const float* amax, const void* layers_dev, int n_layers, int trial_index, int num_trials,
+                               float max_val, hipStream_t s) {
+  if (n_layers == 0) return 0;
+  hipLaunchKernelGGL(calib_update_kernel, dim3((n_layers + 63) / 64), dim3(64), 0, s, amax, (const FluxmiCalibLayer*)layers_dev, n_layers,
+                     trial_index, num_trials, max_val);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_quantize_weight(const void* w_bf16, void* q, float* amax_tmp, float* scale, float* recip, int N, int K, int fmt,
+                             hipStream_t s) {
+  FLUXMI_REQUIRE(K % 8 == 0, "quantize_weight: K must be a multiple of 8");
+  FLUXMI_CHECK_HIP(hipMemsetAsync(amax_tmp, 0, sizeof(float), s));
+  int rc = fluxmi_k_amax(w_bf16, amax_tmp, N, K, K, s);
+  if (rc) return rc;
+  const float mx = fmt == FLUXMI_FMT_E5M2 ? 57344.f : 448.f;
+  hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1), 0, s, amax_tmp, scale, recip, mx);
+  FLUXMI_LAUNCH_CHECK();
+  return fluxmi_k_quantize_act(w_bf16, q, scale, N, K, K, K, fmt, s);
+}
+
+int fluxmi_k_dequant(const void* q, float* out, const float* recip, long long n, int fmt, hipStream_t s) {
+  FLUXMI_REQUIRE(n % 4 == 0, "dequant: n must be a multiple of 4");
+  if (n == 0) return 0;
+  const int g = grid_for(n / 4);
+  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL(dequant_kernel<FLUXMI_FMT_E5M2>, dim3(g), dim3(256), 0, s, (const unsigned char*)q, out, recip, n);
+  else hipLaunchKernelGGL(dequant_kernel<FLUXMI_FMT_E4M3>, dim3(g), dim3(256), 0, s, (const unsigned char*)q, out, recip, n);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_requantize_f32(const float* w32, void* q, float* amax_tmp, float* scale, float* recip, long long n, int fmt,
+                            hipStream_t s) {
+  FLUXMI_REQUIRE(n % 4 == 0, "requantize: n must be a multiple of 4");
+  FLUXMI_CHECK_HIP(hipMemsetAsync(amax_tmp, 0, sizeof(float), s));
+  hipLaunchKernelGGL(amax_f32_as_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, w32, amax_tmp, n);
+  const float mx = fmt == FLUXMI_FMT_E5M2 ? 57344.f : 448.f;
+  hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1), 0, s, amax_tmp, scale, recip, mx);
+  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL(quantize_f32_kernel<FLUXMI_FMT_E5M2>, dim3(grid_for(n / 4)), dim3(256), 0, s, w32, (unsigned char*)q, scale, n);
+  else hipLaunchKernelGGL(quantize_f32_kernel<FLUXMI_FMT_E4M3>, dim3(grid_for(n / 4)), dim3(256), 0, s, w32, (unsigned char*)q, scale, n);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_lora_delta(const float* Bm, const float* A, float* delta, int N, int K, int R, float scale, int accumulate, hipStream_t s) {
+  if (N == 0 || K == 0) return 0;
+  hipLaunchKernelGGL(lora_delta_kernel, dim3((K + 255) / 256, N), dim3(256), 0, s, Bm, A, delta, N, K, R, scale, accumulate);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+int fluxmi_k_axpy_f32(float* w, const float* d, float alpha, long long n, hipStream_t s) {
+  FLUXMI_REQUIRE(n % 4 == 0, "axpy: n must be a multiple of 4");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(axpy_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, w, d, alpha, n);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void* out, long long ldo, long long out_bstride,
+                         const void* shift0, const void* scale0, const void* shift1, const void* scale1, long long mod_bstride,
+                         const float* q0, const float* q1, int B, int L, int split, int H, int out_fp8, int fmt, hipStream_t s) {
+  FLUXMI_REQUIRE(H % 8 == 0 && H <= 4096, "ln_modulate: hidden size %d unsupported (need %%8==0, <=4096)", H);
+  FLUXMI_REQUIRE(!out_fp8 || (q0 && q1), "ln_modulate: fp8 output needs q_scale pointers");
+  if (B * L == 0) return 0;
+  LnModArgs a;
+  a.x = (const u16*)x; a.ldx = ldx; a.x_bstride = x_bstride; a.out = out; a.ldo = ldo; a.out_bstride = out_bstride;
+  a.shift[0] = (const u16*)shift0; a.scale[0] = (const u16*)scale0;
+  a.shift[1] = (const u16*)shift1; a.scale[1] = (const u16*)scale1;
+  a.mod_bstride = mod_bstride; a.q_scale[0] = q0; a.q_scale[1] = q1;
+  a.B = B; a.L = L; a.split = split; a.H = H;
+  const dim3 grid((B * L + 3) / 4), block(256);
+  const int nch = (H + 511) / 512;
+#define LNM(N_)                                                                                                       \
+  do {                                                                                                                \
+    if (!out_fp8) hipLaunchKernelGGL((ln_modulate_kernel<N_, false, FLUXMI_FMT_E5M2>), grid, block, 0, s, a);           \
+    else if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((ln_modulate_kernel<N_, true, FLUXMI_FMT_E5M2>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((ln_modulate_kernel<N_, true, FLUXMI_FMT_E4M3>), grid, block, 0, s, a);                     \
+  } while (0)
+  if (nch <= 1) LNM(1);
+  else if (nch <= 2) LNM(2);
+  else if (nch <= 4) LNM(4);
+  else if (nch <= 6) LNM(6);
+  else LNM(8);
+#undef LNM
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_act(const void* x, void* y, int rows, int cols, long long ld_in, long long ld_out, int mode, hipStream_t s) {
+  FLUXMI_REQUIRE(cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, "act: cols/ld must be multiples of 8");
+  if (rows == 0 || cols == 0) return 0;
+  hipLaunchKernelGGL(act_kernel, dim3(grid_for((long long)rows * (cols / 8))), dim3(256), 0, s, (const u16*)x, (u16*)y, rows, cols, ld_in, ld_out, mode);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_gate_residual(const void* x, const void* y, const void* gate, void* out, int B, int L, int H, long long ldx,
+                           long long ldy, long long ldo, long long gate_bstride, hipStream_t s) {
+  FLUXMI_REQUIRE(H % 8 == 0, "gate_residual: H must be a multiple of 8");
+  if ((long long)B * L * H == 0) return 0;
+  hipLaunchKernelGGL(gate_residual_kernel, dim3(grid_for((long long)B * L * (H / 8))), dim3(256), 0, s, (const u16*)x, (const u16*)y,
+                     (const u16*)gate, (u16*)out, B, L, H, ldx, ldy, ldo, gate_bstride);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_add(const void* a, const void* b, void* z, long long n, hipStream_t s) {
+  FLUXMI_REQUIRE(n % 8 == 0, "add: n must be a multiple of 8");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const u16*)a, (const u16*)b, (u16*)z, n);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, hipStream_t s) {
+  if (B * half == 0) return 0;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * half + 127) / 128), dim3(128), 0, s, (const u16*)t, freqs, (u16*)out, B, half, time_factor);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_rope_table(const void* ids, const float* omega, const int* axis, void* pe, long long rows, int n_axes, int pairs, hipStream_t s) {
+  if (rows * pairs == 0) return 0;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((rows * pairs + 255) / 256)), dim3(256), 0, s, (const u16*)ids, omega, axis, (u16*)pe, rows, n_axes, pairs);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_euler(void* img, const void* pred, const float* dts, const int* step, long long n, hipStream_t s) {
+  FLUXMI_REQUIRE(n % 8 == 0, "euler: n must be a multiple of 8");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(euler_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (u16*)img, (const u16*)pred, dts, step, n);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+int fluxmi_k_set_timestep(void* t_vec, const float* ts, const int* step, int B, hipStream_t s) {
+  FLUXMI_REQUIRE(B <= 64, "set_timestep: batch %d > 64", B);
+  hipLaunchKernelGGL(set_timestep_kernel, dim3(1), dim3(64), 0, s, (u16*)t_vec, ts, step, B);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+int fluxmi_k_advance_step(int* step, hipStream_t s) {
+  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, step);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}

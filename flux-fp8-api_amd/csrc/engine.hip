@@ -1,0 +1,675 @@
+// fluxmi -- the Flux denoise engine: Flux.forward (reference modules/flux_model.py:672-716) and the Euler
+// loop of FluxPipeline.generate (flux_pipeline.py:619-651) sequenced natively over the HIP kernels.
+//
+// Two execution modes share every kernel:
+//   unfused (mode 0 calibrating / mode 2 frozen): producer -> bf16 -> [amax -> scale update] -> quantise -> GEMM,
+//       i.e. the reference's eager op order, advancing F8Linear's 12-trial input-scale state machine
+//       (float8_quantize.py:220-246) with device-resident amax/scale (no host sync);
+//   fused (mode 1, frozen scales): LN+modulate+quantise, GEMM epilogues (GELU+quantise, gate*y+x, qkv|mlp split),
+//       attention writing fp8 directly; ~8 launches per double block, 5 per single block, hipGraph-captured.
+// Because every fused kernel re-applies the reference's bf16 rounding points, both modes produce the same bits
+// for the same scales (tests/test_engine.py checks this on the GPU).
+//
+// HBM layout (per request shape B, Li, Lt; L = Lt + Li, txt rows first so torch.cat is free):
+//   x      bf16 [B, L, H]        residual stream (img = rows Lt.., txt = rows ..Lt)
+//   a8     fp8  [B, L, H]        quantised LN+modulate output (GEMM A operand)
+//   qkv    bf16 [B, L, 3H]       qkv GEMM output
+//   Q,K    bf16 [B, heads, L, 128];  VT bf16 [B, heads, 128, Lp]  (attention operands)
+//   attn8  fp8  [B, L, H];  h8 fp8 [B, L, 4H];  cat8 fp8 [B, L, 5H]  (single block: attn | gelu(mlp))
+//   mod    bf16 [B, 12H*depth + 3H*single + 2H]   all modulation vectors of the step
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "fluxmi_internal.h"
+
+namespace {
+constexpr int MAX_STEPS = 1024;
+struct Buf { void* p; size_t n; };
+}  // namespace
+
+struct fluxmi_engine {
+  fluxmi_model_desc_t d;
+  std::vector<fluxmi_linear_t> lin;
+  std::vector<const void*> norm;
+  int i_img_in, i_time_in, i_vec_in, i_guid_in, i_txt_in, i_double0, i_single0, i_final_mod, i_final_lin;
+  int B = 0, Li = 0, Lt = 0, L = 0, Lp = 0;
+  long long mod_cols = 0;
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  std::map<std::string, Buf> bufs;
+  // persistent small device state
+  char* consts = nullptr;
+  float *d_freqs, *d_omega, *d_ts, *d_dts, *d_amax;
+  int *d_axis, *d_step;
+  FluxmiCalibLayer* d_calib;
+  FluxmiGemvLayer* d_gemv = nullptr;
+  std::vector<FluxmiGemvLayer> h_gemv;
+  std::vector<FluxmiCalibLayer> h_calib_mod;  // modulation layers that share silu(vec)
+  FluxmiCalibLayer* d_calib_mod = nullptr;
+  int gemv_blocks = 0, gemv_maxK = 0;
+  hipGraphExec_t exec = nullptr;
+  bool graph_ok = false;
+  bool txt_emb_valid = false;
+};
+
+namespace {
+
+typedef fluxmi_engine E;
+
+template <class T> T* buf(E* e, const char* name) {
+  auto it = e->bufs.find(name);
+  return it == e->bufs.end() ? nullptr : (T*)it->second.p;
+}
+
+int lin_count(const fluxmi_model_desc_t& d) { return 6 + (d.guidance_embed ? 2 : 0) + d.depth * 10 + d.depth_single * 3 + 2; }
+
+// double-block linear slots / single-block linear slots
+enum { D_IMG_MOD = 0, D_IMG_QKV, D_IMG_PROJ, D_IMG_MLP0, D_IMG_MLP2, D_TXT_MOD, D_TXT_QKV, D_TXT_PROJ, D_TXT_MLP0, D_TXT_MLP2 };
+enum { S_MOD = 0, S_LIN1, S_LIN2 };
+
+const fluxmi_linear_t& DL(E* e, int blk, int slot) { return e->lin[e->i_double0 + blk * 10 + slot]; }
+const fluxmi_linear_t& SL(E* e, int blk, int slot) { return e->lin[e->i_single0 + blk * 3 + slot]; }
+int DLi(E* e, int blk, int slot) { return e->i_double0 + blk * 10 + slot; }
+int SLi(E* e, int blk, int slot) { return e->i_single0 + blk * 3 + slot; }
+
+FluxmiGemmGroup mk_group(const fluxmi_linear_t& l, const void* A, long long lda, void* C, long long ldc, int M) {
+  FluxmiGemmGroup g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.W = l.weight; g.bias = l.bias;
+  g.sa_recip = l.kind ? l.in_scale_recip : nullptr;
+  g.sb_recip = l.kind ? l.w_scale_recip : nullptr;
+  g.C = C; g.lda = lda; g.ldc = ldc; g.M = M;
+  return g;
+}
+
+int run_gemm(std::vector<FluxmiGemmGroup>& gs, int N, int K, int is_fp8, int act_fmt, int epi, hipStream_t s) {
+  for (size_t off = 0; off < gs.size(); off += FLUXMI_MAX_GROUPS) {
+    FluxmiGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.n_groups = (int)std::min<size_t>(FLUXMI_MAX_GROUPS, gs.size() - off);
+    for (int i = 0; i < p.n_groups; ++i) p.g[i] = gs[off + i];
+    p.N = N; p.K = K; p.epi = epi;
+    const int cfg = fluxmi_gemm_auto_cfg(p, is_fp8);
+    const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % ((cfg == 0 || cfg == 3) ? 256 : 128) == 0);
+    if (cfg < 0 || !split_ok) FLUXMI_TRY(fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, s));
+    else FLUXMI_TRY(fluxmi_launch_gemm(p, is_fp8, act_fmt, cfg, s));
+  }
+  return 0;
+}
+
+// ---- calibration helpers (unfused path) ------------------------------------------------------------
+int calib_begin(E* e, int li, hipStream_t s) { return hipMemsetAsync(e->d_amax + li, 0, sizeof(float), s) == hipSuccess ? 0 : 2; }
+int calib_amax(E* e, int li, const void* x, int rows, int cols, long long ld, hipStream_t s) {
+  return fluxmi_k_amax(x, e->d_amax + li, rows, cols, ld, s);
+}
+int calib_commit(E* e, int li, int trial, hipStream_t s) {
+  const fluxmi_linear_t& l = e->lin[li];
+  const float mx = l.in_fmt == FLUXMI_E5M2 ? 57344.f : 448.f;
+  return fluxmi_k_calib_update(e->d_amax + li, l.amax_trials, l.in_scale, l.in_scale_recip, trial, e->d.num_trials, mx, s);
+}
+
+// Quantise the bf16 input of linear `li` (rows given as nb blocks of `rows` rows, block stride bstride) into dst8.
+int stage_input(E* e, int li, bool calib, int trial, const u16* src, long long ld_src, long long src_bstride, uint8_t* dst,
+                long long ld_dst, long long dst_bstride, int nb, int rows, int cols, hipStream_t s) {
+  const fluxmi_linear_t& l = e->lin[li];
+  if (!l.kind) return 0;
+  if (calib) {
+    FLUXMI_TRY(calib_begin(e, li, s));
+    for (int b = 0; b < nb; ++b) FLUXMI_TRY(calib_amax(e, li, src + b * src_bstride, rows, cols, ld_src, s));
+    FLUXMI_TRY(calib_commit(e, li, trial, s));
+  }
+  for (int b = 0; b < nb; ++b)
+    FLUXMI_TRY(fluxmi_k_quantize_act(src + b * src_bstride, dst + b * dst_bstride, l.in_scale, rows, cols, ld_src, ld_dst, l.in_fmt, s));
+  return 0;
+}
+
+// skinny linear through the GEMV kernel (M = B).  In calibrating mode the (possibly SiLU'd) input is materialised first.
+int small_linear(E* e, int li, const u16* x, long long ldx, u16* out, long long ld_out, int pre_silu, bool calib, int trial,
+                 u16* scratch, hipStream_t s) {
+  const fluxmi_linear_t& l = e->lin[li];
+  const u16* xin = x;
+  if (l.kind && calib) {
+    if (pre_silu) {
+      FLUXMI_TRY(fluxmi_k_act(x, scratch, e->B, l.K, ldx, l.K, 1, s));
+      xin = scratch; ldx = l.K; pre_silu = 0;
+    }
+    FLUXMI_TRY(calib_begin(e, li, s));
+    FLUXMI_TRY(calib_amax(e, li, xin, e->B, l.K, ldx, s));
+    FLUXMI_TRY(calib_commit(e, li, trial, s));
+  }
+  FluxmiGemvLayer g;
+  memset(&g, 0, sizeof(g));
+  g.W = l.weight; g.bias = l.bias; g.in_scale = l.in_scale; g.sa_recip = l.in_scale_recip; g.sb_recip = l.w_scale_recip;
+  g.out = out; g.x = xin; g.ld_out = ld_out; g.ldx = ldx; g.N = l.N; g.K = l.K; g.w_fp8 = l.kind; g.pre_silu = pre_silu;
+  g.act_fmt = l.in_fmt;
+  return fluxmi_launch_gemv(nullptr, &g, 1, e->B, 0, 0, s);
+}
+
+int build_gemv_table(E* e, hipStream_t s) {
+  const int H = e->d.hidden;
+  e->h_gemv.clear();
+  e->h_calib_mod.clear();
+  u16* mod = buf<u16>(e, "mod");
+  u16* svec = buf<u16>(e, "svec");
+  auto add = [&](int li, long long off) {
+    const fluxmi_linear_t& l = e->lin[li];
+    FluxmiGemvLayer g;
+    memset(&g, 0, sizeof(g));
+    g.W = l.weight; g.bias = l.bias; g.in_scale = l.in_scale; g.sa_recip = l.in_scale_recip; g.sb_recip = l.w_scale_recip;
+    g.out = mod + off; g.x = svec; g.ld_out = e->mod_cols; g.ldx = H; g.N = l.N; g.K = l.K; g.w_fp8 = l.kind;
+    g.pre_silu = 0; g.act_fmt = l.in_fmt;
+    e->h_gemv.push_back(g);
+    if (l.kind) e->h_calib_mod.push_back(FluxmiCalibLayer{l.amax_trials, l.in_scale, l.in_scale_recip});
+  };
+  for (int i = 0; i < e->d.depth; ++i) {
+    add(DLi(e, i, D_IMG_MOD), (long long)i * 12 * H);
+    add(DLi(e, i, D_TXT_MOD), (long long)i * 12 * H + 6 * H);
+  }
+  for (int i = 0; i < e->d.depth_single; ++i) add(SLi(e, i, S_MOD), (long long)e->d.depth * 12 * H + (long long)i * 3 * H);
+  add(e->i_final_mod, (long long)e->d.depth * 12 * H + (long long)e->d.depth_single * 3 * H);
+  int blk = 0, maxK = 0;
+  for (auto& g : e->h_gemv) {
+    g.blk_start = blk;
+    blk += (g.N + 63) / 64;
+    maxK = g.K > maxK ? g.K : maxK;
+  }
+  e->gemv_blocks = blk; e->gemv_maxK = maxK;
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(e->d_gemv, e->h_gemv.data(), sizeof(FluxmiGemvLayer) * e->h_gemv.size(), hipMemcpyHostToDevice, s));
+  if (!e->h_calib_mod.empty())
+    FLUXMI_CHECK_HIP(hipMemcpyAsync(e->d_calib_mod, e->h_calib_mod.data(), sizeof(FluxmiCalibLayer) * e->h_calib_mod.size(), hipMemcpyHostToDevice, s));
+  FLUXMI_CHECK_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// vec = time_in(temb(t)) + guidance_in(temb(g)) + vector_in(y)  and all modulations      flux_model.py:687-697, 251-257
+// ---------------------------------------------------------------------------------------------------------
+int compute_vec_and_mods(E* e, const u16* t_vec, const u16* g_vec, const u16* y, bool calib, int trial, hipStream_t s) {
+  const int H = e->d.hidden, B = e->B;
+  u16 *temb = buf<u16>(e, "temb"), *emb_h = buf<u16>(e, "emb_h"), *emb_s = buf<u16>(e, "emb_s");
+  u16 *vec_t = buf<u16>(e, "vec_t"), *vec_g = buf<u16>(e, "vec_g"), *vec_y = buf<u16>(e, "vec_y");
+  u16 *vec = buf<u16>(e, "vec"), *svec = buf<u16>(e, "svec");
+  FLUXMI_TRY(fluxmi_k_timestep_embedding(t_vec, e->d_freqs, temb, B, 128, 1000.0f, s));
+  FLUXMI_TRY(small_linear(e, e->i_time_in, temb, 256, emb_h, H, 0, calib, trial, emb_s, s));
+  FLUXMI_TRY(small_linear(e, e->i_time_in + 1, emb_h, H, vec_t, H, 1, calib, trial, emb_s, s));
+  const u16* acc = vec_t;
+  if (e->d.guidance_embed) {
+    FLUXMI_REQUIRE(g_vec, "Didn't get guidance strength for guidance distilled model.");
+    FLUXMI_TRY(fluxmi_k_timestep_embedding(g_vec, e->d_freqs, temb, B, 128, 1000.0f, s));
+    FLUXMI_TRY(small_linear(e, e->i_guid_in, temb, 256, emb_h, H, 0, calib, trial, emb_s, s));
+    FLUXMI_TRY(small_linear(e, e->i_guid_in + 1, emb_h, H, vec_g, H, 1, calib, trial, emb_s, s));
+    FLUXMI_TRY(fluxmi_k_add(vec_t, vec_g, vec, (long long)B * H, s));
+    acc = vec;
+  }
+  FLUXMI_TRY(small_linear(e, e->i_vec_in, y, e->d.vec_in, emb_h, H, 0, calib, trial, emb_s, s));
+  FLUXMI_TRY(small_linear(e, e->i_vec_in + 1, emb_h, H, vec_y, H, 1, calib, trial, emb_s, s));
+  FLUXMI_TRY(fluxmi_k_add(acc, vec_y, vec, (long long)B * H, s));
+  // silu(vec) feeds every Modulation.lin and LastLayer.adaLN_modulation
+  FLUXMI_TRY(fluxmi_k_act(vec, svec, B, H, H, H, 1, s));
+  if (calib && !e->h_calib_mod.empty()) {
+    FLUXMI_CHECK_HIP(hipMemsetAsync(e->d_amax, 0, sizeof(float), s));
+    FLUXMI_TRY(fluxmi_k_amax(svec, e->d_amax, B, H, H, s));
+    FLUXMI_TRY(fluxmi_k_calib_update_many(e->d_amax, e->d_calib_mod, (int)e->h_calib_mod.size(), trial, e->d.num_trials, 57344.f, s));
+  }
+  return fluxmi_launch_gemv(e->d_gemv, nullptr, (int)e->h_gemv.size(), B, e->gemv_blocks, e->gemv_maxK, s);
+}
+
+int embed_txt(E* e, const u16* txt, bool calib, int trial, u16* dst, long long dst_bstride, hipStream_t s) {
+  const int H = e->d.hidden, B = e->B, Lt = e->Lt, C = e->d.ctx_in;
+  const fluxmi_linear_t& l = e->lin[e->i_txt_in];
+  uint8_t* in8 = buf<uint8_t>(e, "in8");
+  FLUXMI_TRY(stage_input(e, e->i_txt_in, calib, trial, txt, C, 0, in8, C, 0, 1, B * Lt, C, s));
+  std::vector<FluxmiGemmGroup> gs;
+  for (int b = 0; b < B; ++b)
+    gs.push_back(mk_group(l, l.kind ? (const void*)(in8 + (long long)b * Lt * C) : (const void*)(txt + (long long)b * Lt * C), C,
+                          dst + b * dst_bstride, H, Lt));
+  return run_gemm(gs, H, C, l.kind, l.in_fmt, FLUXMI_EPI_BF16, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* t_vec, const u16* g_vec, u16* pred, int mode,
+                 int trial, bool txt_cached, hipStream_t s) {
+  const int H = e->d.hidden, Hm = e->d.mlp_hidden, B = e->B, L = e->L, Lt = e->Lt, Li = e->Li, heads = e->d.heads;
+  const bool fused = mode == 1, calib = mode == 0;
+  const long long XB = (long long)L * H;  // batch stride of x
+  u16* x = buf<u16>(e, "x");
+  u16 *mod = buf<u16>(e, "mod"), *qkv = buf<u16>(e, "qkv"), *Q = buf<u16>(e, "Q"), *K = buf<u16>(e, "K"), *VT = buf<u16>(e, "VT");
+  u16 *pe = buf<u16>(e, "pe"), *abf = buf<u16>(e, "abf"), *catbf = buf<u16>(e, "catbf"), *hbf = buf<u16>(e, "hbf");
+  u16 *attnbf = buf<u16>(e, "attnbf"), *fin = buf<u16>(e, "fin");
+  uint8_t *a8 = buf<uint8_t>(e, "a8"), *attn8 = buf<uint8_t>(e, "attn8"), *h8 = buf<uint8_t>(e, "h8"), *cat8 = buf<uint8_t>(e, "cat8");
+  uint8_t* in8 = buf<uint8_t>(e, "in8");
+  const long long MC = e->mod_cols;
+
+  if (fused) {
+    for (int i = 0; i < e->d.depth; ++i)
+      for (int sl : {D_IMG_QKV, D_IMG_PROJ, D_IMG_MLP0, D_IMG_MLP2, D_TXT_QKV, D_TXT_PROJ, D_TXT_MLP0, D_TXT_MLP2})
+        FLUXMI_REQUIRE(DL(e, i, sl).kind == 1, "fused mode needs every block linear to be F8Linear (double block %d)", i);
+    for (int i = 0; i < e->d.depth_single; ++i)
+      FLUXMI_REQUIRE(SL(e, i, S_LIN1).kind == 1 && SL(e, i, S_LIN2).kind == 1, "fused mode needs F8Linear in single block %d", i);
+  }
+
+  // ---- img_in / txt_in                                                             flux_model.py:686,699
+  {
+    const fluxmi_linear_t& l = e->lin[e->i_img_in];
+    const int C = e->d.in_channels;
+    FLUXMI_TRY(stage_input(e, e->i_img_in, calib, trial, img, C, 0, in8, C, 0, 1, B * Li, C, s));
+    std::vector<FluxmiGemmGroup> gs;
+    for (int b = 0; b < B; ++b)
+      gs.push_back(mk_group(l, l.kind ? (const void*)(in8 + (long long)b * Li * C) : (const void*)(img + (long long)b * Li * C), C,
+                            x + b * XB + (long long)Lt * H, H, Li));
+    FLUXMI_TRY(run_gemm(gs, H, C, l.kind, l.in_fmt, FLUXMI_EPI_BF16, s));
+  }
+  if (txt_cached) {
+    FLUXMI_CHECK_HIP(hipMemcpy2DAsync(x, XB * 2, buf<u16>(e, "txt_emb"), (size_t)Lt * H * 2, (size_t)Lt * H * 2, B, hipMemcpyDeviceToDevice, s));
+  } else {
+    FLUXMI_TRY(embed_txt(e, txt, calib, trial, x, XB, s));
+  }
+  FLUXMI_TRY(compute_vec_and_mods(e, t_vec, g_vec, y, calib, trial, s));
+
+  // ---- double blocks                                                              flux_model.py:356-400
+  for (int i = 0; i < e->d.depth; ++i) {
+    const u16* mi = mod + (long long)i * 12 * H;  // img: shift1 scale1 gate1 shift2 scale2 gate2
+    const u16* mt = mi + 6 * H;                   // txt
+    const int li_q[2] = {DLi(e, i, D_TXT_QKV), DLi(e, i, D_IMG_QKV)};
+    const int li_p[2] = {DLi(e, i, D_TXT_PROJ), DLi(e, i, D_IMG_PROJ)};
+    const int li_m0[2] = {DLi(e, i, D_TXT_MLP0), DLi(e, i, D_IMG_MLP0)};
+    const int li_m2[2] = {DLi(e, i, D_TXT_MLP2), DLi(e, i, D_IMG_MLP2)};
+    const u16* mods[2] = {mt, mi};
+    const int roff[2] = {0, Lt}, rows[2] = {Lt, Li};
+    const void* const* ns = &e->norm[i * 4];  // img q, img k, txt q, txt k
+
+    // -- attention half -------------------------------------------------------------------------
+    for (int half = 0; half < 2; ++half) {
+      const int so = half * 3;  // offset of (shift, scale, gate) triple inside the 6H chunk
+      const int* li_in = half == 0 ? li_q : li_m0;
+      if (fused) {
+        FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, mt + so * H, mt + (so + 1) * H, mi + so * H, mi + (so + 1) * H, MC,
+                                        e->lin[li_in[0]].in_scale, e->lin[li_in[1]].in_scale, B, L, Lt, H, 1, e->lin[li_in[0]].in_fmt, s));
+      } else {
+        FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, mt + so * H, mt + (so + 1) * H, mi + so * H, mi + (so + 1) * H, MC, nullptr,
+                                        nullptr, B, L, Lt, H, 0, 0, s));
+        for (int st = 0; st < 2; ++st)
+          FLUXMI_TRY(stage_input(e, li_in[st], calib, trial, abf + (long long)roff[st] * H, H, XB, a8 + (long long)roff[st] * H, H, XB, B,
+                                 rows[st], H, s));
+      }
+      if (half == 0) {
+        // qkv GEMM (both streams, all batch elements in one grouped launch)
+        std::vector<FluxmiGemmGroup> gs;
+        for (int b = 0; b < B; ++b)
+          for (int st = 0; st < 2; ++st) {
+            const fluxmi_linear_t& l = e->lin[li_q[st]];
+            const long long r0 = (long long)b * L + roff[st];
+            gs.push_back(mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H, qkv + r0 * 3 * H, 3 * H, rows[st]));
+          }
+        FLUXMI_TRY(run_gemm(gs, 3 * H, H, e->lin[li_q[0]].kind, e->lin[li_q[0]].in_fmt, FLUXMI_EPI_BF16, s));
+        FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], Q, K, VT, B, L, e->Lp, heads, Lt, s));
+        if (fused) {
+          FLUXMI_TRY(fluxmi_k_attention(Q, K, VT, attn8, H, 0, 1, e->lin[li_p[0]].in_scale, e->lin[li_p[1]].in_scale, Lt, B, L, e->Lp,
+                                        heads, e->lin[li_p[0]].in_fmt, s));
+        } else {
+          FLUXMI_TRY(fluxmi_k_attention(Q, K, VT, attnbf, H, 0, 0, nullptr, nullptr, Lt, B, L, e->Lp, heads, 0, s));
+          for (int st = 0; st < 2; ++st)
+            FLUXMI_TRY(stage_input(e, li_p[st], calib, trial, attnbf + (long long)roff[st] * H, H, XB, attn8 + (long long)roff[st] * H, H,
+                                   XB, B, rows[st], H, s));
+        }
+        // proj GEMM + gate1 * y + x
+        gs.clear();
+        for (int b = 0; b < B; ++b)
+          for (int st = 0; st < 2; ++st) {
+            const fluxmi_linear_t& l = e->lin[li_p[st]];
+            const long long r0 = (long long)b * L + roff[st];
+            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(attn8 + r0 * H) : (const void*)(attnbf + r0 * H), H, x + r0 * H, H, rows[st]);
+            g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 2 * H;
+            gs.push_back(g);
+          }
+        FLUXMI_TRY(run_gemm(gs, H, H, e->lin[li_p[0]].kind, e->lin[li_p[0]].in_fmt, FLUXMI_EPI_GATE_RESID, s));
+      } else {
+        // MLP: mlp.0 (+GELU, + quantise for mlp.2) then mlp.2 + gate2 * y + x
+        std::vector<FluxmiGemmGroup> gs;
+        for (int b = 0; b < B; ++b)
+          for (int st = 0; st < 2; ++st) {
+            const fluxmi_linear_t& l = e->lin[li_m0[st]];
+            const long long r0 = (long long)b * L + roff[st];
+            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H,
+                                         fused ? (void*)(h8 + r0 * Hm) : (void*)(hbf + r0 * Hm), Hm, rows[st]);
+            g.q_scale = e->lin[li_m2[st]].in_scale;
+            gs.push_back(g);
+          }
+        FLUXMI_TRY(run_gemm(gs, Hm, H, e->lin[li_m0[0]].kind, e->lin[li_m2[0]].in_fmt, fused ? FLUXMI_EPI_GELU_QUANT : FLUXMI_EPI_BF16, s));
+        if (!fused) {
+          FLUXMI_TRY(fluxmi_k_act(hbf, hbf, B * L, Hm, Hm, Hm, 0, s));
+          for (int st = 0; st < 2; ++st)
+            FLUXMI_TRY(stage_input(e, li_m2[st], calib, trial, hbf + (long long)roff[st] * Hm, Hm, (long long)L * Hm,
+                                   h8 + (long long)roff[st] * Hm, Hm, (long long)L * Hm, B, rows[st], Hm, s));
+        }
+        gs.clear();
+        for (int b = 0; b < B; ++b)
+          for (int st = 0; st < 2; ++st) {
+            const fluxmi_linear_t& l = e->lin[li_m2[st]];
+            const long long r0 = (long long)b * L + roff[st];
+            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(h8 + r0 * Hm) : (const void*)(hbf + r0 * Hm), Hm, x + r0 * H, H, rows[st]);
+            g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 5 * H;
+            gs.push_back(g);
+          }
+        FLUXMI_TRY(run_gemm(gs, H, Hm, e->lin[li_m2[0]].kind, e->lin[li_m2[0]].in_fmt, FLUXMI_EPI_GATE_RESID, s));
+      }
+    }
+  }
+
+  // ---- single blocks                                                              flux_model.py:467-485
+  const int HC = H + Hm;
+  for (int i = 0; i < e->d.depth_single; ++i) {
+    const u16* ms = mod + (long long)e->d.depth * 12 * H + (long long)i * 3 * H;  // shift scale gate
+    const int l1 = SLi(e, i, S_LIN1), l2 = SLi(e, i, S_LIN2);
+    const fluxmi_linear_t &L1 = e->lin[l1], &L2 = e->lin[l2];
+    const void* const* ns = &e->norm[e->d.depth * 4 + i * 2];
+    if (fused) {
+      FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, ms, ms + H, ms, ms + H, MC, L1.in_scale, L1.in_scale, B, L, L, H, 1, L1.in_fmt, s));
+      std::vector<FluxmiGemmGroup> gs;
+      FluxmiGemmGroup g = mk_group(L1, a8, H, qkv, 3 * H, B * L);
+      g.C2 = cat8; g.ldc2 = HC; g.split_n = 3 * H; g.c2_col0 = H; g.q_scale = L2.in_scale;
+      gs.push_back(g);
+      FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, 1, L2.in_fmt, FLUXMI_EPI_SPLIT, s));
+      FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], Q, K, VT, B, L, e->Lp, heads, L, s));
+      FLUXMI_TRY(fluxmi_k_attention(Q, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s));
+    } else {
+      u16* lin1 = buf<u16>(e, "lin1");
+      FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, ms, ms + H, ms, ms + H, MC, nullptr, nullptr, B, L, L, H, 0, 0, s));
+      FLUXMI_TRY(stage_input(e, l1, calib, trial, abf, H, 0, a8, H, 0, 1, B * L, H, s));
+      std::vector<FluxmiGemmGroup> gs;
+      gs.push_back(mk_group(L1, L1.kind ? (const void*)a8 : (const void*)abf, H, lin1, 3 * H + Hm, B * L));
+      FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, L1.kind, L1.in_fmt, FLUXMI_EPI_BF16, s));
+      FLUXMI_TRY(fluxmi_k_qkv_rope(lin1, 3 * H + Hm, pe, ns[0], ns[1], ns[0], ns[1], Q, K, VT, B, L, e->Lp, heads, L, s));
+      FLUXMI_TRY(fluxmi_k_attention(Q, K, VT, catbf, HC, 0, 0, nullptr, nullptr, L, B, L, e->Lp, heads, 0, s));
+      FLUXMI_TRY(fluxmi_k_act(lin1 + 3 * H, catbf + H, B * L, Hm, 3 * H + Hm, HC, 0, s));
+      FLUXMI_TRY(stage_input(e, l2, calib, trial, catbf, HC, 0, cat8, HC, 0, 1, B * L, HC, s));
+    }
+    std::vector<FluxmiGemmGroup> gs;
+    for (int b = 0; b < B; ++b) {
+      const long long r0 = (long long)b * L;
+      FluxmiGemmGroup g = mk_group(L2, L2.kind ? (const void*)(cat8 + r0 * HC) : (const void*)(catbf + r0 * HC), HC, x + r0 * H, H, L);
+      g.resid = x + r0 * H; g.ldr = H; g.gate = ms + (long long)b * MC + 2 * H;
+      gs.push_back(g);
+    }
+    FLUXMI_TRY(run_gemm(gs, H, HC, L2.kind, L2.in_fmt, FLUXMI_EPI_GATE_RESID, s));
+  }
+
+  // ---- final layer                                                                flux_model.py:499-503, 714-715
+  {
+    const u16* mf = mod + (long long)e->d.depth * 12 * H + (long long)e->d.depth_single * 3 * H;  // shift | scale
+    FLUXMI_TRY(fluxmi_k_ln_modulate(x + (long long)Lt * H, H, XB, fin, H, (long long)Li * H, mf, mf + H, mf, mf + H, MC, nullptr, nullptr, B,
+                                    Li, Li, H, 0, 0, s));
+    const fluxmi_linear_t& l = e->lin[e->i_final_lin];
+    std::vector<FluxmiGemmGroup> gs;
+    gs.push_back(mk_group(l, fin, H, pred, l.N, B * Li));
+    FLUXMI_TRY(run_gemm(gs, l.N, H, 0, 0, FLUXMI_EPI_BF16, s));
+  }
+  return 0;
+}
+
+void free_ws(E* e) {
+  if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+  e->graph_ok = false;
+  if (e->ws) { hipFree(e->ws); e->ws = nullptr; }
+  e->bufs.clear();
+  e->ws_bytes = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fluxmi_engine_num_linears(const fluxmi_model_desc_t* desc) { return desc ? lin_count(*desc) : -1; }
+
+int fluxmi_engine_create(const fluxmi_model_desc_t* desc, const fluxmi_linear_t* linears, int n_linears,
+                         const void* const* norm_scales, int n_norm_scales, fluxmi_engine_t** out) {
+  FLUXMI_REQUIRE(desc && linears && norm_scales && out, "engine_create: NULL argument");
+  FLUXMI_REQUIRE(desc->hidden == desc->heads * 128, "engine_create: head_dim must be 128 (hidden %d, heads %d)", desc->hidden, desc->heads);
+  FLUXMI_REQUIRE(desc->axes_dim[0] + desc->axes_dim[1] + desc->axes_dim[2] == 128, "engine_create: sum(axes_dim) must be 128");
+  FLUXMI_REQUIRE(n_linears == lin_count(*desc), "engine_create: expected %d linears, got %d", lin_count(*desc), n_linears);
+  FLUXMI_REQUIRE(n_norm_scales == desc->depth * 4 + desc->depth_single * 2, "engine_create: expected %d norm scales, got %d",
+                 desc->depth * 4 + desc->depth_single * 2, n_norm_scales);
+  FLUXMI_REQUIRE(desc->num_trials >= 1 && desc->num_trials <= 64, "engine_create: num_trials out of range");
+  E* e = new E();
+  e->d = *desc;
+  e->lin.assign(linears, linears + n_linears);
+  e->norm.assign(norm_scales, norm_scales + n_norm_scales);
+  int i = 0;
+  e->i_img_in = i++; e->i_time_in = i; i += 2; e->i_vec_in = i; i += 2;
+  e->i_guid_in = -1;
+  if (desc->guidance_embed) { e->i_guid_in = i; i += 2; }
+  e->i_txt_in = i++;
+  e->i_double0 = i; i += desc->depth * 10;
+  e->i_single0 = i; i += desc->depth_single * 3;
+  e->i_final_mod = i++; e->i_final_lin = i++;
+  const int H = desc->hidden;
+  e->mod_cols = (long long)desc->depth * 12 * H + (long long)desc->depth_single * 3 * H + 2 * H;
+  // constants block
+  const int n_mod = desc->depth * 2 + desc->depth_single + 1;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_freqs = carve(128 * 4), o_omega = carve(64 * 4), o_axis = carve(64 * 4), o_ts = carve((MAX_STEPS + 1) * 4),
+               o_dts = carve((MAX_STEPS + 1) * 4), o_step = carve(4), o_amax = carve((size_t)n_linears * 4),
+               o_gemv = carve(sizeof(FluxmiGemvLayer) * n_mod), o_cm = carve(sizeof(FluxmiCalibLayer) * n_mod);
+  if (hipMalloc((void**)&e->consts, off) != hipSuccess) { delete e; fluxmi_set_error("engine_create: hipMalloc(%zu) failed", off); return 2; }
+  e->d_freqs = (float*)(e->consts + o_freqs); e->d_omega = (float*)(e->consts + o_omega); e->d_axis = (int*)(e->consts + o_axis);
+  e->d_ts = (float*)(e->consts + o_ts); e->d_dts = (float*)(e->consts + o_dts); e->d_step = (int*)(e->consts + o_step);
+  e->d_amax = (float*)(e->consts + o_amax); e->d_gemv = (FluxmiGemvLayer*)(e->consts + o_gemv);
+  e->d_calib_mod = (FluxmiCalibLayer*)(e->consts + o_cm);
+  hipMemset(e->consts, 0, off);
+  *out = e;
+  return 0;
+}
+
+int fluxmi_engine_destroy(fluxmi_engine_t* e) {
+  if (!e) return 0;
+  free_ws(e);
+  if (e->consts) hipFree(e->consts);
+  delete e;
+  return 0;
+}
+
+int fluxmi_engine_rebind(fluxmi_engine_t* e, const fluxmi_linear_t* linears, int n_linears) {
+  FLUXMI_REQUIRE(e && linears && n_linears == (int)e->lin.size(), "engine_rebind: bad arguments");
+  e->lin.assign(linears, linears + n_linears);
+  e->graph_ok = false;
+  e->txt_emb_valid = false;
+  if (e->ws) return build_gemv_table(e, 0);
+  return 0;
+}
+
+// host_consts: [0,128) timestep freqs, [128,192) rope omega per pair, then 64 ints (axis per pair) -- computed by the host
+// with the reference's own torch expressions so that the tables are bit-identical (flux_model.py:50-51,106-110).
+int fluxmi_engine_set_tables(fluxmi_engine_t* e, const float* freqs128, const float* omega64, const int* axis64) {
+  FLUXMI_REQUIRE(e && freqs128 && omega64 && axis64, "engine_set_tables: NULL argument");
+  FLUXMI_CHECK_HIP(hipMemcpy(e->d_freqs, freqs128, 128 * 4, hipMemcpyHostToDevice));
+  FLUXMI_CHECK_HIP(hipMemcpy(e->d_omega, omega64, 64 * 4, hipMemcpyHostToDevice));
+  FLUXMI_CHECK_HIP(hipMemcpy(e->d_axis, axis64, 64 * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void* img_ids, const void* txt_ids, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  FLUXMI_REQUIRE(e && B >= 1 && B <= 8 && Li >= 1 && Lt >= 0, "engine_prepare: bad shape B=%d Li=%d Lt=%d (B must be 1..8)", B, Li, Lt);
+  FLUXMI_REQUIRE(img_ids && (Lt == 0 || txt_ids), "engine_prepare: NULL ids");
+  const int H = e->d.hidden, Hm = e->d.mlp_hidden, L = Li + Lt, Lp = ((L + 63) / 64) * 64;
+  if (B != e->B || Li != e->Li || Lt != e->Lt || !e->ws) {
+    FLUXMI_CHECK_HIP(hipStreamSynchronize(s));
+    free_ws(e);
+    e->B = B; e->Li = Li; e->Lt = Lt; e->L = L; e->Lp = Lp;
+    struct Item { const char* name; size_t bytes; };
+    const size_t BL = (size_t)B * L;
+    const size_t in8 = std::max((size_t)B * Li * e->d.in_channels, (size_t)B * Lt * e->d.ctx_in);
+    std::vector<Item> items = {
+        {"x", BL * H * 2}, {"a8", BL * H}, {"attn8", BL * H}, {"qkv", BL * 3 * H * 2}, {"Q", BL * H * 2}, {"K", BL * H * 2},
+        {"VT", (size_t)B * H * Lp * 2}, {"h8", BL * Hm}, {"cat8", BL * (H + Hm)}, {"pe", BL * 64 * 2 * 2},
+        {"mod", (size_t)B * e->mod_cols * 2}, {"fin", (size_t)B * Li * H * 2},
+        // unfused-path temporaries
+        {"abf", BL * H * 2}, {"attnbf", BL * H * 2}, {"hbf", BL * Hm * 2}, {"catbf", BL * (H + Hm) * 2}, {"lin1", BL * (3 * H + Hm) * 2},
+        {"in8", in8},
+        // small
+        {"vec", (size_t)B * H * 2}, {"svec", (size_t)B * H * 2}, {"temb", (size_t)B * 256 * 2}, {"emb_h", (size_t)B * H * 2},
+        {"emb_s", (size_t)B * std::max(H, 1024) * 2}, {"vec_t", (size_t)B * H * 2}, {"vec_g", (size_t)B * H * 2}, {"vec_y", (size_t)B * H * 2},
+        {"tvec", 256}, {"gvec", 256}, {"ids", BL * 3 * 2},
+        // static request buffers (make the captured graph independent of caller pointers)
+        {"img_s", (size_t)B * Li * e->d.in_channels * 2}, {"txt_s", (size_t)B * Lt * e->d.ctx_in * 2}, {"y_s", (size_t)B * e->d.vec_in * 2},
+        {"pred_s", (size_t)B * Li * e->d.in_channels * 2}, {"txt_emb", (size_t)B * Lt * H * 2},
+    };
+    size_t total = 0;
+    for (auto& it : items) total += (it.bytes + 255) & ~(size_t)255;
+    if (hipMalloc((void**)&e->ws, total) != hipSuccess) {
+      fluxmi_set_error("engine_prepare: hipMalloc(%zu bytes) failed", total);
+      return 2;
+    }
+    e->ws_bytes = total;
+    FLUXMI_CHECK_HIP(hipMemsetAsync(e->ws, 0, total, s));
+    size_t off = 0;
+    for (auto& it : items) {
+      e->bufs[it.name] = Buf{e->ws + off, it.bytes};
+      off += (it.bytes + 255) & ~(size_t)255;
+    }
+    FLUXMI_TRY(build_gemv_table(e, s));
+  }
+  // ids = cat(txt_ids, img_ids) per batch element; pe table                              flux_model.py:701-702
+  u16* ids = buf<u16>(e, "ids");
+  if (Lt > 0)
+    FLUXMI_CHECK_HIP(hipMemcpy2DAsync(ids, (size_t)L * 6, txt_ids, (size_t)Lt * 6, (size_t)Lt * 6, B, hipMemcpyDeviceToDevice, s));
+  FLUXMI_CHECK_HIP(hipMemcpy2DAsync(ids + (size_t)Lt * 3, (size_t)L * 6, img_ids, (size_t)Li * 6, (size_t)Li * 6, B, hipMemcpyDeviceToDevice, s));
+  FLUXMI_TRY(fluxmi_k_rope_table(ids, e->d_omega, e->d_axis, buf<u16>(e, "pe"), (long long)B * L, 3, 64, s));
+  e->txt_emb_valid = false;
+  return 0;
+}
+
+int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, const void* y, const void* timesteps,
+                          const void* guidance, void* pred, int mode, int trial_index, void* stream) {
+  FLUXMI_REQUIRE(e && e->ws, "engine_forward: call fluxmi_engine_prepare first");
+  FLUXMI_REQUIRE(img && txt && y && timesteps && pred, "engine_forward: NULL tensor");
+  FLUXMI_REQUIRE(mode >= 0 && mode <= 2, "engine_forward: bad mode %d", mode);
+  if (mode == 0) FLUXMI_REQUIRE(trial_index >= 0 && trial_index <= e->d.num_trials, "engine_forward: trial_index %d out of range", trial_index);
+  return forward_impl(e, (const u16*)img, (const u16*)txt, (const u16*)y, (const u16*)timesteps, (const u16*)guidance, (u16*)pred,
+                      mode, trial_index, false, (hipStream_t)stream);
+}
+
+static u16 host_f2bf(double v) {
+  float f = (float)v;
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+
+int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const void* y, float guidance,
+                          const double* timesteps_host, int n_steps, int* trial_index_inout, int use_graph, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  FLUXMI_REQUIRE(e && e->ws, "engine_denoise: call fluxmi_engine_prepare first");
+  FLUXMI_REQUIRE(img && txt && y && timesteps_host && trial_index_inout, "engine_denoise: NULL argument");
+  FLUXMI_REQUIRE(n_steps >= 0 && n_steps <= MAX_STEPS, "engine_denoise: n_steps=%d out of range", n_steps);
+  const int B = e->B, Li = e->Li, Lt = e->Lt, C = e->d.in_channels;
+  // any bf16 block linear -> the fused path is unavailable, run unfused-frozen (mode 2)
+  bool all_f8 = true;
+  for (int i = e->i_double0; i < e->i_final_mod; ++i) {
+    const int rel = i < e->i_single0 ? (i - e->i_double0) % 10 : -1;
+    const bool is_mod = (i < e->i_single0) ? (rel == D_IMG_MOD || rel == D_TXT_MOD) : ((i - e->i_single0) % 3 == S_MOD);
+    if (!is_mod && !e->lin[i].kind) all_f8 = false;
+  }
+  bool any_f8 = false;
+  for (auto& l : e->lin) any_f8 |= (l.kind != 0);
+
+  std::vector<float> ts(n_steps + 1), dts(n_steps + 1, 0.f);
+  for (int i = 0; i <= n_steps; ++i) ts[i] = (float)timesteps_host[i];
+  for (int i = 0; i < n_steps; ++i) dts[i] = (float)(timesteps_host[i + 1] - timesteps_host[i]);
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(e->d_ts, ts.data(), (n_steps + 1) * 4, hipMemcpyHostToDevice, s));
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(e->d_dts, dts.data(), (n_steps + 1) * 4, hipMemcpyHostToDevice, s));
+  u16 gv[64];
+  for (int b = 0; b < B; ++b) gv[b] = host_f2bf((double)guidance);
+  u16 *gvec = buf<u16>(e, "gvec"), *tvec = buf<u16>(e, "tvec");
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(gvec, gv, B * 2, hipMemcpyHostToDevice, s));
+  FLUXMI_CHECK_HIP(hipMemsetAsync(e->d_step, 0, 4, s));
+  u16 *img_s = buf<u16>(e, "img_s"), *txt_s = buf<u16>(e, "txt_s"), *y_s = buf<u16>(e, "y_s"), *pred_s = buf<u16>(e, "pred_s");
+  const long long n_img = (long long)B * Li * C;
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(img_s, img, n_img * 2, hipMemcpyDeviceToDevice, s));
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(txt_s, txt, (size_t)B * Lt * e->d.ctx_in * 2, hipMemcpyDeviceToDevice, s));
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(y_s, y, (size_t)B * e->d.vec_in * 2, hipMemcpyDeviceToDevice, s));
+  FLUXMI_CHECK_HIP(hipStreamSynchronize(s));  // host staging buffers (ts, dts, gv) go out of scope below
+
+  int trial = *trial_index_inout;
+  int step = 0;
+  const u16* g_arg = e->d.guidance_embed ? gvec : nullptr;
+  // -- calibrating steps: the reference's first num_trials+1 calls of every F8Linear ----------------------
+  while (step < n_steps && any_f8 && trial <= e->d.num_trials) {
+    FLUXMI_TRY(fluxmi_k_set_timestep(tvec, e->d_ts, e->d_step, B, s));
+    FLUXMI_TRY(forward_impl(e, img_s, txt_s, y_s, tvec, g_arg, pred_s, 0, trial, false, s));
+    FLUXMI_TRY(fluxmi_k_euler(img_s, pred_s, e->d_dts, e->d_step, n_img, s));
+    FLUXMI_TRY(fluxmi_k_advance_step(e->d_step, s));
+    ++trial; ++step;
+  }
+  // -- frozen steps -------------------------------------------------------------------------------------------
+  if (step < n_steps) {
+    const int mode = all_f8 ? 1 : 2;
+    if (mode == 1) {
+      FLUXMI_TRY(embed_txt(e, txt_s, false, 0, buf<u16>(e, "txt_emb"), (long long)Lt * e->d.hidden, s));
+      e->txt_emb_valid = true;
+    }
+    auto one_step = [&](hipStream_t st) -> int {
+      FLUXMI_TRY(fluxmi_k_set_timestep(tvec, e->d_ts, e->d_step, B, st));
+      FLUXMI_TRY(forward_impl(e, img_s, txt_s, y_s, tvec, g_arg, pred_s, mode, 0, mode == 1, st));
+      FLUXMI_TRY(fluxmi_k_euler(img_s, pred_s, e->d_dts, e->d_step, n_img, st));
+      return fluxmi_k_advance_step(e->d_step, st);
+    };
+    if (use_graph && !e->graph_ok) {
+      // the first frozen step runs eagerly so that every lazy one-time init (function attributes) happens outside capture
+      FLUXMI_TRY(one_step(s));
+      ++step;
+    }
+    if (use_graph && step < n_steps) {
+      if (!e->graph_ok) {
+        hipStream_t cs;
+        FLUXMI_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        FLUXMI_CHECK_HIP(hipStreamSynchronize(s));
+        hipGraph_t graph = nullptr;
+        FLUXMI_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int rc = one_step(cs);
+        hipError_t ce = hipStreamEndCapture(cs, &graph);
+        if (rc || ce != hipSuccess) {
+          if (graph) hipGraphDestroy(graph);
+          hipStreamDestroy(cs);
+          if (!rc) fluxmi_set_error("engine_denoise: hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+          return rc ? rc : 2;
+        }
+        if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+        hipError_t ie = hipGraphInstantiate(&e->exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        hipStreamDestroy(cs);
+        if (ie != hipSuccess) { fluxmi_set_error("engine_denoise: hipGraphInstantiate failed: %s", hipGetErrorString(ie)); return 2; }
+        e->graph_ok = true;
+      }
+      for (; step < n_steps; ++step) FLUXMI_CHECK_HIP(hipGraphLaunch(e->exec, s));
+    } else {
+      for (; step < n_steps; ++step) FLUXMI_TRY(one_step(s));
+    }
+  }
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(img, img_s, n_img * 2, hipMemcpyDeviceToDevice, s));
+  *trial_index_inout = trial;
+  return 0;
+}
+
+int fluxmi_engine_workspace_bytes(fluxmi_engine_t* e, long long* bytes) {
+  FLUXMI_REQUIRE(e && bytes, "engine_workspace_bytes: NULL argument");
+  *bytes = (long long)e->ws_bytes;
+  return 0;
+}
+
+int fluxmi_engine_get_buffer(fluxmi_engine_t* e, const char* name, void** ptr, long long* bytes) {
+  FLUXMI_REQUIRE(e && name && ptr, "engine_get_buffer: NULL argument");
+  auto it = e->bufs.find(name);
+  FLUXMI_REQUIRE(it != e->bufs.end(), "engine_get_buffer: no buffer named '%s'", name);
+  *ptr = it->second.p;
+  if (bytes) *bytes = (long long)it->second.n;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// fluxmi -- internal launch descriptors shared by the kernels, the C-ABI layer and the engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fluxmi.h"
+
+typedef fluxmi_gemm_group_t FluxmiGemmGroup;
+
+#define FLUXMI_MAX_GROUPS 16
+struct FluxmiGemmParams {
+  FluxmiGemmGroup g[FLUXMI_MAX_GROUPS];
+  int n_groups, N, K, epi, tiles_m_total, group_m;
+};
+
+// ---- batched skinny GEMV (modulations + embedders, M = batch <= 8) ----------------------------
+struct FluxmiGemvLayer {
+  const void* W;           // [N,K] fp8 or bf16
+  const void* bias;        // bf16 [N] or nullptr
+  const float* in_scale;   // fp8: device scalar input_scale
+  const float* sa_recip;   // fp8
+  const float* sb_recip;   // fp8
+  void* out;               // bf16, row b at out + b*ld_out
+  const void* x;           // bf16 [B,K] (row stride ldx)
+  long long ld_out, ldx;
+  int N, K;
+  int w_fp8;               // 1: fp8 weights (x quantised on the fly), 0: bf16 weights
+  int pre_silu;            // apply SiLU (rounded to bf16) to x first        flux_model.py:252,155,496
+  int blk_start;           // first block id of this layer (filled by launcher)
+  int act_fmt;
+};
+
+struct FluxmiCalibLayer { float* trials; float* scale; float* recip; };
+
+// ---- misc ------------------------------------------------------------------------------------
+void fluxmi_set_error(const char* fmt, ...);
+#define FLUXMI_CHECK_HIP(expr)                                                            \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      fluxmi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return 2;                                                                           \
+    }                                                                                     \
+  } while (0)
+#define FLUXMI_REQUIRE(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      fluxmi_set_error(__VA_ARGS__);         \
+      return 1;                              \
+    }                                        \
+  } while (0)
+#define FLUXMI_LAUNCH_CHECK() FLUXMI_CHECK_HIP(hipGetLastError())
+#define FLUXMI_TRY(expr)        \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc) return _rc;        \
+  } while (0)
+
+// ---- internal launchers (defined in the .hip files) --------------------------------------------
+int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg);
+int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int tile_cfg, hipStream_t s);
+int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
+int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8);
+int fluxmi_launch_gemv(const FluxmiGemvLayer* layers_dev, FluxmiGemvLayer* layers_host, int n_layers, int B, int total_blocks,
+                       int max_K, hipStream_t s);
+int fluxmi_gemv_blocks(const FluxmiGemvLayer* layers_host, int n_layers);
+
+int fluxmi_k_quantize_act(const void* x, void* q, const float* scale, int rows, int cols, long long ld_in, long long ld_out, int fmt, hipStream_t s);
+int fluxmi_k_amax(const void* x, float* amax, int rows, int cols, long long ld, hipStream_t s);
+int fluxmi_k_calib_update(const float* amax, float* trials, float* scale, float* recip, int trial_index, int num_trials, float max_val, hipStream_t s);
+int fluxmi_k_calib_update_many(const float* amax, const void* layers_dev, int n_layers, int trial_index, int num_trials, float max_val, hipStream_t s);
+int fluxmi_k_quantize_weight(const void* w_bf16, void* q, float* amax_tmp, float* scale, float* recip, int N, int K, int fmt, hipStream_t s);
+int fluxmi_k_dequant(const void* q, float* out, const float* recip, long long n, int fmt, hipStream_t s);
+int fluxmi_k_requantize_f32(const float* w32, void* q, float* amax_tmp, float* scale, float* recip, long long n, int fmt, hipStream_t s);
+int fluxmi_k_lora_delta(const float* Bm, const float* A, float* delta, int N, int K, int R, float scale, int accumulate, hipStream_t s);
+int fluxmi_k_axpy_f32(float* w, const float* d, float alpha, long long n, hipStream_t s);
+int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void* out, long long ldo, long long out_bstride,
+                         const void* shift0, const void* scale0, const void* shift1, const void* scale1, long long mod_bstride,
+                         const float* q0, const float* q1, int B, int L, int split, int H, int out_fp8, int fmt, hipStream_t s);
+int fluxmi_k_act(const void* x, void* y, int rows, int cols, long long ld_in, long long ld_out, int mode, hipStream_t s);
+int fluxmi_k_gate_residual(const void* x, const void* y, const void* gate, void* out, int B, int L, int H, long long ldx,
+                           long long ldy, long long ldo, long long gate_bstride, hipStream_t s);
+int fluxmi_k_add(const void* a, const void* b, void* z, long long n, hipStream_t s);
+int fluxmi_k_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, hipStream_t s);
+int fluxmi_k_rope_table(const void* ids, const float* omega, const int* axis, void* pe, long long rows, int n_axes, int pairs, hipStream_t s);
+int fluxmi_k_euler(void* img, const void* pred, const float* dts, const int* step, long long n, hipStream_t s);
+int fluxmi_k_set_timestep(void* t_vec, const float* ts, const int* step, int B, hipStream_t s);
+int fluxmi_k_advance_step(int* step, hipStream_t s);
+int fluxmi_k_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0,
+                      const void* q_scale1, const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H,
+                      int split, hipStream_t s);
+int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
+                       const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, hipStream_t s);

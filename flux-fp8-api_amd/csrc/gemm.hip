@@ -1,0 +1,393 @@
+// fluxmi -- grouped F8Linear / Linear GEMM for gfx950 (CDNA4).
+//
+// Replaces torch._scaled_mm as called by F8Linear.forward (reference float8_quantize.py:284-292):
+//     out[M,N] = bf16( (A_e5m2[M,K] . W_e4m3[N,K]^T) * (1/in_scale)*(1/w_scale) + bias )
+// and the surrounding eager elementwise ops (GELU / gate*y+x / next-layer quantise) as epilogues.
+//
+// Design (MI355X-first):
+//  * fp8 runs on the MX-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with all E8M0 block scales = 2^0
+//    (0x7F): the only opcode family that reaches the ~5 PF dense fp8 rate on gfx950; the real
+//    per-tensor scales are applied in the epilogue.  bf16 layers use v_mfma_f32_32x32x16_bf16 through
+//    the same byte-level pipeline (a K-step is 128 BYTES of every row for both dtypes).
+//  * operands are swapped: MFMA "A" = weight rows (n), MFMA "B" = activation rows (m), so that a lane
+//    ends up with 4 consecutive output columns n of one row m -> packed 8 B (bf16) / 4 B (fp8) stores
+//    and per-lane bias/gate vectors.
+//  * global -> LDS by LDS-DMA (global_load_lds, 16 B/lane), double buffered, one barrier per K-step.
+//    The LDS image is lane-linear, so the bank-conflict XOR swizzle (16-B slot ^= (row>>1)&7) is
+//    applied on the per-lane SOURCE address and again on the ds_read_b128 address.
+//  * 1-D grid, XCD-aware bijective remap + grouped (GROUP_M) rasterisation so the 32 tiles resident
+//    on one XCD share A/W panels through that XCD's private 4 MiB L2.
+//  * grouped launch: up to 16 independent problems (txt/img streams x batch) sharing N,K in one grid.
+#include "common.h"
+#include "fluxmi_internal.h"
+
+namespace {
+
+template <int CNT> __device__ __forceinline__ void load_bf(const void* base, long long idx, float* out) {
+  const u16* p = (const u16*)base + idx;
+  if constexpr (CNT == 4) {
+    uint2 v = *(const uint2*)p;
+    out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+    out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+  } else {
+    out[0] = bf2f(p[0]);
+  }
+}
+template <int CNT> __device__ __forceinline__ void store_bf(void* base, long long idx, const float* v) {
+  u16* p = (u16*)base + idx;
+  if constexpr (CNT == 4) {
+    uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+    *(uint2*)p = o;
+  } else {
+    p[0] = f2bf(v[0]);
+  }
+}
+template <int FMT, int CNT> __device__ __forceinline__ void store_q(void* base, long long idx, const float* v, float qs) {
+  unsigned char* p = (unsigned char*)base + idx;
+  if constexpr (CNT == 4) {
+    *(unsigned*)p = cvt4_fp8<FMT>(q_prepare<FMT>(v[0], qs), q_prepare<FMT>(v[1], qs),
+                                  q_prepare<FMT>(v[2], qs), q_prepare<FMT>(v[3], qs));
+  } else {
+    p[0] = (unsigned char)(cvt2_fp8<FMT>(q_prepare<FMT>(v[0], qs), 0.f) & 0xff);
+  }
+}
+
+// h = bf16(acc*s + bias) already applied by the caller; h holds CNT consecutive columns n..n+CNT-1 of row m
+template <int EPI, int FMT, int CNT>
+__device__ __forceinline__ void epilogue(const FluxmiGemmGroup& G, float qs, int m, int n,
+                                         const float* h, const float* gate) {
+  if constexpr (EPI == FLUXMI_EPI_SPLIT) {
+    if (n < G.split_n) {
+      store_bf<CNT>(G.C, (long long)m * G.ldc + n, h);
+    } else {
+      float g[CNT];
+#pragma unroll
+      for (int j = 0; j < CNT; ++j) g[j] = rbf(gelu_tanh_f(h[j]));
+      store_q<FMT, CNT>(G.C2, (long long)m * G.ldc2 + G.c2_col0 + (n - G.split_n), g, qs);
+    }
+  } else if constexpr (EPI == FLUXMI_EPI_BF16) {
+    store_bf<CNT>(G.C, (long long)m * G.ldc + n, h);
+  } else if constexpr (EPI == FLUXMI_EPI_GELU_QUANT) {
+    float g[CNT];
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) g[j] = rbf(gelu_tanh_f(h[j]));
+    store_q<FMT, CNT>(G.C, (long long)m * G.ldc + n, g, qs);
+  } else if constexpr (EPI == FLUXMI_EPI_SILU_QUANT) {
+    float g[CNT];
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) g[j] = rbf(silu_f(h[j]));
+    store_q<FMT, CNT>(G.C, (long long)m * G.ldc + n, g, qs);
+  } else if constexpr (EPI == FLUXMI_EPI_QUANT) {
+    store_q<FMT, CNT>(G.C, (long long)m * G.ldc + n, h, qs);
+  } else if constexpr (EPI == FLUXMI_EPI_GATE_RESID) {
+    float r[CNT], o[CNT];
+    load_bf<CNT>(G.resid, (long long)m * G.ldr + n, r);
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) o[j] = r[j] + rbf(gate[j] * h[j]);
+    store_bf<CNT>(G.C, (long long)m * G.ldc + n, o);
+  }
+}
+
+__device__ __forceinline__ float load_scale(const float* p) { return p ? *p : 1.0f; }
+
+// Per-wave epilogue over its TM x TN grid of 32x32 accumulator tiles.  Lane (l31, hi) owns row
+// m = mrow0 + 32*i and columns n = ncol0 + 32*j + 8*g4 + [0,4)  (C/D layout of the 32x32 MFMA with
+// weights as the A operand: i_row = (reg&3) + 8*(reg>>2) + 4*hi -> n, column = lane&31 -> m).
+template <int EPI, int FMT, int TM, int TN>
+__device__ __forceinline__ void tile_epilogue(const FluxmiGemmGroup& G, v16f (&acc)[TM][TN], float s, float qs,
+                                              int mrow0, int ncol0, int M) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int n = ncol0 + j * 32 + g4 * 8;
+      float bias[4] = {0.f, 0.f, 0.f, 0.f}, gate[4] = {0.f, 0.f, 0.f, 0.f};
+      if (G.bias) load_bf<4>(G.bias, n, bias);
+      if constexpr (EPI == FLUXMI_EPI_GATE_RESID) load_bf<4>(G.gate, n, gate);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = mrow0 + i * 32;
+        if (m < M) {
+          float h[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = rbf(fmaf(acc[i][j][g4 * 4 + e], s, bias[e]));
+          epilogue<EPI, FMT, 4>(G, qs, m, n, h, gate);
+        }
+      }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// tiled MFMA kernel
+// -------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool FP8, int ACT_FMT>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_tile_kernel(const FluxmiGemmParams P) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+  constexpr int IA = (BM * 8) / NT, IW = (BN * 8) / NT;  // 16-B slots per thread per K-step
+  constexpr int EB = FP8 ? 1 : 2;
+  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/threads mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // ---- block -> (problem, m-tile, n-tile) ------------------------------------------------------
+  const int tiles_n = P.N / BN;
+  const int nblk = P.tiles_m_total * tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nblk);
+  const int width = P.group_m * tiles_n;
+  const int first_m = (lid / width) * P.group_m;
+  const int gsz = min(P.tiles_m_total - first_m, P.group_m);
+  const int tm = first_m + (lid % width) % gsz;
+  const int tn = (lid % width) / gsz;
+  int gi = 0;
+  for (int i = 1; i < P.n_groups; ++i) gi = (tm >= P.g[i].m_tile_start) ? i : gi;
+  const FluxmiGemmGroup& G = P.g[gi];
+  const int M = G.M;
+  const int m0 = (tm - G.m_tile_start) * BM;
+  const int n0 = tn * BN;
+  const int nk = (P.K * EB) / 128;
+
+  // ---- per-thread LDS-DMA source pointers (swizzle on the source side) -------------------------
+  const unsigned char* srcA[IA];
+  const unsigned char* srcW[IW];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int p = tid + NT * i, row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
+    const int gr = min(m0 + row, M - 1);
+    srcA[i] = (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < IW; ++i) {
+    const int p = tid + NT * i, row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
+    srcW[i] = (const unsigned char*)G.W + ((long long)(n0 + row) * P.K) * EB + slot * 16;
+  }
+  auto stage = [&](int buf, int kt) {
+    unsigned char* dA = smem + buf * STAGE + wave * 1024;
+    unsigned char* dW = dA + A_BYTES;
+    const long long koff = (long long)kt * 128;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) glds16(srcA[i] + koff, dA + NT * 16 * i);
+#pragma unroll
+    for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, dW + NT * 16 * i);
+  };
+
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment row offsets (bytes) and swizzle keys
+  int a_off[TM], a_sw[TM], w_off[TN], w_sw[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * WTM + i * 32 + l31;
+    a_off[i] = r * 128; a_sw[i] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int r = wn * WTN + j * 32 + l31;
+    w_off[j] = A_BYTES + r * 128; w_sw[j] = (r >> 1) & 7;
+  }
+
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const unsigned char* sb = smem + (kt & 1) * STAGE;
+    if constexpr (FP8) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int s0 = kk * 4 + hi * 2;
+        v8i fa[TM], fw[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const v4i lo = *(const v4i*)(sb + a_off[i] + (((s0) ^ a_sw[i]) << 4));
+          const v4i hi4 = *(const v4i*)(sb + a_off[i] + (((s0 + 1) ^ a_sw[i]) << 4));
+          fa[i] = (v8i){lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const v4i lo = *(const v4i*)(sb + w_off[j] + (((s0) ^ w_sw[j]) << 4));
+          const v4i hi4 = *(const v4i*)(sb + w_off[j] + (((s0 + 1) ^ w_sw[j]) << 4));
+          fw[j] = (v8i){lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                fw[j], fa[i], acc[i][j], FLUXMI_FMT_E4M3 /*A = weights*/, ACT_FMT /*B = activations*/,
+                0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int s0 = kk * 2 + hi;
+        v8bf fa[TM], fw[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *(const v8bf*)(sb + a_off[i] + ((s0 ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fw[j] = *(const v8bf*)(sb + w_off[j] + ((s0 ^ w_sw[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  const float s = load_scale(G.sa_recip) * load_scale(G.sb_recip);
+  const float qs = G.q_scale ? *G.q_scale : 1.0f;
+  const int mrow0 = m0 + wm * WTM + l31, ncol0 = n0 + wn * WTN + hi * 4;
+  switch (P.epi) {
+    case FLUXMI_EPI_BF16: tile_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, mrow0, ncol0, M); break;
+    case FLUXMI_EPI_GELU_QUANT: tile_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, mrow0, ncol0, M); break;
+    case FLUXMI_EPI_GATE_RESID: tile_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, mrow0, ncol0, M); break;
+    case FLUXMI_EPI_SPLIT: tile_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, mrow0, ncol0, M); break;
+    case FLUXMI_EPI_QUANT: tile_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, mrow0, ncol0, M); break;
+    case FLUXMI_EPI_SILU_QUANT: tile_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, mrow0, ncol0, M); break;
+    default: break;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// generic kernel: any M,N,K (K % 16 == 0 for fp8, K % 8 == 0 for bf16).  One thread per output.
+// Used for odd shapes (e.g. img_in K=64 when quantize_flow_embedder_layers) and as an on-device
+// cross-check of the tiled kernel at full size.
+// -------------------------------------------------------------------------------------------------
+template <bool FP8, int ACT_FMT>
+__global__ void __launch_bounds__(256) gemm_generic_kernel(const FluxmiGemmParams P) {
+  const int gi = blockIdx.z;
+  const FluxmiGemmGroup& G = P.g[gi];
+  const int n = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int m = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (m >= G.M || n >= P.N) return;
+  float acc = 0.f;
+  if constexpr (FP8) {
+    const unsigned char* a = (const unsigned char*)G.A + (long long)m * G.lda;
+    const unsigned char* w = (const unsigned char*)G.W + (long long)n * P.K;
+    for (int k = 0; k < P.K; k += 16) {
+      const uint4 av = *(const uint4*)(a + k), wv = *(const uint4*)(w + k);
+      const unsigned aw[4] = {av.x, av.y, av.z, av.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc = fmaf(fp8_to_f32<ACT_FMT>(aw[q], b), fp8_to_f32<FLUXMI_FMT_E4M3>(ww[q], b), acc);
+    }
+  } else {
+    const u16* a = (const u16*)G.A + (long long)m * G.lda;
+    const u16* w = (const u16*)G.W + (long long)n * P.K;
+    for (int k = 0; k < P.K; k += 8) {
+      float fa[8], fw[8];
+      unpack8(*(const uint4*)(a + k), fa);
+      unpack8(*(const uint4*)(w + k), fw);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc = fmaf(fa[q], fw[q], acc);
+    }
+  }
+  const float s = load_scale(G.sa_recip) * load_scale(G.sb_recip);
+  const float qs = G.q_scale ? *G.q_scale : 1.0f;
+  float b = 0.f, g = 0.f;
+  if (G.bias) load_bf<1>(G.bias, n, &b);
+  if (P.epi == FLUXMI_EPI_GATE_RESID) load_bf<1>(G.gate, n, &g);
+  float h = rbf(fmaf(acc, s, b));
+  switch (P.epi) {
+    case FLUXMI_EPI_BF16: epilogue<FLUXMI_EPI_BF16, ACT_FMT, 1>(G, qs, m, n, &h, &g); break;
+    case FLUXMI_EPI_GELU_QUANT: epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, 1>(G, qs, m, n, &h, &g); break;
+    case FLUXMI_EPI_GATE_RESID: epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, 1>(G, qs, m, n, &h, &g); break;
+    case FLUXMI_EPI_SPLIT: epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, 1>(G, qs, m, n, &h, &g); break;
+    case FLUXMI_EPI_QUANT: epilogue<FLUXMI_EPI_QUANT, ACT_FMT, 1>(G, qs, m, n, &h, &g); break;
+    case FLUXMI_EPI_SILU_QUANT: epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, 1>(G, qs, m, n, &h, &g); break;
+    default: break;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool FP8, int ACT>
+int launch_tile(FluxmiGemmParams& p, hipStream_t s) {
+  int t = 0;
+  for (int i = 0; i < p.n_groups; ++i) {
+    p.g[i].m_tile_start = t;
+    t += (p.g[i].M + BM - 1) / BM;
+  }
+  p.tiles_m_total = t;
+  p.group_m = 8;
+  constexpr int SMEM = 2 * (BM + BN) * 128;
+  auto kern = gemm_tile_kernel<BM, BN, WM, WN, FP8, ACT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  const int nblk = t * (p.N / BN);
+  if (nblk == 0) return 0;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(WM * WN * 64), SMEM, s, p);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool FP8, int ACT>
+int launch_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
+  switch (cfg) {
+    case 0: return launch_tile<256, 256, 2, 4, FP8, ACT>(p, s);
+    case 1: return launch_tile<256, 128, 4, 2, FP8, ACT>(p, s);
+    case 2: return launch_tile<128, 128, 2, 2, FP8, ACT>(p, s);
+    case 3: return launch_tile<128, 256, 2, 4, FP8, ACT>(p, s);
+    default: fluxmi_set_error("gemm: unknown tile config %d", cfg); return 1;
+  }
+}
+
+}  // namespace
+
+static const int kTileBN[4] = {256, 128, 128, 256};
+
+int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg) {
+  if (cfg < 0 || cfg > 3) return 0;
+  const int kb = K * (is_fp8 ? 1 : 2);
+  return (N % kTileBN[cfg] == 0) && (kb % 128 == 0) && kb >= 128;
+}
+
+int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s) {
+  FLUXMI_REQUIRE(p.n_groups >= 1 && p.n_groups <= FLUXMI_MAX_GROUPS, "gemm: n_groups=%d out of range", p.n_groups);
+  FLUXMI_REQUIRE(fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, cfg), "gemm: shape N=%d K=%d not tileable with cfg %d", p.N, p.K, cfg);
+  if (p.epi == FLUXMI_EPI_SPLIT)
+    FLUXMI_REQUIRE(p.g[0].split_n % kTileBN[cfg] == 0, "gemm: split_n=%d must be a multiple of the N tile", p.g[0].split_n);
+  if (is_fp8) {
+    if (act_fmt == FLUXMI_FMT_E5M2) return launch_cfg<true, FLUXMI_FMT_E5M2>(p, cfg, s);
+    return launch_cfg<true, FLUXMI_FMT_E4M3>(p, cfg, s);
+  }
+  // bf16 operands; act_fmt only selects the fp8 format of quantising epilogues
+  if (act_fmt == FLUXMI_FMT_E5M2) return launch_cfg<false, FLUXMI_FMT_E5M2>(p, cfg, s);
+  return launch_cfg<false, FLUXMI_FMT_E4M3>(p, cfg, s);
+}
+
+int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {
+  FLUXMI_REQUIRE(p.n_groups >= 1 && p.n_groups <= FLUXMI_MAX_GROUPS, "gemm: n_groups=%d out of range", p.n_groups);
+  FLUXMI_REQUIRE(p.K % (is_fp8 ? 16 : 8) == 0, "gemm: K=%d must be a multiple of %d", p.K, is_fp8 ? 16 : 8);
+  int maxM = 0;
+  for (int i = 0; i < p.n_groups; ++i) maxM = p.g[i].M > maxM ? p.g[i].M : maxM;
+  if (maxM == 0 || p.N == 0) return 0;
+  dim3 grid((p.N + 15) / 16, (maxM + 15) / 16, p.n_groups);
+  if (is_fp8) {
+    if (act_fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((gemm_generic_kernel<true, FLUXMI_FMT_E5M2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_generic_kernel<true, FLUXMI_FMT_E4M3>), grid, dim3(256), 0, s, p);
+  } else {
+    if (act_fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((gemm_generic_kernel<false, FLUXMI_FMT_E5M2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_generic_kernel<false, FLUXMI_FMT_E4M3>), grid, dim3(256), 0, s, p);
+  }
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,243 @@
+"""Operator-level host wrappers: torch CUDA(HIP) tensors in, libfluxmi kernels underneath.
+
+PyTorch is plumbing only (device memory + current stream).  Every function launches on
+`torch.cuda.current_stream()` and never synchronises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import E4M3, E5M2, GemmGroup, call
+
+F8_DTYPES = {torch.float8_e4m3fn: E4M3, torch.float8_e5m2: E5M2}
+F8_MAX = {E4M3: 448.0, E5M2: 57344.0}
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"fluxmi: {name} must live on the GPU (got {t.device}); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"fluxmi: {name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def fmt_of(dtype) -> int:
+    return F8_DTYPES[dtype]
+
+
+def dtype_of(fmt: int):
+    return torch.float8_e5m2 if fmt == E5M2 else torch.float8_e4m3fn
+
+
+# ---- quantisation ------------------------------------------------------------------------------
+def quantize_act(x: torch.Tensor, scale: torch.Tensor, fmt: int = E5M2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float8_quantize.py:217-218 + cast.  x: bf16 [..., K] (last dim contiguous)."""
+    _req(x, torch.bfloat16, "x")
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    if out is None:
+        out = torch.empty(x2.shape, dtype=dtype_of(fmt), device=x.device)
+    call("fluxmi_quantize_act", _p(x2), _p(out), _p(scale), x2.shape[0], x2.shape[1], x2.stride(0), out.stride(0), fmt, _stream())
+    return out.view(*x.shape[:-1], x.shape[-1])
+
+
+def amax(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, torch.bfloat16, "x")
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    if out is None:
+        out = torch.zeros((), dtype=torch.float32, device=x.device)
+    call("fluxmi_amax", _p(x2), _p(out), x2.shape[0], x2.shape[1], x2.stride(0), _stream())
+    return out
+
+
+def calib_update(amax_t, trials, scale, scale_recip, trial_index: int, num_trials: int, max_val: float) -> None:
+    call("fluxmi_calib_update", _p(amax_t), _p(trials), _p(scale), _p(scale_recip), trial_index, num_trials, max_val, _stream())
+
+
+def quantize_weight(w: torch.Tensor, fmt: int = E4M3):
+    """F8Linear.quantize_weight (float8_quantize.py:195-207) -> (float8_data, scale, scale_reciprocal)."""
+    _req(w, torch.bfloat16, "weight")
+    w = w.contiguous()
+    q = torch.empty(w.shape, dtype=dtype_of(fmt), device=w.device)
+    tmp = torch.zeros(3, dtype=torch.float32, device=w.device)
+    call("fluxmi_quantize_weight", _p(w), _p(q), _p(tmp[0:1]), _p(tmp[1:2]), _p(tmp[2:3]), w.shape[0], w.shape[1], fmt, _stream())
+    return q, tmp[1].clone(), tmp[2].clone()
+
+
+def dequant(q: torch.Tensor, scale_recip: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    call("fluxmi_dequant", _p(q), _p(out), _p(scale_recip), q.numel(), fmt_of(q.dtype), _stream())
+    return out
+
+
+def lora_fuse_f8(w8: torch.Tensor, w_scale: torch.Tensor, w_scale_recip: torch.Tensor, lora_B: torch.Tensor,
+                 lora_A: torch.Tensor, lora_scale: float, n_chunks: int = 1) -> None:
+    """In-place LoRA fuse + re-quantise of an e4m3 weight (lora_loading.py:509-577,615-631,686-687)."""
+    N, K = w8.shape
+    R = lora_B.shape[1]
+    work = torch.empty(2 * N * K, dtype=torch.float32, device=w8.device)
+    tmp = torch.zeros(1, dtype=torch.float32, device=w8.device)
+    call("fluxmi_lora_fuse_f8", _p(w8), _p(w_scale), _p(w_scale_recip), _p(lora_B.float().contiguous()),
+         _p(lora_A.float().contiguous()), N, K, R, n_chunks, float(lora_scale), _p(work), _p(tmp), _stream())
+
+
+# ---- linear ----------------------------------------------------------------------------------------
+def make_group(A, W, bias, sa_recip, sb_recip, Cout, M, lda, ldc, *, C2=None, ldc2=0, gate=None, resid=None, ldr=0,
+               q_scale=None, split_n=0, c2_col0=0) -> GemmGroup:
+    g = GemmGroup()
+    g.A, g.W, g.bias, g.sa_recip, g.sb_recip = A, W, bias, sa_recip, sb_recip
+    g.C, g.C2, g.gate, g.resid, g.q_scale = Cout, C2, gate, resid, q_scale
+    g.lda, g.ldc, g.ldc2, g.ldr, g.M, g.split_n, g.c2_col0 = lda, ldc, ldc2, ldr, M, split_n, c2_col0
+    return g
+
+
+def gemm_grouped(groups: Sequence[GemmGroup], N: int, K: int, is_fp8: bool, act_fmt: int, epilogue: int, tile_cfg: int = -1) -> None:
+    arr = (GemmGroup * len(groups))(*groups)
+    call("fluxmi_gemm_grouped", arr, len(groups), N, K, int(is_fp8), act_fmt, epilogue, tile_cfg, _stream())
+
+
+def linear(x, W, bias=None, sa_recip=None, sb_recip=None, *, epilogue=_lib.EPI_BF16, gate=None, resid=None, q_scale=None,
+           out=None, out2=None, split_n=0, c2_col0=0, tile_cfg=-1, out_fmt=E5M2):
+    """One (F8)Linear: x [M,K] fp8 or bf16, W [N,K].  Returns the primary output tensor."""
+    is_fp8 = W.dtype in F8_DTYPES
+    M, K = x.shape
+    N = W.shape[0]
+    act_fmt = fmt_of(x.dtype) if is_fp8 else out_fmt
+    fp8_out = epilogue in (_lib.EPI_GELU_QUANT, _lib.EPI_QUANT, _lib.EPI_SILU_QUANT)
+    n_primary = split_n if epilogue == _lib.EPI_SPLIT else N
+    if out is None:
+        out = torch.empty((M, n_primary), dtype=dtype_of(act_fmt) if fp8_out else torch.bfloat16, device=x.device)
+    g = make_group(_p(x), _p(W), _p(bias), _p(sa_recip), _p(sb_recip), _p(out), M, x.stride(0), out.stride(0),
+                   C2=_p(out2), ldc2=out2.stride(0) if out2 is not None else 0, gate=_p(gate), resid=_p(resid),
+                   ldr=resid.stride(0) if resid is not None else 0, q_scale=_p(q_scale), split_n=split_n, c2_col0=c2_col0)
+    gemm_grouped([g], N, K, is_fp8, act_fmt, epilogue, tile_cfg)
+    return out
+
+
+def gemv(x, W, bias=None, in_scale=None, sa_recip=None, sb_recip=None, pre_silu=False, act_fmt=E5M2, out=None):
+    B, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.bfloat16, device=x.device)
+    call("fluxmi_gemv", _p(x), x.stride(0), _p(W), _p(bias), _p(in_scale), _p(sa_recip), _p(sb_recip), _p(out), out.stride(0),
+         B, N, K, int(W.dtype in F8_DTYPES), act_fmt, int(pre_silu), _stream())
+    return out
+
+
+# ---- block elementwise ---------------------------------------------------------------------------------
+def ln_modulate(x, shift0, scale0, shift1=None, scale1=None, split=None, q_scale0=None, q_scale1=None, fmt=E5M2):
+    """x [B,L,H] bf16; shift/scale [B,H] (row stride = mod_bstride).  fp8 output iff q_scale0 is given."""
+    B, L, H = x.shape
+    split = L if split is None else split
+    shift1 = shift0 if shift1 is None else shift1
+    scale1 = scale0 if scale1 is None else scale1
+    out_fp8 = q_scale0 is not None
+    q_scale1 = q_scale0 if q_scale1 is None else q_scale1
+    out = torch.empty((B, L, H), dtype=dtype_of(fmt) if out_fp8 else torch.bfloat16, device=x.device)
+    call("fluxmi_ln_modulate", _p(x), x.stride(1), _p(out), H, _p(shift0), _p(scale0), _p(shift1), _p(scale1), shift0.stride(0),
+         _p(q_scale0), _p(q_scale1), B, L, split, H, int(out_fp8), fmt, _stream())
+    return out
+
+
+def act(x, mode: int):
+    x2 = x.reshape(-1, x.shape[-1])
+    y = torch.empty_like(x2)
+    call("fluxmi_act", _p(x2), _p(y), x2.shape[0], x2.shape[1], x2.stride(0), y.stride(0), mode, _stream())
+    return y.view(x.shape)
+
+
+def gate_residual(x, y, gate):
+    B, L, H = x.shape
+    out = torch.empty_like(x)
+    call("fluxmi_gate_residual", _p(x), _p(y), _p(gate), _p(out), B, L, H, H, H, H, gate.stride(0), _stream())
+    return out
+
+
+def add(a, b):
+    z = torch.empty_like(a)
+    call("fluxmi_add", _p(a), _p(b), _p(z), a.numel(), _stream())
+    return z
+
+
+# ---- attention path -------------------------------------------------------------------------------------
+def rope_tables_host(axes_dim, theta):
+    """Host-side constants, evaluated with the reference's own torch expressions (flux_model.py:50-51)."""
+    omega, axis = [], []
+    for i, d in enumerate(axes_dim):
+        frac = torch.arange(0, d, 2, dtype=torch.float32) / d
+        om = 1.0 / (theta ** frac)
+        omega.append(om)
+        axis += [i] * om.numel()
+    return torch.cat(omega).contiguous(), torch.tensor(axis, dtype=torch.int32)
+
+
+def timestep_freqs_host(half=128, max_period=10000):
+    import math
+    return torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+
+
+def rope_table(ids: torch.Tensor, axes_dim, theta) -> torch.Tensor:
+    """ids bf16 [B,L,3] -> pe bf16 [B,L,64,2] (cos, sin)."""
+    om, ax = rope_tables_host(axes_dim, theta)
+    om, ax = om.to(ids.device), ax.to(ids.device)
+    B, L, n_axes = ids.shape
+    pe = torch.empty((B, L, om.numel(), 2), dtype=torch.bfloat16, device=ids.device)
+    call("fluxmi_rope_table", _p(ids.contiguous()), _p(om), _p(ax), _p(pe), B * L, n_axes, om.numel(), _stream())
+    return pe
+
+
+def qkv_rope(qkv, pe, q_scale0, k_scale0, q_scale1=None, k_scale1=None, split=None, heads=None):
+    """qkv bf16 [B,L,>=3*H*128] -> Q,K [B,H,L,128], VT [B,H,128,Lp]."""
+    B, L, _ = qkv.shape
+    split = L if split is None else split
+    q_scale1 = q_scale0 if q_scale1 is None else q_scale1
+    k_scale1 = k_scale0 if k_scale1 is None else k_scale1
+    Lp = (L + 63) // 64 * 64
+    Q = torch.empty((B, heads, L, 128), dtype=torch.bfloat16, device=qkv.device)
+    K = torch.empty_like(Q)
+    VT = torch.empty((B, heads, 128, Lp), dtype=torch.bfloat16, device=qkv.device)
+    call("fluxmi_qkv_rope", _p(qkv), qkv.stride(1), _p(pe), _p(q_scale0), _p(k_scale0), _p(q_scale1), _p(k_scale1), _p(Q), _p(K),
+         _p(VT), B, L, Lp, heads, split, _stream())
+    return Q, K, VT
+
+
+def attention(Q, K, VT, q_scale0=None, q_scale1=None, split=None, fmt=E5M2, out=None, col_off=0):
+    B, H, L, _ = Q.shape
+    Lp = VT.shape[-1]
+    split = L if split is None else split
+    out_fp8 = q_scale0 is not None
+    q_scale1 = q_scale0 if q_scale1 is None else q_scale1
+    if out is None:
+        out = torch.empty((B, L, H * 128), dtype=dtype_of(fmt) if out_fp8 else torch.bfloat16, device=Q.device)
+    call("fluxmi_attention", _p(Q), _p(K), _p(VT), _p(out), out.stride(1), col_off, int(out_fp8), _p(q_scale0), _p(q_scale1), split,
+         B, L, Lp, H, fmt, _stream())
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, freqs: torch.Tensor, time_factor: float = 1000.0) -> torch.Tensor:
+    B = t.shape[0]
+    half = freqs.numel()
+    out = torch.empty((B, 2 * half), dtype=torch.bfloat16, device=t.device)
+    call("fluxmi_timestep_embedding", _p(t), _p(freqs), _p(out), B, half, time_factor, _stream())
+    return out
+
+
+def euler_(img: torch.Tensor, pred: torch.Tensor, dt: float) -> torch.Tensor:
+    dts = torch.tensor([dt], dtype=torch.float32, device=img.device)
+    call("fluxmi_euler", _p(img), _p(pred), _p(dts), None, img.numel(), _stream())
+    return img

@@ -1,0 +1,181 @@
+/* fluxmi.h -- C ABI of libfluxmi.so, the MI355X (gfx950) implementation of the Flux denoise hot path
+ * of aredden/flux-fp8-api.
+ *
+ * The reference has no FFI of its own: its only operator-swap mechanism is Python module replacement
+ * (float8_quantize.py:320-392 swaps nn.Linear -> F8Linear / the external cublas_ops.CublasLinear).
+ * This header is therefore the boundary a maintainer binds from the reference's Python operator
+ * classes (ctypes stub in INTEGRATION.md).  Each entry point cites the reference code it replaces
+ * (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain C types only: raw DEVICE pointers, sizes, a hipStream_t passed as void* (0 = null stream)
+ *   - every function returns 0 on success; non-zero -> call fluxmi_last_error() (thread-local string)
+ *   - nothing throws across the ABI; no allocation, host sync or hipMalloc inside any *_forward /
+ *     op call (all are hipGraph-capturable); engine_create/prepare allocate the private workspace
+ *   - caller owns every buffer passed in; row strides ("ld") are in ELEMENTS of that buffer
+ *   - tensors are bf16 (uint16 storage) unless stated; fp8 tensors are OCP e4m3fn / e5m2 bytes
+ *   - an engine handle is not re-entrant: the host wrapper serialises calls per engine
+ */
+#ifndef FLUXMI_H
+#define FLUXMI_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUXMI_ABI_VERSION 1
+
+/* fp8 format codes (torch.float8_e4m3fn / torch.float8_e5m2, float8_quantize.py:39,43) */
+#define FLUXMI_E4M3 0
+#define FLUXMI_E5M2 1
+
+/* GEMM epilogues: what happens to h = bf16(acc * sa * sb + bias) */
+enum {
+  FLUXMI_EPI_BF16 = 0,       /* C(bf16) = h                                   float8_quantize.py:284-292 */
+  FLUXMI_EPI_GELU_QUANT = 1, /* C(fp8)  = q(bf16(gelu_tanh(h)), q_scale)      flux_model.py:301,335 + float8_quantize.py:274-276 */
+  FLUXMI_EPI_GATE_RESID = 2, /* C(bf16) = bf16(resid + bf16(gate[n] * h))     flux_model.py:387-396,484 */
+  FLUXMI_EPI_SPLIT = 3,      /* n < split_n: C(bf16) = h ; else C2(fp8) = q(gelu) at column c2_col0 + n - split_n
+                                                                              flux_model.py:471-480 */
+  FLUXMI_EPI_QUANT = 4,      /* C(fp8)  = q(h, q_scale) */
+  FLUXMI_EPI_SILU_QUANT = 5  /* C(fp8)  = q(bf16(silu(h)), q_scale)           flux_model.py:154-155 */
+};
+
+/* one problem of a (grouped) linear: out[M,N] = epilogue(A[M,K] . W[N,K]^T) */
+typedef struct fluxmi_gemm_group {
+  const void* A;          /* activations [M,K]: fp8 bytes (F8Linear) or bf16 (nn.Linear) */
+  const void* W;          /* weight [N,K] row-major = F8Linear.float8_data / nn.Linear.weight */
+  const void* bias;       /* bf16 [N] or NULL */
+  const float* sa_recip;  /* device scalar F8Linear.input_scale_reciprocal (NULL = 1) */
+  const float* sb_recip;  /* device scalar F8Linear.scale_reciprocal       (NULL = 1) */
+  void* C;                /* primary output */
+  void* C2;               /* secondary output (FLUXMI_EPI_SPLIT) */
+  const void* gate;       /* bf16 [N] */
+  const void* resid;      /* bf16 [M, ldr] (may alias C) */
+  const float* q_scale;   /* device scalar: input_scale of the consuming F8Linear */
+  long long lda, ldc, ldc2, ldr;
+  int M;
+  int m_tile_start;       /* internal, filled by the launcher */
+  int split_n, c2_col0;
+} fluxmi_gemm_group_t;
+
+const char* fluxmi_last_error(void);
+int fluxmi_abi_version(void);
+
+/* ---- F8Linear / Linear ------------------------------------------------------------------------- */
+/* Grouped linear.  is_fp8=1: A is `act_fmt` fp8, W is e4m3fn (torch._scaled_mm, float8_quantize.py:284-292);
+ * is_fp8=0: A, W bf16 (F.linear).  tile_cfg: -1 auto, 0..3 MFMA tile shapes, 100 = generic any-shape kernel. */
+int fluxmi_gemm_grouped(const fluxmi_gemm_group_t* groups, int n_groups, int N, int K, int is_fp8, int act_fmt,
+                        int epilogue, int tile_cfg, void* stream);
+/* single-problem convenience form of the above (F8Linear.forward after quantisation) */
+int fluxmi_f8_gemm(const void* a_fp8, const void* w_e4m3, const float* sa_recip, const float* sb_recip, const void* bias,
+                   void* out, int M, int N, int K, int act_fmt, int epilogue, const void* gate, const void* resid,
+                   const float* q_scale, int tile_cfg, void* stream);
+/* skinny linear (M = batch <= 8): out[b,n] = bf16((x_q[b,:].W[n,:]) * sa*sb + bias), optional SiLU on x first
+ * (Modulation.forward flux_model.py:251-257, MLPEmbedder flux_model.py:154-155, LastLayer.adaLN flux_model.py:495-500) */
+int fluxmi_gemv(const void* x, long long ldx, const void* W, const void* bias, const float* in_scale, const float* sa_recip,
+                const float* sb_recip, void* out, long long ld_out, int B, int N, int K, int w_fp8, int act_fmt, int pre_silu,
+                void* stream);
+
+/* ---- quantisation state machine (F8Linear) ------------------------------------------------------- */
+/* q = fp8(clamp(bf16(x*scale)))                                                float8_quantize.py:217-218,274-276 */
+int fluxmi_quantize_act(const void* x, void* q, const float* scale, int rows, int cols, long long ld_in, long long ld_out,
+                        int fmt, void* stream);
+/* *amax = max(*amax, max|x|)  (caller zeroes *amax first)                      float8_quantize.py:227 */
+int fluxmi_amax(const void* x, float* amax, int rows, int cols, long long ld, void* stream);
+/* one call of F8Linear.quantize_input's scale logic for trial `trial_index`     float8_quantize.py:220-246 */
+int fluxmi_calib_update(const float* amax, float* trials, float* scale, float* scale_recip, int trial_index, int num_trials,
+                        float max_val, void* stream);
+/* F8Linear.quantize_weight: amax -> scale -> e4m3 data + reciprocal             float8_quantize.py:195-207 */
+int fluxmi_quantize_weight(const void* w_bf16, void* q, float* amax_tmp, float* scale, float* scale_recip, int N, int K, int fmt,
+                           void* stream);
+/* LoRA fuse into an fp8 weight: W' = requant(bf16(dequant(W) + scale * B@A))     lora_loading.py:509-577,615-631,686-687 */
+int fluxmi_lora_fuse_f8(void* w_fp8, float* w_scale, float* w_scale_recip, const float* lora_B, const float* lora_A, int N, int K,
+                        int R, int n_chunks, float lora_scale, float* work_f32, float* amax_tmp, void* stream);
+int fluxmi_dequant(const void* q, float* out, const float* scale_recip, long long n, int fmt, void* stream);
+
+/* ---- block elementwise ----------------------------------------------------------------------------- */
+/* y = (1+scale)*LayerNorm(x)+shift (+fp8 quantise); rows [B][L], rows l<split use set 0   flux_model.py:367-368,389,469-470,501 */
+int fluxmi_ln_modulate(const void* x, long long ldx, void* out, long long ldo, const void* shift0, const void* scale0,
+                       const void* shift1, const void* scale1, long long mod_bstride, const float* q_scale0,
+                       const float* q_scale1, int B, int L, int split, int H, int out_fp8, int fmt, void* stream);
+/* mode 0: GELU(tanh), 1: SiLU (bf16 -> bf16)                                     flux_model.py:301,139 */
+int fluxmi_act(const void* x, void* y, int rows, int cols, long long ld_in, long long ld_out, int mode, void* stream);
+/* out = x + gate[b] * y                                                           flux_model.py:387-396,484 */
+int fluxmi_gate_residual(const void* x, const void* y, const void* gate, void* out, int B, int L, int H, long long ldx,
+                         long long ldy, long long ldo, long long gate_bstride, void* stream);
+int fluxmi_add(const void* a, const void* b, void* z, long long n, void* stream);
+
+/* ---- attention path --------------------------------------------------------------------------------- */
+/* pe[rows, pairs, (cos,sin)] from position ids                                    flux_model.py:49-57,82-92 */
+int fluxmi_rope_table(const void* ids, const float* omega, const int* axis, void* pe, long long rows, int n_axes, int pairs,
+                      void* stream);
+/* qkv split + QKNorm + RoPE + head-major relayout (V transposed)                  flux_model.py:351-354,158-176,60-65,380-382 */
+int fluxmi_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0,
+                    const void* q_scale1, const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H, int split,
+                    void* stream);
+/* softmax(QK^T/sqrt(128))V -> [B,L,H*128] (bf16, or fp8 with the consumer's input scale)   flux_model.py:41-45 */
+int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
+                     const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream);
+
+/* ---- step scalars -------------------------------------------------------------------------------------- */
+/* timestep_embedding(t, 2*half) with host-provided frequency table                 flux_model.py:95-116 */
+int fluxmi_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, void* stream);
+/* img += dts[*step] * pred                                                          flux_pipeline.py:651 */
+int fluxmi_euler(void* img, const void* pred, const float* dts, const int* step, long long n, void* stream);
+
+/* ---- whole-model engine ------------------------------------------------------------------------------- */
+typedef struct fluxmi_linear {
+  const void* weight;      /* fp8 float8_data [N,K] (kind 1) or bf16 weight [N,K] (kind 0) */
+  const void* bias;        /* bf16 [N] or NULL */
+  float* w_scale_recip;    /* F8Linear.scale_reciprocal        (device scalar) */
+  float* in_scale;         /* F8Linear.input_scale             (device scalar) */
+  float* in_scale_recip;   /* F8Linear.input_scale_reciprocal  (device scalar) */
+  float* amax_trials;      /* F8Linear.input_amax_trials [num_trials] (device) */
+  int kind;                /* 0 = nn.Linear (bf16), 1 = F8Linear */
+  int N, K;
+  int in_fmt;              /* FLUXMI_E5M2 / FLUXMI_E4M3 */
+} fluxmi_linear_t;
+
+typedef struct fluxmi_model_desc {
+  int hidden, heads, mlp_hidden, depth, depth_single, in_channels, vec_in, ctx_in, guidance_embed;
+  int axes_dim[3];
+  int theta;
+  int num_trials;
+} fluxmi_model_desc_t;
+
+/* Layer order in `linears` (count = fluxmi_engine_num_linears(desc)):
+ *   img_in, time_in.in, time_in.out, vector_in.in, vector_in.out, [guidance_in.in, guidance_in.out], txt_in,
+ *   per double block i: img_mod.lin, img_attn.qkv, img_attn.proj, img_mlp.0, img_mlp.2,
+ *                       txt_mod.lin, txt_attn.qkv, txt_attn.proj, txt_mlp.0, txt_mlp.2
+ *   per single block i: modulation.lin, linear1, linear2
+ *   final_layer.adaLN_modulation.1, final_layer.linear
+ * `norm_scales`: bf16 [128] pointers, per double block: img q, img k, txt q, txt k; per single block: q, k. */
+typedef struct fluxmi_engine fluxmi_engine_t;
+int fluxmi_engine_num_linears(const fluxmi_model_desc_t* desc);
+int fluxmi_engine_create(const fluxmi_model_desc_t* desc, const fluxmi_linear_t* linears, int n_linears,
+                         const void* const* norm_scales, int n_norm_scales, fluxmi_engine_t** out);
+int fluxmi_engine_destroy(fluxmi_engine_t* e);
+/* constant tables computed by the host with the reference's own expressions: timestep frequencies
+ * exp(-ln(1e4)*i/128) (flux_model.py:106-110), RoPE omega per pair and the id axis each pair uses (flux_model.py:50-51,84-90) */
+int fluxmi_engine_set_tables(fluxmi_engine_t* e, const float* freqs128, const float* omega64, const int* axis64);
+/* re-read weight pointers / kinds after a LoRA fuse or dtype swap (float8_quantize.py:209-212) */
+int fluxmi_engine_rebind(fluxmi_engine_t* e, const fluxmi_linear_t* linears, int n_linears);
+/* per-request setup: (re)allocates the workspace for (B, Li, Lt), builds the RoPE table from the position ids
+ * (step-invariant: flux_model.py:701-702) */
+int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void* img_ids, const void* txt_ids, void* stream);
+/* one Flux.forward (flux_model.py:672-716).  mode 0 = calibrating/unfused (advances the F8Linear trial state
+ * machine exactly like the reference's first 13 calls), 1 = frozen/fused.  pred: bf16 [B,Li,in_channels]. */
+int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, const void* y, const void* timesteps,
+                          const void* guidance, void* pred, int mode, int trial_index, void* stream);
+/* the denoise loop (flux_pipeline.py:619-651): timesteps_host[n_steps+1]; img updated in place.
+ * Steps with trial_index <= num_trials run unfused; the remainder replays ONE captured hipGraph per step. */
+int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const void* y, float guidance,
+                          const double* timesteps_host, int n_steps, int* trial_index_inout, int use_graph, void* stream);
+/* introspection for tests / bench */
+int fluxmi_engine_workspace_bytes(fluxmi_engine_t* e, long long* bytes);
+int fluxmi_engine_get_buffer(fluxmi_engine_t* e, const char* name, void** ptr, long long* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUXMI_H */

@@ -1,0 +1,377 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerances (stated per test):
+  * fp8 / bf16 casts, quantise, amax, scale state machine: bit-exact
+  * GEMM on identical quantised operands: <= 1 bf16 ulp of the fp64 result, >= 99 % bit-exact
+  * fused elementwise chains: <= 1 bf16 ulp (reduction order / exp approximation), >= 99.9 % bit-exact
+  * attention: |err| <= 2e-2 * max|V| against an fp64 softmax (bf16 P, bf16 output rounding)
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import flux_oracle as fo
+from util import assert_bf16_close, assert_f8_close, round_fp64_to_bf16, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+E4M3, E5M2 = 0, 1
+F8T = {E4M3: torch.float8_e4m3fn, E5M2: torch.float8_e5m2}
+F8MAX = {E4M3: 448.0, E5M2: 57344.0}
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from fluxmi import ops as _ops
+
+    return _ops
+
+
+def all_bf16():
+    x = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
+    return x[~torch.isnan(x)]
+
+
+def scalar(v, dev):
+    return torch.tensor(float(v), dtype=torch.float32, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", [E5M2, E4M3])
+@pytest.mark.parametrize("scale", [1.0, 3.3, 448.0, 57344.0, 0.0123])
+def test_quantize_exhaustive(ops, dev, fmt, scale):
+    """G1: every bf16 input through q = fp8(clamp(bf16(x*scale))) -- bit-exact vs float8_quantize.py:217-218."""
+    x = all_bf16()
+    x = x[: (x.numel() // 8) * 8].reshape(-1, 8)
+    s = torch.tensor(scale, dtype=torch.float32)
+    ref = fo.to_fp8_saturated(x, s, F8MAX[fmt]).to(F8T[fmt])
+    got = ops.quantize_act(x.to(dev), s.to(dev), fmt).cpu()
+    bad = (got.view(torch.uint8) != ref.view(torch.uint8))
+    assert not bad.any(), f"{bad.sum().item()} mismatching bytes, first inputs {x[bad][:5].float().tolist()}"
+
+
+def test_amax_and_calibration_trace(ops, dev):
+    """G2/G3: amax + the 12-trial running-max scale state machine (float8_quantize.py:214-246), bit-exact."""
+    torch.manual_seed(1)
+    st = fo.F8LinearState(torch.randn(16, 64).bfloat16(), None)
+    trials = torch.zeros(12, dtype=torch.float32, device=dev)
+    scale = torch.zeros((), dtype=torch.float32, device=dev)
+    recip = torch.zeros((), dtype=torch.float32, device=dev)
+    for call in range(15):
+        x = (torch.randn(40, 64) * (0.5 + 3.0 * ((call * 7) % 5))).bfloat16()
+        if call == 3:
+            x = x * 1e-3  # amax < 1 -> scale clamps at max_val
+        ref_q = st.quantize_input(x)
+        if call <= 12:
+            a = ops.amax(x.to(dev))
+            assert a.item() == x.abs().max().float().item()
+            ops.calib_update(a, trials, scale, recip, call, 12, 57344.0)
+        assert scale.item() == st.input_scale.item(), f"call {call}: scale {scale.item()} vs {st.input_scale.item()}"
+        assert recip.item() == st.input_scale_reciprocal.item()
+        got_q = ops.quantize_act(x.to(dev), scale, E5M2).cpu()
+        assert torch.equal(got_q.view(torch.uint8), ref_q.view(torch.uint8)), f"call {call}"
+    assert st.input_scale_initialized and torch.equal(trials.cpu(), st.input_amax_trials)
+
+
+@pytest.mark.parametrize("amax", [0.0, 1e-13, 0.5, 1.0, 2.0, 448.0, 1e5])
+def test_amax_to_scale_edges(ops, dev, amax):
+    for max_val in (448.0, 57344.0):
+        trials = torch.zeros(12, dtype=torch.float32, device=dev)
+        scale, recip = scalar(0, dev), scalar(0, dev)
+        ops.calib_update(scalar(amax, dev), trials, scale, recip, 0, 12, max_val)
+        ref = fo.amax_to_scale(torch.tensor(amax, dtype=torch.float32), max_val)
+        assert scale.item() == ref.item() and recip.item() == ref.reciprocal().item()
+
+
+def test_quantize_weight(ops, dev):
+    torch.manual_seed(2)
+    for amp in (0.02, 1.0, 30.0):
+        w = (torch.randn(192, 256) * amp).bfloat16()
+        w[5, 7] = w.abs().max() * 4
+        q_ref, s_ref, r_ref = fo.quantize_weight(w)
+        q, s, r = ops.quantize_weight(w.to(dev))
+        assert s.item() == s_ref.item() and r.item() == r_ref.item()
+        assert torch.equal(q.cpu().view(torch.uint8), q_ref.view(torch.uint8))
+
+
+# ------------------------------------------------------------------------------------------------
+def make_f8_problem(M, N, K, fmt, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn(M, K, generator=g) * 2.0).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    a[:, 3] += 1.5  # asymmetric data: catches row/col or k permutation mistakes
+    w[1] *= 3.0
+    sa = fo.amax_to_scale(a.abs().max().float(), F8MAX[fmt])
+    a8 = fo.to_fp8_saturated(a, sa, F8MAX[fmt]).to(F8T[fmt])
+    w8, sb, sbr = fo.quantize_weight(w)
+    bias = torch.randn(N, generator=g).bfloat16()
+    return a8, w8, sa.reciprocal(), sbr, bias
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 100])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (512, 768, 256), (300, 512, 384), (37, 256, 3072), (1024, 1024, 1024)])
+@pytest.mark.parametrize("fmt", [E5M2, E4M3])
+def test_f8_gemm(ops, dev, cfg, shape, fmt):
+    """K1: fp8 GEMM on identical quantised operands vs fp64 (float8_quantize.py:284-292): <= 1 bf16 ulp."""
+    M, N, K = shape
+    if fmt == E4M3 and (cfg not in (0, 100) or shape != (512, 768, 256)):
+        pytest.skip("e4m3 activations: one representative case per kernel")
+    a8, w8, sar, sbr, bias = make_f8_problem(M, N, K, fmt, seed=M + N + K)
+    ref = round_fp64_to_bf16(fo.scaled_mm_fp64(a8, w8, sar, sbr, bias))
+    out = ops.linear(a8.to(dev), w8.to(dev), bias.to(dev), sar.to(dev), sbr.to(dev), tile_cfg=cfg)
+    torch.cuda.synchronize()
+    assert_bf16_close(out, ref, max_ulp=1, min_exact=0.99, what=f"f8 gemm cfg={cfg} {shape}")
+    # and against torch's own CPU _scaled_mm (what the reference executes)
+    ref2 = fo.scaled_mm_ref(a8, w8, sar, sbr, bias)
+    assert_bf16_close(out, ref2, max_ulp=1, min_exact=0.99, what="vs torch._scaled_mm")
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 100])
+def test_bf16_gemm(ops, dev, cfg):
+    torch.manual_seed(5)
+    M, N, K = 320, 512, 192
+    a = torch.randn(M, K).bfloat16()
+    w = (torch.randn(N, K) * 0.1).bfloat16()
+    a[:, 1] += 2
+    bias = torch.randn(N).bfloat16()
+    ref = round_fp64_to_bf16(a.double() @ w.double().T + bias.double())
+    out = ops.linear(a.to(dev), w.to(dev), bias.to(dev), tile_cfg=cfg)
+    assert_bf16_close(out, ref, max_ulp=1, min_exact=0.99, what=f"bf16 gemm cfg={cfg}")
+
+
+@pytest.mark.parametrize("cfg", [0, 2, 100])
+def test_gemm_epilogues(ops, dev, cfg):
+    """K8/K9/K2 fused epilogues == the reference's eager chain applied to the GEMM's own bf16 output."""
+    from fluxmi import _lib
+
+    M, N, K = 384, 1024, 256
+    a8, w8, sar, sbr, bias = make_f8_problem(M, N, K, E5M2, seed=11)
+    d = lambda t: t.to(dev)
+    h = ops.linear(d(a8), d(w8), d(bias), d(sar), d(sbr), tile_cfg=cfg).cpu()  # bf16(acc*s+bias)
+    qs = torch.tensor(37.5, dtype=torch.float32)
+    # GELU + quantise                                                     flux_model.py:301 + float8_quantize.py:274-276
+    ref = fo.to_fp8_saturated(F.gelu(h, approximate="tanh"), qs, 57344.0).to(torch.float8_e5m2)
+    got = ops.linear(d(a8), d(w8), d(bias), d(sar), d(sbr), epilogue=_lib.EPI_GELU_QUANT, q_scale=d(qs), tile_cfg=cfg)
+    assert_f8_close(got, ref, max_ulp=1, min_exact=0.999, what="gelu+quant")
+    # gate * y + x                                                        flux_model.py:387-388
+    g = torch.Generator().manual_seed(3)
+    gate = torch.randn(N, generator=g).bfloat16()
+    resid = torch.randn(M, N, generator=g).bfloat16()
+    ref = resid + gate * h
+    got = ops.linear(d(a8), d(w8), d(bias), d(sar), d(sbr), epilogue=_lib.EPI_GATE_RESID, gate=d(gate), resid=d(resid), tile_cfg=cfg)
+    assert torch.equal(got.cpu(), ref), f"gate-resid: max ulp {ulp_diff(got, ref).max().item()}"
+    # in place on the residual buffer
+    r2 = d(resid).clone()
+    ops.linear(d(a8), d(w8), d(bias), d(sar), d(sbr), epilogue=_lib.EPI_GATE_RESID, gate=d(gate), resid=r2, out=r2, tile_cfg=cfg)
+    assert torch.equal(r2.cpu(), ref)
+    # split: qkv part bf16, mlp part gelu+quant into a wider buffer at a column offset   flux_model.py:471-480
+    split = 512
+    out2 = torch.zeros(M, 128 + (N - split), dtype=torch.float8_e5m2, device=dev)
+    got = ops.linear(d(a8), d(w8), d(bias), d(sar), d(sbr), epilogue=_lib.EPI_SPLIT, q_scale=d(qs), out2=out2, split_n=split,
+                     c2_col0=128, tile_cfg=cfg)
+    assert torch.equal(got.cpu(), h[:, :split])
+    ref = fo.to_fp8_saturated(F.gelu(h[:, split:], approximate="tanh"), qs, 57344.0).to(torch.float8_e5m2)
+    assert_f8_close(out2[:, 128:], ref, max_ulp=1, min_exact=0.999, what="split gelu+quant")
+    assert (out2[:, :128].cpu().view(torch.uint8) == 0).all()
+
+
+def test_gemm_grouped(ops, dev):
+    """txt+img streams (different weights, different M incl. a ragged one) in one launch."""
+    from fluxmi import _lib
+
+    N, K = 512, 256
+    probs = [make_f8_problem(M, N, K, E5M2, seed=100 + M) for M in (64, 333, 256)]
+    outs, groups, keep = [], [], []
+    for a8, w8, sar, sbr, bias in probs:
+        t = [x.to(dev) for x in (a8, w8, sar, sbr, bias)]
+        o = torch.empty(a8.shape[0], N, dtype=torch.bfloat16, device=dev)
+        keep.append(t)
+        outs.append(o)
+        groups.append(ops.make_group(t[0].data_ptr(), t[1].data_ptr(), t[4].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                                     o.data_ptr(), a8.shape[0], K, N))
+    for cfg in (0, 1, 2, 3):
+        for o in outs:
+            o.zero_()
+        ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_BF16, cfg)
+        for (a8, w8, sar, sbr, bias), o in zip(probs, outs):
+            ref = round_fp64_to_bf16(fo.scaled_mm_fp64(a8, w8, sar, sbr, bias))
+            assert_bf16_close(o, ref, 1, 0.99, what=f"grouped cfg={cfg} M={a8.shape[0]}")
+
+
+@pytest.mark.parametrize("B", [1, 3, 8])
+def test_gemv(ops, dev, B):
+    """K10: Modulation / MLPEmbedder skinny linears (flux_model.py:251-257,154-155)."""
+    torch.manual_seed(7)
+    K, N = 768, 200
+    x = torch.randn(B, K).bfloat16()
+    w = (torch.randn(N, K) * 0.05).bfloat16()
+    bias = torch.randn(N).bfloat16()
+    d = lambda t: t.to(dev)
+    # fp8 weights, SiLU prologue
+    st = fo.F8LinearState(w, bias)
+    ref = st(F.silu(x))  # first calibration call fixes the scale from this input
+    out = ops.gemv(d(x), d(st.float8_data), d(bias), d(st.input_scale), d(st.input_scale_reciprocal), d(st.scale_reciprocal),
+                   pre_silu=True)
+    ref64 = round_fp64_to_bf16(fo.scaled_mm_fp64(st.quantize_input(F.silu(x)), st.float8_data, st.input_scale_reciprocal,
+                                                 st.scale_reciprocal, bias))
+    assert_bf16_close(out, ref64, 1, 0.99, what="gemv fp8")
+    assert_bf16_close(out, ref, 1, 0.99, what="gemv fp8 vs scaled_mm")
+    # bf16 weights, no prologue
+    out = ops.gemv(d(x), d(w), d(bias))
+    ref = round_fp64_to_bf16(x.double() @ w.double().T + bias.double())
+    assert_bf16_close(out, ref, 1, 0.99, what="gemv bf16")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H", [256, 3072])
+def test_ln_modulate(ops, dev, H):
+    """K4(+K2): (1+scale)*LayerNorm(x)+shift with the reference's bf16 rounding points (flux_model.py:367-368)."""
+    torch.manual_seed(9)
+    B, L, Lt = 2, 40, 12
+    x = (torch.randn(B, L, H) * 2 + 0.3).bfloat16()
+    mods = (torch.randn(B, 4 * H) * 0.5).bfloat16()  # txt shift|scale, img shift|scale, row stride 4H
+    sh0, sc0, sh1, sc1 = mods[:, :H], mods[:, H:2 * H], mods[:, 2 * H:3 * H], mods[:, 3 * H:]
+    ln = F.layer_norm(x, (H,), eps=1e-6)
+    ref = torch.empty_like(x)
+    ref[:, :Lt] = (1 + sc0[:, None]) * ln[:, :Lt] + sh0[:, None]
+    ref[:, Lt:] = (1 + sc1[:, None]) * ln[:, Lt:] + sh1[:, None]
+    md = mods.to(dev)
+    v = lambda a, b: md[:, a * H:b * H]
+    got = ops.ln_modulate(x.to(dev), v(0, 1), v(1, 2), v(2, 3), v(3, 4), split=Lt)
+    assert_bf16_close(got, ref, max_ulp=1, min_exact=0.999, what="ln_modulate bf16")
+    q0, q1 = torch.tensor(900.0), torch.tensor(20000.0)
+    refq = torch.empty(B, L, H, dtype=torch.float8_e5m2)
+    refq[:, :Lt] = fo.to_fp8_saturated(ref[:, :Lt], q0, 57344.0).to(torch.float8_e5m2)
+    refq[:, Lt:] = fo.to_fp8_saturated(ref[:, Lt:], q1, 57344.0).to(torch.float8_e5m2)
+    gotq = ops.ln_modulate(x.to(dev), v(0, 1), v(1, 2), v(2, 3), v(3, 4), split=Lt, q_scale0=q0.to(dev), q_scale1=q1.to(dev))
+    assert_f8_close(gotq, refq, max_ulp=1, min_exact=0.999, what="ln_modulate fp8")
+
+
+def test_act_tables(ops, dev):
+    """K9/K10: GELU(tanh) and SiLU over every finite bf16 input vs ATen's CPU kernels."""
+    x = all_bf16()
+    x = x[torch.isfinite(x)]
+    x = x[: (x.numel() // 8) * 8].reshape(-1, 8)
+    g = ops.act(x.to(dev), 0)
+    assert_bf16_close(g, F.gelu(x, approximate="tanh"), max_ulp=1, min_exact=0.999, what="gelu table")
+    s = ops.act(x.to(dev), 1)
+    assert_bf16_close(s, F.silu(x), max_ulp=1, min_exact=0.999, what="silu table")
+
+
+def test_gate_residual_add_euler(ops, dev):
+    torch.manual_seed(4)
+    B, L, H = 2, 24, 256
+    x, y = torch.randn(B, L, H).bfloat16(), torch.randn(B, L, H).bfloat16()
+    gate = torch.randn(B, H).bfloat16()
+    assert torch.equal(ops.gate_residual(x.to(dev), y.to(dev), gate.to(dev)).cpu(), x + gate[:, None] * y)
+    assert torch.equal(ops.add(x.to(dev), y.to(dev)).cpu(), x + y)
+    dt = 0.9762182831764221 - 0.9884144067764282
+    img = x.to(dev).clone()
+    ops.euler_(img, y.to(dev), dt)
+    assert torch.equal(img.cpu(), x + dt * y)
+
+
+def test_rope_table_and_timestep_embedding(ops, dev):
+    """K13/K12 vs flux_model.py:49-57,82-92 and :95-116."""
+    img_ids, txt_ids = fo.make_ids(2, 16, 16, 24, torch.bfloat16)
+    ids = torch.cat((txt_ids, img_ids), dim=1)
+    ref = fo.rope_table(ids, [16, 56, 56], 10000, torch.bfloat16)  # [B,1,L,64,2,2]
+    pe = ops.rope_table(ids.to(dev), [16, 56, 56], 10000).cpu()
+    assert_bf16_close(pe[..., 0], ref[:, 0, :, :, 0, 0], 1, 0.999, what="rope cos")
+    assert_bf16_close(pe[..., 1], ref[:, 0, :, :, 1, 0], 1, 0.999, what="rope sin")
+    ts = fo.get_schedule(28, 4096)
+    t = torch.tensor(ts[:-1] + [3.5], dtype=torch.float32).bfloat16()  # the 28 bf16-rounded schedule points + guidance
+    ref = fo.timestep_embedding(t, 256).bfloat16()
+    got = ops.timestep_embedding(t.to(dev), ops.timestep_freqs_host().to(dev))
+    assert_bf16_close(got, ref, max_ulp=1, min_exact=0.995, what="timestep embedding")
+
+
+@pytest.mark.parametrize("L,Lt", [(128, 32), (200, 72)])
+def test_qkv_rope(ops, dev, L, Lt):
+    """K5+K6+K11: split + QK RMSNorm (fp32) + RoPE (bf16 arithmetic) + relayout (flux_model.py:351-354,158-176,60-65)."""
+    torch.manual_seed(6)
+    B, H = 2, 3
+    extra = 64  # qkv lives inside a wider row (SingleStreamBlock.linear1 output)
+    qkv_full = torch.randn(B, L, 3 * H * 128 + extra).bfloat16()
+    qkv = qkv_full[..., : 3 * H * 128]
+    s = [(1 + 0.1 * torch.randn(128)).bfloat16() for _ in range(4)]  # txt q,k ; img q,k
+    side = int(math.isqrt(L - Lt)) if int(math.isqrt(L - Lt)) ** 2 == L - Lt else None
+    img_ids = torch.zeros(B, L - Lt, 3, dtype=torch.bfloat16)
+    img_ids[..., 1] = (torch.arange(L - Lt) // 8).bfloat16()
+    img_ids[..., 2] = (torch.arange(L - Lt) % 8).bfloat16()
+    ids = torch.cat((torch.zeros(B, Lt, 3, dtype=torch.bfloat16), img_ids), 1)
+    pe6 = fo.rope_table(ids, [16, 56, 56], 10000, torch.bfloat16)
+    q, k, v = fo.split_heads(qkv, H)
+    qn = torch.cat((fo.rms_norm(q[:, :, :Lt], s[0]), fo.rms_norm(q[:, :, Lt:], s[2])), 2)
+    kn = torch.cat((fo.rms_norm(k[:, :, :Lt], s[1]), fo.rms_norm(k[:, :, Lt:], s[3])), 2)
+    q_ref, k_ref = fo.apply_rope(qn, kn, pe6)
+    pe = torch.stack((pe6[:, 0, :, :, 0, 0], pe6[:, 0, :, :, 1, 0]), -1).contiguous()  # exact table -> isolates this kernel
+    d = lambda t: t.to(dev)
+    Q, K, VT = ops.qkv_rope(d(qkv_full)[..., : 3 * H * 128], d(pe), d(s[0]), d(s[1]), d(s[2]), d(s[3]), split=Lt, heads=H)
+    assert_bf16_close(Q, q_ref, max_ulp=1, min_exact=0.999, what="Q")
+    assert_bf16_close(K, k_ref, max_ulp=1, min_exact=0.999, what="K")
+    # V^T with the bit2<->bit3 key permutation inside every 16-key group, zero padded to Lp
+    Lp = VT.shape[-1]
+    pos = torch.arange(Lp)
+    j = pos % 16
+    key = (pos // 16) * 16 + ((j & 3) | (((j >> 2) & 1) << 3) | (((j >> 3) & 1) << 2))
+    vpad = torch.zeros(B, H, Lp, 128, dtype=torch.bfloat16)
+    vpad[:, :, :L] = v
+    assert torch.equal(VT.cpu(), vpad[:, :, key].transpose(-1, -2))
+
+
+@pytest.mark.parametrize("B,H,L,Lt", [(1, 2, 320, 64), (2, 1, 200, 40), (1, 1, 4608, 512)])
+def test_attention(ops, dev, B, H, L, Lt):
+    """K7: softmax(QK^T/sqrt(128))V vs fp64 (flux_model.py:41-45); bf16 and fused-fp8 outputs."""
+    torch.manual_seed(8)
+    q = torch.randn(B, H, L, 128).bfloat16()
+    k = torch.randn(B, H, L, 128).bfloat16()
+    v = torch.randn(B, H, L, 128).bfloat16()
+    q[:, :, 5] *= 4.0  # a peaky row: exercises the running-max rescale
+    k[:, :, L // 2] *= 3.0
+    ref = fo.attention_fp64(q, k, v).transpose(1, 2).reshape(B, L, H * 128)
+    Lp = (L + 63) // 64 * 64
+    pos = torch.arange(Lp)
+    j = pos % 16
+    key = (pos // 16) * 16 + ((j & 3) | (((j >> 2) & 1) << 3) | (((j >> 3) & 1) << 2))
+    vpad = torch.zeros(B, H, Lp, 128, dtype=torch.bfloat16)
+    vpad[:, :, :L] = v
+    VT = vpad[:, :, key].transpose(-1, -2).contiguous()
+    d = lambda t: t.to(dev)
+    out = ops.attention(d(q), d(k), d(VT)).cpu()
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-2 * v.abs().max().item(), f"attention bf16: max abs err {err}"
+    sdpa = F.scaled_dot_product_attention(q.float(), k.float(), v.float()).transpose(1, 2).reshape(B, L, H * 128)
+    assert (out.float() - sdpa).abs().max().item() <= 2e-2 * v.abs().max().item()
+    # fused quantised output, two scales split at Lt                      float8_quantize.py:274-276
+    s0, s1 = torch.tensor(3000.0), torch.tensor(9000.0)
+    got = ops.attention(d(q), d(k), d(VT), q_scale0=d(s0), q_scale1=d(s1), split=Lt).cpu()
+    deq = torch.cat((got[:, :Lt].float() / s0, got[:, Lt:].float() / s1), 1)
+    # e5m2 has 2 mantissa bits: relative step 2^-2 -> half-step 12.5 %; compare against the quantised bf16 output
+    refq = torch.cat((fo.to_fp8_saturated(out[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float() / s0,
+                      fo.to_fp8_saturated(out[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float() / s1), 1)
+    assert torch.equal(deq, refq), f"fp8 attention output differs from quantise(bf16 output): {(deq != refq).float().mean().item()}"
+
+
+def test_lora_fuse(ops, dev):
+    """Config 5: dequant + B@A + requant on device (lora_loading.py:509-577,615-631 -> float8_quantize.py:209-212)."""
+    torch.manual_seed(12)
+    N, K, R = 384, 256, 16
+    w = (torch.randn(N, K) * 0.05).bfloat16()
+    for chunks in (1, 3):
+        st = fo.F8LinearState(w, None)
+        A = torch.randn(chunks * R, K) * 0.1
+        Bm = torch.randn(N, R) * 0.1
+        alpha = 8.0
+        delta = fo.lora_delta(A, Bm, alpha, 0.8)
+        st_ref_w = (st.dequantized_weight() + delta).type(torch.bfloat16)
+        st2 = fo.F8LinearState(w, None)
+        q = st2.float8_data.to(dev).clone()
+        sc, rc = st2.scale.to(dev).clone(), st2.scale_reciprocal.to(dev).clone()
+        A_scaled = (A * alpha / R)
+        ops.lora_fuse_f8(q, sc, rc, Bm.to(dev), A_scaled.to(dev), 0.8, n_chunks=chunks)
+        st.set_weight_tensor(st_ref_w)
+        assert abs(sc.item() - st.scale.item()) <= 1e-6 * st.scale.item()
+        assert_f8_close(q, st.float8_data, max_ulp=1, min_exact=0.995, what=f"lora fuse chunks={chunks}")
