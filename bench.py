@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoise it/s, Flux-dev 1024x1024, fp8 F8Linear + bf16 flow (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the hot path = one Flux.forward + Euler update of the denoise loop
+(reference flux_pipeline.py:641-651) on one 1024x1024 latent (Li=4096 image tokens + Lt=512 text tokens), inputs
+resident in HBM, replayed from the captured hipGraph.  Synthetic seeded request + random-init weights of the
+Flux-dev architecture (no checkpoint exists offline).  Setup (untimed, like the reference's compile() warm-up,
+flux_pipeline.py:197-212): 13 calibrating steps that freeze the F8Linear input scales.
+N GPUs = N batch-sharded replicas (1 image per GPU, weak scaling); the only collective is the one-off RCCL
+broadcast of the T5/CLIP embeddings + noise before the loop.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel -- the fp8 MX-MFMA GEMM -- from HIP-event
+timings taken live in this process on the launch stream; `cpu_baseline` times the oracle's bf16 flow path (a port of
+the reference's CPU path) on the host cores for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "flux-fp8-api_amd"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+H100_COMPILED_ITS = 11.5  # reference README.md:25 -- the only published number for this metric (other hardware)
+FP8_PEAK_TFLOPS = 5000.0  # MI355X dense fp8 MFMA (MX-scaled K=128/64 opcodes), /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flux_dev_gemm_shapes(Li=4096, Lt=512, H=3072):
+    """(name, M, N, K, launches/step, fused epilogue) for the tiled-GEMM launches of one step."""
+    L, Hm = Li + Lt, 4 * H
+    return [
+        ("double.qkv(img+txt)", (Li, Lt), 3 * H, H, 19), ("double.proj(img+txt)", (Li, Lt), H, H, 19),
+        ("double.mlp0(img+txt)", (Li, Lt), Hm, H, 19), ("double.mlp2(img+txt)", (Li, Lt), H, Hm, 19),
+        ("single.linear1", (L,), 3 * H + Hm, H, 38), ("single.linear2", (L,), H, H + Hm, 38),
+    ]
+
+
+def linear_flops_per_step(Li=4096, Lt=512, H=3072):
+    return sum(2.0 * sum(Ms) * N * K * cnt for _, Ms, N, K, cnt in flux_dev_gemm_shapes(Li, Lt, H))
+
+
+def measure_gemm_roofline(torch, ops, dev, iters=10):
+    """Average duration of one fp8 GEMM launch of the step, HIP events on the launch stream, random operands."""
+    from fluxmi import _lib
+
+    one = torch.tensor(1.0, device=dev)
+    tot_t, tot_f, n_launch = 0.0, 0.0, 0
+    for name, Ms, N, K, cnt in flux_dev_gemm_shapes():
+        groups, keep = [], []
+        for M in Ms:
+            a = (torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2)
+            w = (torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn)
+            o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            keep += [a, w, o]
+            groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), None, one.data_ptr(), one.data_ptr(), o.data_ptr(), M, K, N))
+        fn = lambda: ops.gemm_grouped(groups, N, K, True, _lib.E5M2, _lib.EPI_BF16, -1)
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / iters
+        tot_t += t * cnt
+        tot_f += 2.0 * sum(Ms) * N * K * cnt
+        n_launch += cnt
+    return tot_f / n_launch, tot_t / n_launch  # flops per launch, seconds per launch
+
+
+def cpu_baseline(torch, budget_s=25.0):
+    """Reference CPU flow path (bf16 nn.Linear, no fp8) as restated by oracle/flux_oracle.py, on the host cores:
+    one DoubleStreamBlock + one SingleStreamBlock at the 1024^2 sequence length, extrapolated x19 / x38."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import flux_oracle as fo
+    from fluxmi import synth
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = fo.FluxParams(depth=1, depth_single_blocks=1)
+    sd = synth.make_state_dict(p, seed=0)
+    orc = fo.FluxOracle(sd, p, quantize=None)
+    Li, Lt, H = 4096, 512, p.hidden_size
+    g = torch.Generator().manual_seed(0)
+    img = torch.randn(1, Li, H, generator=g).bfloat16()
+    txt = torch.randn(1, Lt, H, generator=g).bfloat16()
+    vec = torch.randn(1, H, generator=g).bfloat16()
+    img_ids, txt_ids = fo.make_ids(1, 64, 64, Lt, torch.bfloat16)
+    pe = fo.rope_table(torch.cat((txt_ids, img_ids), 1), p.axes_dim, p.theta, torch.bfloat16)
+    with torch.inference_mode():
+        t0 = time.time()
+        orc.double_block(0, img, txt, vec, pe)  # warm-up
+        orc.single_block(0, torch.cat((txt, img), 1), vec, pe)
+        warm = time.time() - t0
+        reps = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
+        t0 = time.time()
+        for _ in range(reps):
+            orc.double_block(0, img, txt, vec, pe)
+        td = (time.time() - t0) / reps
+        t0 = time.time()
+        for _ in range(reps):
+            orc.single_block(0, torch.cat((txt, img), 1), vec, pe)
+        ts = (time.time() - t0) / reps
+    step_s = 19 * td + 38 * ts
+    return {"value": 1.0 / step_s, "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": f"bf16 flow path (no fp8) of the oracle: 1 DoubleStreamBlock ({td:.3f} s) + 1 SingleStreamBlock ({ts:.3f} s) at "
+                      f"L=4608, {reps} reps each, extrapolated to 19+38 blocks = {step_s:.1f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=28)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--depth", type=int, default=None, help="debug only: fewer blocks (the result is then flagged invalid)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as td
+
+    from fluxmi import dist as fdist
+
+    rank, world, local = fdist.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import util
+    from float8_quantize import quantize_flow_transformer_and_dispatch_float8
+    from fluxmi import ops, synth
+
+    cfg = util.load_config(util.ModelVersion.flux_dev, flow_dtype="bfloat16", quantize_modulation=True, quantize_flow_embedder_layers=False)
+    if args.depth is not None:
+        cfg.params.depth, cfg.params.depth_single_blocks = args.depth, 2 * args.depth
+    p = cfg.params
+    t_setup = time.time()
+    with torch.inference_mode():
+        sd = synth.make_state_dict(p, seed=0, device=dev)
+        model = util.load_flow_model(cfg, sd)
+        del sd
+        quantize_flow_transformer_and_dispatch_float8(model, dev, flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
+                                                      quantize_modulation=True, quantize_flow_embedder_layers=False)
+        torch.cuda.empty_cache()
+        # request: rank 0 plays the text-encoder rank; ONE RCCL broadcast of embeddings + noise
+        inp = synth.make_inputs(p, args.height, args.width, 512, batch=world, seed=0)
+        txt, vec, img = (inp[k].to(dev) for k in ("txt", "y", "img"))
+        if world > 1:
+            if rank != 0:
+                txt, vec, img = torch.zeros_like(txt), torch.zeros_like(vec), torch.zeros_like(img)
+            txt, vec, img = fdist.broadcast_request(txt, vec, img, src=0)
+        lo, hi = fdist.shard_bounds(world, rank, world)
+        txt, vec, img = txt[lo:hi].contiguous(), vec[lo:hi].contiguous(), img[lo:hi].contiguous()
+        img_ids, txt_ids = inp["img_ids"][lo:hi].to(dev), inp["txt_ids"][lo:hi].to(dev)
+        Li = img.shape[1]
+        sched = lambda n: util_schedule(n, Li)
+        # calibration (untimed): 13 unfused steps freeze every F8Linear input scale
+        lat = model.denoise(img, img_ids, txt, txt_ids, vec, sched(13), guidance=3.5, use_graph=False)
+        assert model.calibration_state()[0]
+        if args.warmup > 0:
+            model.denoise(img, img_ids, txt, txt_ids, vec, sched(max(args.warmup, 2)), guidance=3.5, use_graph=not args.no_graph)
+        torch.cuda.synchronize()
+        setup_s = time.time() - t_setup
+
+        ts = sched(args.steps)
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = model.denoise(img, img_ids, txt, txt_ids, vec, ts, guidance=3.5, use_graph=not args.no_graph)
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+        elapsed = time.perf_counter() - t0
+        finite = bool(torch.isfinite(out).all())
+        if world > 1:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            elapsed = float(tt.item())
+
+        result = None
+        if rank == 0:
+            ms_per_step = elapsed / args.steps * 1e3
+            its = world * args.steps / elapsed
+            lin_flops = linear_flops_per_step(Li)
+            flops_per_launch, sec_per_launch = measure_gemm_roofline(torch, ops, dev) if (args.height, args.width) == (1024, 1024) else (0.0, 1.0)
+            achieved = flops_per_launch / sec_per_launch / 1e12
+            result = {
+                "metric": "denoise it/s at 1024x1024, Flux-dev, fp8 F8Linear + bf16 flow",
+                "value": round(its, 4), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "fp8_e4m3 weights x fp8_e5m2 activations (fp32 accumulate), bf16 flow",
+                "data": "synthetic seeded request + random-init Flux-dev weights (no checkpoint available offline)",
+                "config": {"workload": f"Flux-dev {args.height}x{args.width}, batch 1 per GPU, Li={Li}+Lt=512 tokens, 19 double + 38 single blocks, "
+                                       "quantize_modulation=true, quantize_flow_embedder_layers=false, hipGraph denoise loop",
+                           "images_per_gpu": 1, "parallelism": f"batch-sharded replicas x{world}", "finite_output": finite,
+                           "depth_override": args.depth},
+                "reference_h100_compiled_its": H100_COMPILED_ITS,
+                "vs_h100_compiled": round(its / world / H100_COMPILED_ITS, 3),
+                "fp8_mfma_fraction_whole_step": round(lin_flops / (ms_per_step * 1e-3) / (FP8_PEAK_TFLOPS * 1e12), 4),
+                "setup_s": round(setup_s, 1),
+                "roofline": {"bound": "mfma", "kernel": "gemm_tile_kernel<fp8 MX-MFMA 32x32x64> (all F8Linear GEMMs of the step)",
+                             "achieved": round(achieved, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(achieved / FP8_PEAK_TFLOPS, 4), "traffic": None,
+                             "flops_per_launch": flops_per_launch, "avg_launch_us": round(sec_per_launch * 1e6, 2)},
+            }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(torch)
+            except Exception as ex:  # the baseline must never take the measurement down
+                result["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {ex}"}
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def util_schedule(num_steps, image_seq_len):
+    """get_schedule + time_shift (reference flux_pipeline.py:314-344), host floats."""
+    import math
+
+    import torch
+
+    ts = torch.linspace(1, 0, num_steps + 1)
+    m = (1.15 - 0.5) / (4096 - 256)
+    mu = m * image_seq_len + (0.5 - m * 256)
+    return (math.exp(mu) / (math.exp(mu) + (1 / ts - 1) ** 1.0)).tolist()
+
+
+if __name__ == "__main__":
+    main()

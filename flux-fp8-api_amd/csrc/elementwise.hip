@@ -73,8 +73,11 @@ __global__ void __launch_bounds__(256) amax_f32_as_bf16_kernel(const float* __re
 }
 
 // scale = clamp(max_val / max(amax, 1e-12), max = max_val); recip = 1/scale      float8_quantize.py:214-215
+// `python_float / tensor` is Tensor.__rtruediv__ = reciprocal(tensor) * scalar in PyTorch: TWO roundings, reproduced
+// here.  The reciprocals go through fp64 (fp64 division of two fp32 values rounds to the correctly rounded fp32 quotient).
+__device__ __forceinline__ float recip_rn(float x) { return (float)(1.0 / (double)x); }
 __device__ __forceinline__ float amax_to_scale(float amax, float max_val) {
-  return fminf(max_val / fmaxf(amax, 1e-12f), max_val);
+  return fminf(recip_rn(fmaxf(amax, 1e-12f)) * max_val, max_val);
 }
 
 // Calibration state machine of F8Linear.quantize_input (float8_quantize.py:220-246), for `n_layers`
@@ -94,7 +97,7 @@ __global__ void calib_update_kernel(const float* __restrict__ amax_p, const Flux
   for (int t = 1; t < upto; ++t) m = fmaxf(m, L.trials[t]);
   const float s = amax_to_scale(m, max_val);
   *L.scale = s;
-  *L.recip = 1.0f / s;
+  *L.recip = recip_rn(s);
 }
 __global__ void calib_update_single_kernel(const float* amax_p, float* trials, float* scale, float* recip, int trial_index,
                                            int num_trials, float max_val) {
@@ -104,13 +107,13 @@ __global__ void calib_update_single_kernel(const float* amax_p, float* trials, f
   for (int t = 1; t < upto; ++t) m = fmaxf(m, trials[t]);
   const float s = amax_to_scale(m, max_val);
   *scale = s;
-  *recip = 1.0f / s;
+  *recip = recip_rn(s);
 }
 // weight scale from amax                                                float8_quantize.py:198-203
 __global__ void weight_scale_kernel(const float* amax_p, float* scale, float* recip, float max_val) {
   const float s = amax_to_scale(*amax_p, max_val);
   *scale = s;
-  *recip = 1.0f / s;
+  *recip = recip_rn(s);
 }
 // fp32 -> (round to bf16) -> fp8 with scale (re-quantise a LoRA-fused weight)   float8_quantize.py:199-202
 template <int FMT>

@@ -1,0 +1,243 @@
+"""FluxPipeline on MI355X -- the pipeline surface of the reference (flux_pipeline.py of aredden/flux-fp8-api)
+over the native fluxmi denoise engine.
+
+Hot path kept here: seed -> noise -> 2x2 patch packing + position ids ->
+shifted schedule -> the Euler denoise loop (natively, hipGraph-replayed) -> unpack.
+Same public names / kwargs / defaults as the reference: FluxPipeline.load_pipeline_from_config_path /
+load_pipeline_from_config / generate / load_lora / unload_lora / compile / set_seed / get_schedule /
+get_noise / prepare / unpack / vae_decode / into_bytes.
+
+Out of scope for this round (SURVEY.md §8f "next" rows): T5/CLIP text conditioning, VAE, JPEG.  Until they
+exist, `generate()` takes the conditioning as pre-computed embeddings (`prompt={"txt": [B,Lt,4096],
+"vec": [B,768]}`) and returns latents unless an autoencoder object is attached.  CPU-offload flags are accepted
+and ignored (meaningless with 288 GB of HBM).  `compile()` keeps the reference's warm-up/calibration protocol
+(flux_pipeline.py:197-212) but never calls torch.compile: the fused kernels + hipGraph replace it.
+"""
+from __future__ import annotations
+
+import io
+import math
+import random
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+import lora_loading  # noqa: F401  (same import side as the reference)
+from fluxmi import dist as fdist
+from util import ModelSpec, ModelVersion, into_device, into_dtype, load_config_from_path, load_models_from_config
+
+MAX_RAND = 2**32 - 1
+
+
+class FluxPipeline:
+    def __init__(self, name: str, offload: bool = False, clip=None, t5=None, model=None, ae=None,
+                 dtype: torch.dtype = torch.float16, verbose: bool = False, flux_device="cuda:0", ae_device="cuda:1",
+                 clip_device="cuda:1", t5_device="cuda:1", config: ModelSpec = None, debug: bool = False):
+        if config is None:
+            raise ValueError("ModelSpec config is required!")
+        self.debug, self.name, self.verbose, self.offload = debug, name, verbose, offload
+        self.device_flux = into_device(flux_device)
+        self.device_ae, self.device_clip, self.device_t5 = into_device(ae_device), into_device(clip_device), into_device(t5_device)
+        self.dtype = into_dtype(dtype)
+        self.clip, self.t5, self.model, self.ae = clip, t5, model, ae
+        self.rng = torch.Generator(device="cpu")
+        self.ae_dtype = torch.bfloat16
+        self.config = config
+        self.offload_text_encoder = config.offload_text_encoder
+        self.offload_vae = config.offload_vae
+        self.offload_flow = config.offload_flow
+        self.model.to(self.device_flux)
+        if config.compile_blocks or config.compile_extras:
+            self.compile()
+
+    # ---- seeds / noise / schedule (reference flux_pipeline.py:126-149, 314-371) -------------------------------
+    def set_seed(self, seed: int | None = None, seed_globally: bool = False):
+        if isinstance(seed, (int, float)):
+            seed = int(abs(seed)) % MAX_RAND
+        elif isinstance(seed, str):
+            try:
+                seed = abs(int(seed)) % MAX_RAND
+            except Exception:
+                seed = abs(self.rng.seed()) % MAX_RAND
+        else:
+            seed = abs(self.rng.seed()) % MAX_RAND
+        generator = torch.Generator(self.device_flux).manual_seed(seed)
+        if seed_globally:
+            torch.cuda.manual_seed_all(seed)
+            np.random.seed(seed)
+            random.seed(seed)
+        return generator, seed
+
+    def time_shift(self, mu: float, sigma: float, t: torch.Tensor):
+        return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+
+    def get_lin_function(self, x1: float = 256, y1: float = 0.5, x2: float = 4096, y2: float = 1.15) -> Callable[[float], float]:
+        m = (y2 - y1) / (x2 - x1)
+        b = y1 - m * x1
+        return lambda x: m * x + b
+
+    def get_schedule(self, num_steps: int, image_seq_len: int, base_shift: float = 0.5, max_shift: float = 1.15,
+                     shift: bool = True) -> list[float]:
+        timesteps = torch.linspace(1, 0, num_steps + 1)
+        if shift:
+            mu = self.get_lin_function(y1=base_shift, y2=max_shift)(image_seq_len)
+            timesteps = self.time_shift(mu, 1.0, timesteps)
+        return timesteps.tolist()
+
+    def get_noise(self, num_samples: int, height: int, width: int, generator: torch.Generator, dtype=None, device=None) -> torch.Tensor:
+        device = self.device_flux if device is None else device
+        dtype = self.dtype if dtype is None else dtype
+        return torch.randn(num_samples, 16, 2 * math.ceil(height / 16), 2 * math.ceil(width / 16), device=device, dtype=dtype,
+                           generator=generator, requires_grad=False)
+
+    # ---- packing / ids (reference flux_pipeline.py:267-292, 440-448) ----------------------------------------------
+    @staticmethod
+    def pack(img: torch.Tensor) -> torch.Tensor:
+        b, c, h, w = img.shape
+        return img.reshape(b, c, h // 2, 2, w // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(b, (h // 2) * (w // 2), c * 4)
+
+    def unpack(self, x: torch.Tensor, height: int, width: int) -> torch.Tensor:
+        b = x.shape[0]
+        h, w = math.ceil(height / 16), math.ceil(width / 16)
+        return x.reshape(b, h, w, -1, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(b, -1, h * 2, w * 2)
+
+    @staticmethod
+    def make_img_ids(bs: int, h2: int, w2: int, device, dtype) -> torch.Tensor:
+        ids = torch.zeros(h2, w2, 3, device=device, dtype=dtype)
+        ids[..., 1] = ids[..., 1] + torch.arange(h2, device=device, dtype=dtype)[:, None]
+        ids[..., 2] = ids[..., 2] + torch.arange(w2, device=device, dtype=dtype)[None, :]
+        return ids[None].repeat(bs, 1, 1, 1).flatten(1, 2)
+
+    @torch.inference_mode()
+    def prepare(self, img: torch.Tensor, prompt, target_device=None, target_dtype=None):
+        """-> img tokens, img_ids, vec, txt, txt_ids (reference flux_pipeline.py:234-312)."""
+        target_device = self.device_flux if target_device is None else target_device
+        target_dtype = self.dtype if target_dtype is None else target_dtype
+        bs, c, h, w = img.shape
+        tokens = self.pack(img)
+        assert tokens.shape == (bs, (h // 2) * (w // 2), c * 4), f"{tokens.shape} != {(bs, (h // 2) * (w // 2), c * 4)}"
+        img_ids = self.make_img_ids(bs, h // 2, w // 2, target_device, target_dtype)
+        if isinstance(prompt, dict):
+            txt = prompt["txt"].to(device=target_device, dtype=target_dtype)
+            vec = prompt["vec"].to(device=target_device, dtype=target_dtype)
+            if txt.shape[0] == 1 and bs > 1:
+                txt, vec = txt.expand(bs, -1, -1), vec.expand(bs, -1)
+        elif self.t5 is not None and self.clip is not None:
+            raise NotImplementedError("T5/CLIP text conditioning is a SURVEY.md §8(f) 'next' row")
+        else:
+            raise NotImplementedError(
+                "fluxmi: no text encoders attached (SURVEY.md §8f row 2). Pass prompt={'txt': T5 states [B,Lt,4096], 'vec': CLIP pooled [B,768]}.")
+        txt_ids = torch.zeros(bs, txt.shape[1], 3, device=target_device, dtype=target_dtype)
+        return tokens, img_ids, vec, txt, txt_ids
+
+    # ---- LoRA (reference flux_pipeline.py:151-177) -------------------------------------------------------------------
+    def load_lora(self, lora_path, scale: float, name: Optional[str] = None):
+        self.model.load_lora(path=lora_path, scale=scale, name=name)
+
+    def unload_lora(self, path_or_identifier: str):
+        self.model.unload_lora(path_or_identifier=path_or_identifier)
+
+    # ---- calibration warm-up (the part of reference compile() that matters, flux_pipeline.py:197-212) -----------------
+    @torch.inference_mode()
+    def compile(self, prompt=None):
+        if self.config.prequantized_flow:
+            return
+        p = self.model.params
+        lt = self.config.text_enc_max_length
+        if prompt is None:
+            g = torch.Generator().manual_seed(10)
+            prompt = {"txt": 0.1 * torch.randn(1, lt, p.context_in_dim, generator=g), "vec": torch.randn(1, p.vec_in_dim, generator=g)}
+        kw = dict(prompt=prompt, height=768, width=768, num_steps=12, guidance=3.5, seed=10, silent=True, output_type="latent")
+        if self.name == ModelVersion.flux_schnell.value or self.name == "flux-schnell":
+            kw["num_steps"] = 4
+            for _ in range(3):
+                self.generate(**kw)
+        else:
+            self.generate(**kw)
+            self.generate(**{**kw, "num_steps": 1})  # 13th call: freezes the input scales
+
+    # ---- the request (reference flux_pipeline.py:526-663) ---------------------------------------------------------------
+    @torch.inference_mode()
+    def generate(self, prompt, width: int = 720, height: int = 1024, num_steps: int = 24, guidance: float = 3.5,
+                 seed: int | None = None, init_image=None, strength: float = 1.0, silent: bool = False, num_images: int = 1,
+                 return_seed: bool = False, jpeg_quality: int = 99, output_type: str = "jpeg", noise: Optional[torch.Tensor] = None,
+                 use_graph: bool = True):
+        num_steps = 4 if self.name == "flux-schnell" else num_steps
+        if init_image is not None:
+            raise NotImplementedError("img2img needs the VAE encoder (SURVEY.md §8f row 1)")
+        height, width = 16 * (height // 16), 16 * (width // 16)
+        generator, seed = self.set_seed(seed)
+        world, rank = fdist.world_size(), fdist.rank()
+        # batch-sharded replicas: every rank denoises its own slice of the batch
+        if noise is None:
+            noise = self.get_noise(num_images, height, width, generator=generator)
+        noise = noise.to(device=self.device_flux, dtype=self.dtype)
+        timesteps = self.get_schedule(num_steps, noise.shape[-1] * noise.shape[-2] // 4, shift=(self.name != "flux-schnell"))
+        img, img_ids, vec, txt, txt_ids = map(lambda x: x.contiguous(), self.prepare(noise, prompt))
+        if world > 1:
+            txt, vec, img = fdist.broadcast_request(txt, vec, img, src=0)
+            lo, hi = fdist.shard_bounds(img.shape[0], rank, world)
+            img, img_ids, vec, txt, txt_ids = (t[lo:hi].contiguous() for t in (img, img_ids, vec, txt, txt_ids))
+        latents = self.model.denoise(img, img_ids, txt, txt_ids, vec, timesteps, guidance=guidance, use_graph=use_graph)
+        if world > 1:
+            latents = fdist.gather_latents(latents, num_images, dst=0)
+        if output_type == "latent" or self.ae is None:
+            out = self.unpack(latents.float(), height, width) if latents is not None else None
+            return (out, seed) if return_seed else out
+        img_px = self.vae_decode(latents, height, width)
+        out = self.into_bytes(img_px, jpeg_quality=jpeg_quality)
+        return (out, seed) if return_seed else out
+
+    def vae_decode(self, x: torch.Tensor, height: int, width: int) -> torch.Tensor:
+        x = self.unpack(x.to(self.device_ae).float(), height, width)
+        with torch.autocast(device_type=self.device_ae.type, dtype=torch.bfloat16, cache_enabled=False):
+            return self.ae.decode(x)
+
+    def into_bytes(self, x: torch.Tensor, jpeg_quality: int = 99) -> io.BytesIO:
+        from PIL import Image
+
+        imgs = [(x[i].clamp(-1, 1).add(1.0).mul(127.5).clamp(0, 255).permute(1, 2, 0).contiguous().to(torch.uint8).cpu().numpy())
+                for i in range(x.shape[0])]
+        im = imgs[0] if len(imgs) == 1 else np.vstack(imgs)
+        buf = io.BytesIO()
+        Image.fromarray(im).save(buf, format="JPEG", quality=jpeg_quality)
+        buf.seek(0)
+        return buf
+
+    # ---- loading (reference flux_pipeline.py:665-729) -------------------------------------------------------------------------
+    @classmethod
+    def load_pipeline_from_config_path(cls, path: str, flow_model_path: str = None, debug: bool = False, **kwargs) -> "FluxPipeline":
+        with torch.inference_mode():
+            config = load_config_from_path(path)
+            if flow_model_path:
+                config.ckpt_path = flow_model_path
+            state_dict = kwargs.pop("state_dict", None)
+            for k, v in kwargs.items():
+                if hasattr(config, k):
+                    setattr(config, k, v)
+            return cls.load_pipeline_from_config(config, debug=debug, state_dict=state_dict)
+
+    @classmethod
+    def load_pipeline_from_config(cls, config: ModelSpec, debug: bool = False, state_dict=None) -> "FluxPipeline":
+        from float8_quantize import quantize_flow_transformer_and_dispatch_float8
+
+        with torch.inference_mode():
+            models = load_models_from_config(config, state_dict=state_dict)
+            config = models.config
+            flux_device = into_device(config.flux_device)
+            flux_dtype = into_dtype(config.flow_dtype)
+            if flux_dtype != torch.bfloat16:
+                raise ValueError("fluxmi implements the bf16 flow path (north star / README.md:92 of the reference); "
+                                 f"override flow_dtype='bfloat16' (got {config.flow_dtype})")
+            flow_model = models.flow
+            if not config.prequantized_flow:
+                flow_model = quantize_flow_transformer_and_dispatch_float8(
+                    flow_model, flux_device, offload_flow=config.offload_flow, swap_linears_with_cublaslinear=False,
+                    flow_dtype=flux_dtype, quantize_modulation=config.quantize_modulation,
+                    quantize_flow_embedder_layers=config.quantize_flow_embedder_layers)
+            else:
+                flow_model.eval().requires_grad_(False)
+        return cls(name=config.version, clip=models.clip, t5=models.t5, model=flow_model, ae=models.ae, dtype=flux_dtype, verbose=False,
+                   flux_device=flux_device, ae_device=into_device(config.ae_device), clip_device=into_device(config.text_enc_device),
+                   t5_device=into_device(config.text_enc_device), config=config, debug=debug)

@@ -48,3 +48,22 @@ def round_fp64_to_bf16(x: torch.Tensor) -> torch.Tensor:
     nudge = torch.where(x.abs() > f.double().abs(), 1, torch.where(x.abs() < f.double().abs(), -1, 0)).to(torch.int32)
     bits = torch.where(tie, bits + nudge, bits)
     return bits.view(torch.float32).to(torch.bfloat16)
+
+
+def assert_close_mag(got, ref, mag=0.0, ulps=1.0, min_exact=0.99, what=""):
+    """|got - ref| <= `ulps` bf16 ulps evaluated at magnitude max(|ref|, mag)  (mag: scalar or tensor).
+
+    `mag` carries the size of the intermediates the value was computed from: results that are small only
+    because of cancellation cannot be reproduced to a ulp of THEIR magnitude by any other summation order.
+    A bf16 ulp at magnitude v is at most v * 2^-7."""
+    g, r = got.detach().cpu().double(), ref.detach().cpu().double()
+    m = mag.detach().cpu().double() if torch.is_tensor(mag) else torch.full_like(r, float(mag))
+    tol = ulps * torch.maximum(r.abs(), m) * 2.0 ** -7
+    err = (g - r).abs()
+    bad = err > tol
+    exact = (g == r).double().mean().item()
+    assert not bad.any() and exact >= min_exact, (
+        f"{what}: {int(bad.sum())} elements beyond {ulps} bf16 ulp (worst err/tol {float((err / tol.clamp_min(1e-300)).max()):.2f}), "
+        f"bit-exact fraction {exact:.5f} (need {min_exact})"
+    )
+    return exact

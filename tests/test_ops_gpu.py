@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 import flux_oracle as fo
-from util import assert_bf16_close, assert_f8_close, round_fp64_to_bf16, ulp_diff
+from parity_util import assert_bf16_close, assert_close_mag, assert_f8_close, round_fp64_to_bf16, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -122,10 +122,18 @@ def test_f8_gemm(ops, dev, cfg, shape, fmt):
     ref = round_fp64_to_bf16(fo.scaled_mm_fp64(a8, w8, sar, sbr, bias))
     out = ops.linear(a8.to(dev), w8.to(dev), bias.to(dev), sar.to(dev), sbr.to(dev), tile_cfg=cfg)
     torch.cuda.synchronize()
-    assert_bf16_close(out, ref, max_ulp=1, min_exact=0.99, what=f"f8 gemm cfg={cfg} {shape}")
-    # and against torch's own CPU _scaled_mm (what the reference executes)
+    noise = accum_noise(a8, w8, sar * sbr)
+    assert_close_mag(out, ref, mag=noise, ulps=1, min_exact=0.98, what=f"f8 gemm cfg={cfg} {shape} vs fp64")
+    # and against torch's own CPU _scaled_mm (what the reference executes; fp32 accumulation like ours)
     ref2 = fo.scaled_mm_ref(a8, w8, sar, sbr, bias)
-    assert_bf16_close(out, ref2, max_ulp=1, min_exact=0.99, what="vs torch._scaled_mm")
+    assert_close_mag(out, ref2, mag=noise, ulps=1, min_exact=0.995, what="vs torch._scaled_mm")
+
+
+def accum_noise(a, w, s):
+    """Magnitude (already in 'bf16-ulp units', i.e. multiplied by 2^7) of fp32 accumulation-order noise:
+    4*sqrt(K)*2^-24 * sum_k|a||w| * s.  Passed as `mag` so that assert_close_mag allows 1 bf16 ulp + this noise."""
+    S = (a.double().abs() @ w.double().abs().T) * float(s)
+    return 4.0 * math.sqrt(a.shape[1]) * 2.0 ** -24 * S * 2.0 ** 7
 
 
 @pytest.mark.parametrize("cfg", [0, 2, 100])
@@ -138,7 +146,7 @@ def test_bf16_gemm(ops, dev, cfg):
     bias = torch.randn(N).bfloat16()
     ref = round_fp64_to_bf16(a.double() @ w.double().T + bias.double())
     out = ops.linear(a.to(dev), w.to(dev), bias.to(dev), tile_cfg=cfg)
-    assert_bf16_close(out, ref, max_ulp=1, min_exact=0.99, what=f"bf16 gemm cfg={cfg}")
+    assert_close_mag(out, ref, mag=accum_noise(a, w, 1.0), ulps=1, min_exact=0.99, what=f"bf16 gemm cfg={cfg}")
 
 
 @pytest.mark.parametrize("cfg", [0, 2, 100])
@@ -197,7 +205,7 @@ def test_gemm_grouped(ops, dev):
         ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_BF16, cfg)
         for (a8, w8, sar, sbr, bias), o in zip(probs, outs):
             ref = round_fp64_to_bf16(fo.scaled_mm_fp64(a8, w8, sar, sbr, bias))
-            assert_bf16_close(o, ref, 1, 0.99, what=f"grouped cfg={cfg} M={a8.shape[0]}")
+            assert_close_mag(o, ref, mag=accum_noise(a8, w8, sar * sbr), ulps=1, min_exact=0.98, what=f"grouped cfg={cfg} M={a8.shape[0]}")
 
 
 @pytest.mark.parametrize("B", [1, 3, 8])
@@ -216,12 +224,14 @@ def test_gemv(ops, dev, B):
                    pre_silu=True)
     ref64 = round_fp64_to_bf16(fo.scaled_mm_fp64(st.quantize_input(F.silu(x)), st.float8_data, st.input_scale_reciprocal,
                                                  st.scale_reciprocal, bias))
-    assert_bf16_close(out, ref64, 1, 0.99, what="gemv fp8")
-    assert_bf16_close(out, ref, 1, 0.99, what="gemv fp8 vs scaled_mm")
+    x8 = st.quantize_input(F.silu(x))
+    noise = accum_noise(x8, st.float8_data, st.input_scale_reciprocal * st.scale_reciprocal)
+    assert_close_mag(out, ref64, mag=noise, ulps=1, min_exact=0.98, what="gemv fp8")
+    assert_close_mag(out, ref, mag=noise, ulps=1, min_exact=0.98, what="gemv fp8 vs scaled_mm")
     # bf16 weights, no prologue
     out = ops.gemv(d(x), d(w), d(bias))
     ref = round_fp64_to_bf16(x.double() @ w.double().T + bias.double())
-    assert_bf16_close(out, ref, 1, 0.99, what="gemv bf16")
+    assert_close_mag(out, ref, mag=accum_noise(x, w, 1.0), ulps=1, min_exact=0.98, what="gemv bf16")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -240,7 +250,10 @@ def test_ln_modulate(ops, dev, H):
     md = mods.to(dev)
     v = lambda a, b: md[:, a * H:b * H]
     got = ops.ln_modulate(x.to(dev), v(0, 1), v(1, 2), v(2, 3), v(3, 4), split=Lt)
-    assert_bf16_close(got, ref, max_ulp=1, min_exact=0.999, what="ln_modulate bf16")
+    mag = torch.empty(B, L, H)
+    mag[:, :Lt] = ((1 + sc0[:, None]) * ln[:, :Lt]).float().abs() + sh0[:, None].float().abs()
+    mag[:, Lt:] = ((1 + sc1[:, None]) * ln[:, Lt:]).float().abs() + sh1[:, None].float().abs()
+    assert_close_mag(got, ref, mag=mag, ulps=1, min_exact=0.999, what="ln_modulate bf16")
     q0, q1 = torch.tensor(900.0), torch.tensor(20000.0)
     refq = torch.empty(B, L, H, dtype=torch.float8_e5m2)
     refq[:, :Lt] = fo.to_fp8_saturated(ref[:, :Lt], q0, 57344.0).to(torch.float8_e5m2)
@@ -255,9 +268,10 @@ def test_act_tables(ops, dev):
     x = x[torch.isfinite(x)]
     x = x[: (x.numel() // 8) * 8].reshape(-1, 8)
     g = ops.act(x.to(dev), 0)
-    assert_bf16_close(g, F.gelu(x, approximate="tanh"), max_ulp=1, min_exact=0.999, what="gelu table")
+    # results below 1e-4 come out of the 1+tanh / 1+exp cancellation: compare those on an absolute 1e-4*2^-7 scale
+    assert_close_mag(g, F.gelu(x, approximate="tanh"), mag=1e-4, ulps=1, min_exact=0.999, what="gelu table")
     s = ops.act(x.to(dev), 1)
-    assert_bf16_close(s, F.silu(x), max_ulp=1, min_exact=0.999, what="silu table")
+    assert_close_mag(s, F.silu(x), mag=1e-4, ulps=1, min_exact=0.999, what="silu table")
 
 
 def test_gate_residual_add_euler(ops, dev):
