@@ -26,7 +26,11 @@ int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8) {
   }
   if (forced >= 0 && fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, forced)) return forced;
   static const int BM[4] = {256, 256, 128, 128}, BN[4] = {256, 128, 128, 256};
-  static const double eff[4] = {1.00, 0.88, 0.74, 0.88};
+  // measured on MI355X (profiles/r01_kernel_sweep.txt): with K = 3072 (24 K-steps) the 128x128 tile at 2 blocks/CU
+  // hides the prologue/epilogue of one block under the main loop of the other and wins by ~1.3x per flop; only the
+  // long-K GEMMs (K >= 12288) amortise the 256x256 tile's fill/drain.
+  const bool long_k = (long long)p.K * (is_fp8 ? 1 : 2) >= 12288;
+  const double eff[4] = {long_k ? 1.05 : 0.75, 0.85, 1.00, 0.85};
   static const int occ[4] = {1, 1, 2, 1};
   int best = -1;
   double best_cost = 1e300;

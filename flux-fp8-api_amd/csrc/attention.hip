@@ -31,7 +31,7 @@ constexpr int V_BYTES = 128 * KT * 2;  // 16 KiB
 constexpr int A_STAGE = K_BYTES + V_BYTES;
 
 template <int FMT>
-__global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
+__global__ void __launch_bounds__(256, 2) attention_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,40 +89,64 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
     const unsigned char* sk = smem + (kt & 1) * A_STAGE;
     const unsigned char* sv = sk + K_BYTES;
 
-    // ---- S^T = K . Q^T : two 32-key tiles -------------------------------------------------------
+    // ---- S^T = K . Q^T : two 32-key tiles, two independent accumulator chains -----------------------
+    // All 8 K fragments of tile 0 are in flight before the first MFMA; tile 1's fragments are fetched
+    // under tile 0's MFMAs (the MFMA chain on one accumulator needs no wait between links).
     v16f st[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-      const int kr = t * 32 + l31;
-      const unsigned char* rowp = sk + kr * 256;
-      const int sw = kr & 15;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const v8bf kf = *(const v8bf*)(rowp + (((c * 2 + hi) ^ sw) << 4));
-        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[c], st[t], 0, 0, 0);
-      }
-    }
-    // ---- online softmax (log2 domain) ------------------------------------------------------------
-    const int kv0 = kt * KT;
-    float mx = -1e30f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = st[t][r] * a.scale_log2;
-        if (kv0 + KT > a.L) {  // ragged last tile: mask keys >= L
-          const int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          s = key < a.L ? s : -1e30f;
-        }
-        st[t][r] = s;
-        mx = fmaxf(mx, s);
+      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+    {
+      const unsigned char* row0 = sk + l31 * 256;
+      const unsigned char* row1 = row0 + 32 * 256;  // (32 + l31) & 15 == l31 & 15: same swizzle key
+      const int sw = l31 & 15;
+      v8bf ka[8], kb[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ka[c] = *(const v8bf*)(row0 + (((c * 2 + hi) ^ sw) << 4));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        kb[c] = *(const v8bf*)(row1 + (((c * 2 + hi) ^ sw) << 4));
+        st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[c], qf[c], st[0], 0, 0, 0);
       }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[c], qf[c], st[1], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    // ---- online softmax (log2 domain) ------------------------------------------------------------
+    const int kv0 = kt * KT;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[t][r] *= a.scale_log2;
+    if (kv0 + KT > a.L) {  // ragged last tile only: mask keys >= L (kept a real branch, not 64 selects per tile)
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          st[t][r] = key < a.L ? st[t][r] : -1e30f;
+        }
+    }
+    float mx = st[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
+    if (__any(m_new > m_run)) {  // wave-uniform; once the running max has settled the O rescale is skipped exactly
+      asm volatile("" ::: "memory");
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_part *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      m_run = m_new;
+    }
     float psum = 0.f;
     v8bf pf[4];
 #pragma unroll
@@ -131,26 +155,40 @@ __global__ void __launch_bounds__(256) attention_kernel(const AttnArgs a) {
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float p = exp2f(st[t][u * 8 + e] - m_new);
+          const float p = __builtin_amdgcn_exp2f(st[t][u * 8 + e] - m_run);
           psum += p;
           pf[t * 2 + u][e] = (bf16)p;
         }
-    l_part = l_part * alpha + psum;
+    l_part += psum;
+    // ---- O^T += V^T . P^T : four independent accumulators, fragments fetched two key-chunks ahead -----
+    {
+      const unsigned char* vrow[4];
+      int vsw[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-    // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      const int d = db * 32 + l31;
-      const unsigned char* rowp = sv + d * 128;
-      const int sw = (d >> 1) & 7;
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        const v8bf vf = *(const v8bf*)(rowp + (((ch * 2 + hi) ^ sw) << 4));
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ch], o[db], 0, 0, 0);
+      for (int db = 0; db < 4; ++db) {
+        const int d = db * 32 + l31;
+        vrow[db] = sv + d * 128;
+        vsw[db] = (d >> 1) & 7;
       }
+      v8bf va[8], vb[8];
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) va[ch * 4 + db] = *(const v8bf*)(vrow[db] + (((ch * 2 + hi) ^ vsw[db]) << 4));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          vb[ch * 4 + db] = *(const v8bf*)(vrow[db] + ((((ch + 2) * 2 + hi) ^ vsw[db]) << 4));
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[ch * 4 + db], pf[ch], o[db], 0, 0, 0);
+        }
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[ch * 4 + db], pf[ch + 2], o[db], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
   }
 

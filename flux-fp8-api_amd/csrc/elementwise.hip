@@ -43,6 +43,18 @@ __global__ void __launch_bounds__(256) dequant_kernel(const unsigned char* __res
   }
 }
 
+// wave shuffle -> LDS -> ONE atomic per block (16 K same-address atomics from per-wave updates cost ~150 us)
+__device__ __forceinline__ void block_atomic_max(float m, float* amax) {
+  __shared__ float part[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    if (m > 0.f) atomicMax((unsigned*)amax, __float_as_uint(m));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // amax = max(|x|) accumulated into *amax (float bits, atomic max valid for non-negative floats)
 //                                                                        float8_quantize.py:198,227
@@ -59,8 +71,7 @@ __global__ void __launch_bounds__(256) amax_kernel(const u16* __restrict__ x, fl
 #pragma unroll
     for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(f[j]));
   }
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)amax, __float_as_uint(m));
+  block_atomic_max(m, amax);
 }
 
 // amax of an fp32 tensor after rounding each element to bf16 (LoRA-fused weights: weight.type(dtype))
@@ -68,8 +79,7 @@ __global__ void __launch_bounds__(256) amax_f32_as_bf16_kernel(const float* __re
   float m = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     m = fmaxf(m, fabsf(rbf(x[i])));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)amax, __float_as_uint(m));
+  block_atomic_max(m, amax);
 }
 
 // scale = clamp(max_val / max(amax, 1e-12), max = max_val); recip = 1/scale      float8_quantize.py:214-215
@@ -348,7 +358,7 @@ int fluxmi_k_quantize_act(const void* x, void* q, const float* scale, int rows, 
 int fluxmi_k_amax(const void* x, float* amax, int rows, int cols, long long ld, hipStream_t s) {
   FLUXMI_REQUIRE(cols % 8 == 0 && ld % 8 == 0, "amax: cols/ld must be multiples of 8");
   if (rows == 0 || cols == 0) return 0;
-  hipLaunchKernelGGL(amax_kernel, dim3(grid_for((long long)rows * (cols / 8))), dim3(256), 0, s, (const u16*)x, amax, rows, cols, ld);
+  hipLaunchKernelGGL(amax_kernel, dim3(grid_for((long long)rows * (cols / 8), 256, 1024)), dim3(256), 0, s, (const u16*)x, amax, rows, cols, ld);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }
@@ -394,7 +404,7 @@ int fluxmi_k_requantize_f32(const float* w32, void* q, float* amax_tmp, float* s
                             hipStream_t s) {
   FLUXMI_REQUIRE(n % 4 == 0, "requantize: n must be a multiple of 4");
   FLUXMI_CHECK_HIP(hipMemsetAsync(amax_tmp, 0, sizeof(float), s));
-  hipLaunchKernelGGL(amax_f32_as_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, w32, amax_tmp, n);
+  hipLaunchKernelGGL(amax_f32_as_bf16_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, w32, amax_tmp, n);
   const float mx = fmt == FLUXMI_FMT_E5M2 ? 57344.f : 448.f;
   hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1), 0, s, amax_tmp, scale, recip, mx);
   if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL(quantize_f32_kernel<FLUXMI_FMT_E5M2>, dim3(grid_for(n / 4)), dim3(256), 0, s, w32, (unsigned char*)q, scale, n);
