@@ -1,0 +1,175 @@
+"""CPU (no GPU): the C ABI library loads and exports exactly what include/fluxmi.h declares, argument validation
+returns errors instead of crashing, and the host-side mirror of the reference API behaves like the reference."""
+import ctypes as C
+import glob
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "fluxmi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fluxmi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fluxmi import _lib
+
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(_lib.lib, s), f"libfluxmi.so does not export {s}"
+    assert set(_lib.EXPORTS) == set(syms), f"ctypes table out of sync with the header: {set(_lib.EXPORTS) ^ set(syms)}"
+    assert _lib.lib.fluxmi_abi_version() == 1
+
+
+def test_errors_are_returned_not_thrown():
+    from fluxmi import _lib
+
+    lib = _lib.lib
+    assert lib.fluxmi_amax(None, None, 1, 7, 7, None) == 1 and b"multiples of 8" in lib.fluxmi_last_error()
+    g = (_lib.GemmGroup * 1)()
+    assert lib.fluxmi_gemm_grouped(g, 0, 128, 128, 1, 1, 0, -1, None) == 1
+    assert lib.fluxmi_gemm_grouped(g, 1, 0, 128, 1, 1, 0, -1, None) == 1
+    g[0].M = 5
+    assert lib.fluxmi_gemm_grouped(g, 1, 128, 128, 1, 1, 0, -1, None) == 1 and b"NULL" in lib.fluxmi_last_error()
+    assert lib.fluxmi_calib_update(None, None, None, None, 13, 12, 1.0, None) == 1
+    d = _lib.ModelDesc()
+    d.hidden, d.heads, d.depth, d.depth_single, d.guidance_embed = 256, 4, 1, 1, 1  # head_dim 64: unsupported
+    d.axes_dim = (C.c_int * 3)(16, 56, 56)
+    d.num_trials = 12
+    n = lib.fluxmi_engine_num_linears(C.byref(d))
+    assert n == 6 + 2 + 10 + 3 + 2
+    lin = (_lib.Linear * n)()
+    nrm = (C.c_void_p * 6)()
+    h = C.c_void_p()
+    assert lib.fluxmi_engine_create(C.byref(d), lin, n, nrm, 6, C.byref(h)) == 1 and b"head_dim" in lib.fluxmi_last_error()
+    with pytest.raises(RuntimeError, match="fluxmi"):
+        _lib.call("fluxmi_quantize_act", None, None, None, 1, 7, 7, 7, 1, None)
+
+
+def test_struct_layouts_match_the_header():
+    from fluxmi import _lib
+
+    assert C.sizeof(_lib.GemmGroup) == 10 * 8 + 4 * 8 + 4 * 4
+    assert C.sizeof(_lib.Linear) == 6 * 8 + 4 * 4
+    assert C.sizeof(_lib.ModelDesc) == 14 * 4
+
+
+def test_ops_refuse_cpu_tensors():
+    from fluxmi import ops
+
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.quantize_act(torch.zeros(2, 8, dtype=torch.bfloat16), torch.ones(()))
+
+
+# ---- config surface (reference util.py:38-79, 122-222) ----------------------------------------------------------
+def test_modelspec_defaults_and_load_config():
+    import util
+
+    cfg = util.load_config(util.ModelVersion.flux_dev)
+    assert cfg.quantize_modulation is True and cfg.quantize_flow_embedder_layers is False
+    assert cfg.flow_dtype == "float16" and cfg.text_enc_max_length == 512 and cfg.params.guidance_embed
+    s = util.load_config(util.ModelVersion.flux_schnell)
+    assert s.text_enc_max_length == 256 and not s.params.guidance_embed and s.repo_flow == "flux1-schnell.sft"
+    assert (cfg.params.depth, cfg.params.depth_single_blocks, cfg.params.hidden_size, cfg.params.num_heads) == (19, 38, 3072, 24)
+    with pytest.raises(ValueError):
+        util.into_dtype("float64")
+    with pytest.raises(ValueError):
+        util.load_config_from_path("/nonexistent.json")
+    assert util.into_device(1) == torch.device("cuda:1") and util.into_device(None) == torch.device("cuda:0")
+
+
+def test_config_jsons_load(tmp_path):
+    import util
+
+    files = sorted(glob.glob(os.path.join(ROOT, "flux-fp8-api_amd", "configs", "*.json")))
+    files += sorted(glob.glob("/root/reference/configs/*.json"))  # present in the build container only
+    assert files
+    for f in files:
+        cfg = util.load_config_from_path(f)
+        assert cfg.params.hidden_size == 3072
+    # unknown keys (the reference's own JSONs carry offload_ae / offload_text_enc) are ignored
+    d = json.load(open(files[0]))
+    d["offload_ae"] = True
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps(d))
+    assert util.load_config_from_path(str(p)).offload_vae is False
+
+
+def test_flux_module_tree_matches_bfl_state_dict():
+    import util
+    from fluxmi import synth
+
+    cfg = util.load_config(util.ModelVersion.flux_dev, flow_dtype="bfloat16")
+    p = cfg.params
+    p.hidden_size, p.num_heads, p.depth, p.depth_single_blocks, p.context_in_dim, p.vec_in_dim = 256, 2, 2, 3, 128, 64
+    sd = synth.make_state_dict(p, seed=0)
+    m = util.load_flow_model(cfg, sd)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    assert len(m.linear_modules()) == 6 + 2 + 2 * 10 + 3 * 3 + 2
+    # walked-by-name attributes the reference relies on (float8_quantize.py:447-455, lora_loading.py:466-473)
+    for name in ("double_blocks.1.img_attn.qkv", "double_blocks.0.txt_mlp.2", "single_blocks.2.linear2", "single_blocks.0.modulation.lin",
+                 "final_layer.adaLN_modulation.1", "time_in.out_layer", "guidance_in.in_layer", "double_blocks.0.img_attn.norm.key_norm"):
+        m.get_submodule(name)
+    with pytest.raises(ValueError):
+        bad = util.load_config(util.ModelVersion.flux_dev)
+        bad.params.axes_dim = [16, 56, 40]
+        util.load_flow_model(bad)
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3), None, torch.zeros(1, 2, 3), None, None, None)
+
+
+def test_prequantized_state_dict_format():
+    """F8Linear._load_from_state_dict keeps the reference's checkpoint format (float8_quantize.py:91-193)."""
+    from float8_quantize import F8Linear
+
+    lin = F8Linear(16, 8, bias=True, dtype=torch.bfloat16)
+    sd = {"weight": torch.zeros(1, dtype=torch.bfloat16), "bias": torch.ones(8, dtype=torch.bfloat16),
+          "float8_data": torch.randn(8, 16).to(torch.float8_e4m3fn), "scale": torch.tensor(3.0), "scale_reciprocal": torch.tensor(1 / 3.0),
+          "input_scale": torch.tensor(5.0), "input_scale_reciprocal": torch.tensor(0.2)}
+    lin.load_state_dict(sd, assign=True)
+    assert lin.weight_initialized and lin.input_scale_initialized and lin.trial_index == lin.num_scale_trials
+    assert lin.scale.item() == 3.0 and lin.input_scale.item() == 5.0 and lin.weight.shape == (1,)
+    lin2 = F8Linear(16, 8, bias=True, dtype=torch.bfloat16)
+    del sd["input_scale"], sd["input_scale_reciprocal"]
+    lin2.load_state_dict(sd, assign=True)
+    assert lin2.weight_initialized and not lin2.input_scale_initialized and lin2.trial_index == 0
+    lin3 = F8Linear(16, 8, bias=True, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        lin3.load_state_dict({"weight": torch.zeros(3, 3, dtype=torch.bfloat16)}, assign=True)
+    assert set(k for k, _ in lin.named_buffers()) >= {"float8_data", "scale", "scale_reciprocal", "input_scale", "input_scale_reciprocal"}
+
+
+def test_pipeline_schedule_pack_unpack_match_oracle():
+    import flux_oracle as fo
+    from flux_pipeline import FluxPipeline
+
+    pipe = FluxPipeline.__new__(FluxPipeline)
+    assert pipe.get_schedule(28, 4096) == fo.get_schedule(28, 4096)
+    assert pipe.get_schedule(4, 256, shift=False) == fo.get_schedule(4, 256, shift=False)
+    x = torch.randn(2, 16, 8, 12)
+    assert torch.equal(FluxPipeline.pack(x), fo.pack_latent(x))
+    assert torch.equal(pipe.unpack(FluxPipeline.pack(x), 64, 96), x)
+    ids = FluxPipeline.make_img_ids(2, 4, 6, "cpu", torch.bfloat16)
+    assert torch.equal(ids, fo.make_ids(2, 4, 6, 3, torch.bfloat16)[0])
+
+
+def test_kohya_lora_keys_convert():
+    import lora_loading as ll
+
+    sd = {"lora_unet_double_blocks_0_img_attn_qkv.lora_down.weight": torch.zeros(4, 8),
+          "lora_unet_double_blocks_0_img_attn_qkv.lora_up.weight": torch.zeros(24, 4),
+          "lora_unet_double_blocks_0_img_attn_qkv.alpha": torch.tensor(4.0),
+          "lora_unet_single_blocks_11_linear2.lora_down.weight": torch.zeros(4, 8),
+          "lora_unet_double_blocks_3_txt_mlp_2.lora_up.weight": torch.zeros(8, 4)}
+    out = ll._kohya_to_bfl(sd)
+    assert set(out) == {"double_blocks.0.img_attn.qkv.lora_A.weight", "double_blocks.0.img_attn.qkv.lora_B.weight",
+                        "double_blocks.0.img_attn.qkv.alpha", "single_blocks.11.linear2.lora_A.weight", "double_blocks.3.txt_mlp.2.lora_B.weight"}
+    assert ll._keys_without_ab(out) == ["double_blocks.0.img_attn.qkv", "double_blocks.3.txt_mlp.2", "single_blocks.11.linear2"]

@@ -1,0 +1,88 @@
+"""CPU, world_size 2 over gloo: the only multi-GPU exchanges of the path -- one flat broadcast of
+the T5/CLIP embeddings + noise before the loop, batch sharding, gather of the latents, MAX all-reduce of calibration
+amax values.  The same code runs over backend "nccl" (= RCCL/xGMI) on the GPUs."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, batch, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "flux-fp8-api_amd"))
+    from fluxmi import dist as fdist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = fdist.init_from_env("gloo")
+    assert (r, w) == (rank, world) and fdist.is_dist()
+    g = torch.Generator().manual_seed(0)
+    txt = torch.randn(batch, 6, 16, generator=g).bfloat16()
+    vec = torch.randn(batch, 8, generator=g).bfloat16()
+    noise = torch.randn(batch, 12, 4, generator=g).bfloat16()
+    ref = (txt.clone(), vec.clone(), noise.clone())
+    if rank != 0:  # only the text-encoder rank holds the conditioning
+        txt, vec, noise = torch.zeros_like(txt), torch.zeros_like(vec), torch.zeros_like(noise)
+    txt, vec, noise = fdist.broadcast_request(txt, vec, noise, src=0)
+    ok = all(torch.equal(a, b) for a, b in zip((txt, vec, noise), ref))
+    lo, hi = fdist.shard_bounds(batch, rank, world)
+    # "denoise" the local shard: a per-sample function, no cross-sample interaction
+    local = noise[lo:hi] * 2 + txt[lo:hi].float().mean(dim=(1, 2), keepdim=True).bfloat16()
+    full = fdist.gather_latents(local.contiguous(), batch, dst=0)
+    if rank == 0:
+        expect = ref[2] * 2 + ref[0].float().mean(dim=(1, 2), keepdim=True).bfloat16()
+        ok = ok and torch.equal(full, expect)
+    else:
+        ok = ok and full is None
+    am = torch.tensor([1.0 + rank, 5.0 - rank, 0.5])
+    fdist.allreduce_amax(am)
+    ok = ok and am.tolist() == [float(world), 5.0, 0.5]
+    q.put((rank, bool(ok), (lo, hi)))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [2, 3, 8])
+def test_two_rank_request_broadcast_shard_gather(batch):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    (lo0, hi0), (lo1, hi1) = res[0][2], res[1][2]
+    assert lo0 == 0 and hi0 == lo1 and hi1 == batch and abs((hi0 - lo0) - (hi1 - lo1)) <= 1
+
+
+def test_shard_bounds_cover_and_balance():
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "flux-fp8-api_amd"))
+    from fluxmi.dist import shard_bounds
+
+    for batch in (1, 2, 7, 8, 9, 64):
+        for world in (1, 2, 4, 8):
+            b = [shard_bounds(batch, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == batch
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_bounds(8, 3, 8) == (3, 4)  # configs[3]: batch 8, one image per GPU

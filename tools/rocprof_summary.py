@@ -1,0 +1,49 @@
+"""Turn a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel trace into the plain-text per-kernel summary that is
+committed under profiles/:   python tools/rocprof_summary.py <dir-with-*.db> [-o profiles/xyz.txt] [--steady]"""
+import argparse
+import glob
+import os
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    if name.startswith("at::native") or "at::native" in name[:40]:
+        m = re.search(r"at::native::(?:\(anonymous namespace\)::)?([A-Za-z_0-9]+)", name)
+        return "torch::" + (m.group(1) if m else "kernel") + "<...>"
+    return name if len(name) <= 110 else name[:107] + "..."
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("path")
+    ap.add_argument("-o", "--out", default=None)
+    ap.add_argument("--header", default="")
+    args = ap.parse_args()
+    dbs = glob.glob(os.path.join(args.path, "**", "*.db"), recursive=True) if os.path.isdir(args.path) else [args.path]
+    if not dbs:
+        sys.exit("no .db found under " + args.path)
+    rows = {}
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+            k = short(name)
+            c, t = rows.get(k, (0, 0.0))
+            rows[k] = (c + calls, t + total)
+    tot = sum(t for _, t in rows.values())
+    lines = [args.header] if args.header else []
+    lines.append(f"{'kernel':112s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'%':>6s}")
+    for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        lines.append(f"{k:112s} {c:7d} {t:12.1f} {t / c:10.2f} {100 * t / tot:6.2f}")
+    text = "\n".join(lines) + "\n"
+    if args.out:
+        os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+        open(args.out, "w").write(text)
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
