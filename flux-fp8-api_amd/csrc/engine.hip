@@ -94,7 +94,7 @@ int run_gemm(std::vector<FluxmiGemmGroup>& gs, int N, int K, int is_fp8, int act
     for (int i = 0; i < p.n_groups; ++i) p.g[i] = gs[off + i];
     p.N = N; p.K = K; p.epi = epi;
     const int cfg = fluxmi_gemm_auto_cfg(p, is_fp8);
-    const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % ((cfg == 0 || cfg == 3) ? 256 : 128) == 0);
+    const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0);
     if (cfg < 0 || !split_ok) FLUXMI_TRY(fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, s));
     else FLUXMI_TRY(fluxmi_launch_gemm(p, is_fp8, act_fmt, cfg, s));
   }

@@ -18,77 +18,9 @@
 //  * 1-D grid, XCD-aware bijective remap + grouped (GROUP_M) rasterisation so the 32 tiles resident
 //    on one XCD share A/W panels through that XCD's private 4 MiB L2.
 //  * grouped launch: up to 16 independent problems (txt/img streams x batch) sharing N,K in one grid.
-#include "common.h"
-#include "fluxmi_internal.h"
+#include "gemm_epilogue.h"
 
 namespace {
-
-template <int CNT> __device__ __forceinline__ void load_bf(const void* base, long long idx, float* out) {
-  const u16* p = (const u16*)base + idx;
-  if constexpr (CNT == 4) {
-    uint2 v = *(const uint2*)p;
-    out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
-    out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
-  } else {
-    out[0] = bf2f(p[0]);
-  }
-}
-template <int CNT> __device__ __forceinline__ void store_bf(void* base, long long idx, const float* v) {
-  u16* p = (u16*)base + idx;
-  if constexpr (CNT == 4) {
-    uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-    *(uint2*)p = o;
-  } else {
-    p[0] = f2bf(v[0]);
-  }
-}
-template <int FMT, int CNT> __device__ __forceinline__ void store_q(void* base, long long idx, const float* v, float qs) {
-  unsigned char* p = (unsigned char*)base + idx;
-  if constexpr (CNT == 4) {
-    *(unsigned*)p = cvt4_fp8<FMT>(q_prepare<FMT>(v[0], qs), q_prepare<FMT>(v[1], qs),
-                                  q_prepare<FMT>(v[2], qs), q_prepare<FMT>(v[3], qs));
-  } else {
-    p[0] = (unsigned char)(cvt2_fp8<FMT>(q_prepare<FMT>(v[0], qs), 0.f) & 0xff);
-  }
-}
-
-// h = bf16(acc*s + bias) already applied by the caller; h holds CNT consecutive columns n..n+CNT-1 of row m
-template <int EPI, int FMT, int CNT>
-__device__ __forceinline__ void epilogue(const FluxmiGemmGroup& G, float qs, int m, int n,
-                                         const float* h, const float* gate) {
-  if constexpr (EPI == FLUXMI_EPI_SPLIT) {
-    if (n < G.split_n) {
-      store_bf<CNT>(G.C, (long long)m * G.ldc + n, h);
-    } else {
-      float g[CNT];
-#pragma unroll
-      for (int j = 0; j < CNT; ++j) g[j] = rbf(gelu_tanh_f(h[j]));
-      store_q<FMT, CNT>(G.C2, (long long)m * G.ldc2 + G.c2_col0 + (n - G.split_n), g, qs);
-    }
-  } else if constexpr (EPI == FLUXMI_EPI_BF16) {
-    store_bf<CNT>(G.C, (long long)m * G.ldc + n, h);
-  } else if constexpr (EPI == FLUXMI_EPI_GELU_QUANT) {
-    float g[CNT];
-#pragma unroll
-    for (int j = 0; j < CNT; ++j) g[j] = rbf(gelu_tanh_f(h[j]));
-    store_q<FMT, CNT>(G.C, (long long)m * G.ldc + n, g, qs);
-  } else if constexpr (EPI == FLUXMI_EPI_SILU_QUANT) {
-    float g[CNT];
-#pragma unroll
-    for (int j = 0; j < CNT; ++j) g[j] = rbf(silu_f(h[j]));
-    store_q<FMT, CNT>(G.C, (long long)m * G.ldc + n, g, qs);
-  } else if constexpr (EPI == FLUXMI_EPI_QUANT) {
-    store_q<FMT, CNT>(G.C, (long long)m * G.ldc + n, h, qs);
-  } else if constexpr (EPI == FLUXMI_EPI_GATE_RESID) {
-    float r[CNT], o[CNT];
-    load_bf<CNT>(G.resid, (long long)m * G.ldr + n, r);
-#pragma unroll
-    for (int j = 0; j < CNT; ++j) o[j] = r[j] + rbf(gate[j] * h[j]);
-    store_bf<CNT>(G.C, (long long)m * G.ldc + n, o);
-  }
-}
-
-__device__ __forceinline__ float load_scale(const float* p) { return p ? *p : 1.0f; }
 
 // Per-wave epilogue over its TM x TN grid of 32x32 accumulator tiles.  Lane (l31, hi) owns row
 // m = mrow0 + 32*i and columns n = ncol0 + 32*j + 8*g4 + [0,4)  (C/D layout of the 32x32 MFMA with
@@ -352,12 +284,17 @@ int launch_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
 
 }  // namespace
 
-static const int kTileBN[4] = {256, 128, 128, 256};
+// tile configs: 0..3 = double-buffered kernels of this file, 4..6 = ring kernels of gemm_ring.hip
+static const int kTileBN[7] = {256, 128, 128, 256, 256, 128, 128};
+int fluxmi_launch_gemm_ring(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s);
+
+int fluxmi_gemm_tile_bn(int cfg) { return (cfg >= 0 && cfg < 7) ? kTileBN[cfg] : 0; }
 
 int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg) {
-  if (cfg < 0 || cfg > 3) return 0;
+  if (cfg < 0 || cfg > 6) return 0;
   const int kb = K * (is_fp8 ? 1 : 2);
-  return (N % kTileBN[cfg] == 0) && (kb % 128 == 0) && kb >= 128;
+  const int kstep = cfg >= 4 ? 64 : 128;
+  return (N % kTileBN[cfg] == 0) && (kb % kstep == 0) && kb >= kstep;
 }
 
 int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s) {
@@ -365,6 +302,7 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
   FLUXMI_REQUIRE(fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, cfg), "gemm: shape N=%d K=%d not tileable with cfg %d", p.N, p.K, cfg);
   if (p.epi == FLUXMI_EPI_SPLIT)
     FLUXMI_REQUIRE(p.g[0].split_n % kTileBN[cfg] == 0, "gemm: split_n=%d must be a multiple of the N tile", p.g[0].split_n);
+  if (cfg >= 4) return fluxmi_launch_gemm_ring(p, is_fp8, act_fmt, cfg, s);
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) return launch_cfg<true, FLUXMI_FMT_E5M2>(p, cfg, s);
     return launch_cfg<true, FLUXMI_FMT_E4M3>(p, cfg, s);
