@@ -25,23 +25,27 @@ int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8) {
     forced = e ? atoi(e) : -1;
   }
   if (forced >= 0 && fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, forced)) return forced;
-  static const int BM[4] = {256, 256, 128, 128}, BN[4] = {256, 128, 128, 256};
-  // measured on MI355X (profiles/r01_kernel_sweep.txt): with K = 3072 (24 K-steps) the 128x128 tile at 2 blocks/CU
-  // hides the prologue/epilogue of one block under the main loop of the other and wins by ~1.3x per flop; only the
-  // long-K GEMMs (K >= 12288) amortise the 256x256 tile's fill/drain.
-  const bool long_k = (long long)p.K * (is_fp8 ? 1 : 2) >= 12288;
-  const double eff[4] = {long_k ? 1.05 : 0.75, 0.85, 1.00, 0.85};
-  static const int occ[4] = {1, 1, 2, 1};
+  // candidates, in order of preference at equal cost; eff = measured relative rate per flop on MI355X at full occupancy
+  // (profiles/r01_kernel_sweep.txt): 13 = 256x256 ping-pong ring (1 block/CU), 2 = 128x128 double-buffered (2 blocks/CU),
+  // 1 = 256x128, 3 = 128x256, 0 = 256x256 double-buffered.  Cost = (number of block waves) x (time of one wave of blocks).
+  static const int cand[5] = {13, 2, 1, 3, 0};
+  static const double eff[5] = {1.00, 0.84, 0.78, 0.78, 0.80};
+  static const int occ[5] = {1, 2, 1, 1, 1};
   int best = -1;
   double best_cost = 1e300;
-  for (int c = 0; c < 4; ++c) {
+  for (int ci = 0; ci < 5; ++ci) {
+    const int c = cand[ci];
     if (!fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, c)) continue;
+    const int bm = fluxmi_gemm_tile_bm(c), bn = fluxmi_gemm_tile_bn(c);
     long long tiles = 0;
-    for (int i = 0; i < p.n_groups; ++i) tiles += (p.g[i].M + BM[c] - 1) / BM[c];
-    tiles *= p.N / BN[c];
-    const long long slots = 256LL * occ[c];
+    for (int i = 0; i < p.n_groups; ++i) tiles += (p.g[i].M + bm - 1) / bm;
+    tiles *= p.N / bn;
+    const long long slots = 256LL * occ[ci];
     const long long waves = (tiles + slots - 1) / slots;
-    const double cost = (double)waves * occ[c] * (double)BM[c] * BN[c] / eff[c];
+    // a last wave that fills less than half of a 2-blocks/CU machine runs its blocks alone on their CUs (~1.6x faster)
+    double w = (double)waves;
+    if (occ[ci] == 2 && tiles - (waves - 1) * slots <= 256) w -= 0.4;
+    const double cost = w * occ[ci] * (double)bm * bn / eff[ci];
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;

@@ -89,16 +89,20 @@ template <> __device__ __forceinline__ float fp8_to_f32<FLUXMI_FMT_E5M2>(unsigne
 
 // ---- activations (fp32 internals exactly as ATen evaluates them on a bf16 tensor) -------------
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // aten GeluKernel (approximate="tanh"): 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
-  const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
-  float inner = kBeta * (x + kKappa * (x * x * x));
-  float a = fabsf(inner);
-  float e = __expf(2.0f * a);
-  float t = 1.0f - 2.0f / (e + 1.0f);
-  t = copysignf(t, inner);
+  // aten GeluKernel (approximate="tanh"): (0.5*x)*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715*x^3), all in fp32.
+  // tanh(u) = 2*sigmoid(2u)-1 with sigmoid(2u) = 1/(1 + 2^(x*(c1 + c2*x^2))), c1 = -2*log2(e)*sqrt(2/pi), c2 = 0.044715*c1:
+  // 7 plain VALU ops + v_exp_f32 + v_rcp_f32 instead of ~20 with an IEEE division.  tanh is rounded to fp32 BEFORE the
+  // "1 +" exactly as aten does, so the catastrophic cancellation of the negative tail (x < -3, result -> -0 below -5.2)
+  // is reproduced rather than "fixed"; every caller then rounds to bf16 (>= 99.9 % bit-equal to F.gelu over all bf16 inputs).
+  const float c1 = -2.3022081981f, c2 = -0.10294323958f;
+  const float z = x * fmaf(x * x, c2, c1);
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+  const float t = fmaf(2.0f, s, -1.0f);
   return (0.5f * x) * (1.0f + t);
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 // ---- wave-level reductions (wave = 64) ---------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -58,6 +58,7 @@ void fluxmi_set_error(const char* fmt, ...);
 // ---- internal launchers (defined in the .hip files) --------------------------------------------
 int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg);
 int fluxmi_gemm_tile_bn(int cfg);
+int fluxmi_gemm_tile_bm(int cfg);
 int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int tile_cfg, hipStream_t s);
 int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
 int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8);

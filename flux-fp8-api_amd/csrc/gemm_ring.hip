@@ -103,12 +103,12 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool FP8, int ACT_FMT>
-__global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const FluxmiGemmParams P) {
+template <int BM, int BN, int WM, int WN, int NS, bool SPREAD, bool FP8, int ACT_FMT, int ABL = 0>
+__global__ void __launch_bounds__(WM* WN * 64, (NS == 3 ? 2 : 1) * WM * WN / 4) gemm_ring_kernel(const FluxmiGemmParams P) {
   constexpr int NT = WM * WN * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int NS = 4;                                   // ring depth
+  constexpr int D = NS - 1;                               // prefetch distance (K-steps in flight)
   constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
   constexpr int IA = (BM * 4) / NT, IW = (BN * 4) / NT;   // 16-B slots per thread per K-step
   constexpr int LPT = IA + IW;                            // LDS-DMA loads per thread per K-step
@@ -151,15 +151,19 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const FluxmiGemm
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
     srcW[i] = (const unsigned char*)G.W + ((long long)(n0 + row) * P.K) * EB + slot * 16;
   }
-  auto stage = [&](int kt) {
-    unsigned char* dA = smem + (kt & (NS - 1)) * STAGE + wave * 1024;
+  // LDS-DMA loads [from, to) of the LPT loads that bring K-step kt into ring slot kt % NS
+  auto stage_part = [&](int kt, int slot, int from, int to) {
+    unsigned char* dA = smem + slot * STAGE + wave * 1024;
     unsigned char* dW = dA + A_BYTES;
     const long long koff = (long long)kt * 64;
 #pragma unroll
-    for (int i = 0; i < IA; ++i) glds16(srcA[i] + koff, dA + NT * 16 * i);
+    for (int i = 0; i < IA; ++i)
+      if (i >= from && i < to) glds16(srcA[i] + koff, dA + NT * 16 * i);
 #pragma unroll
-    for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, dW + NT * 16 * i);
+    for (int i = 0; i < IW; ++i)
+      if (IA + i >= from && IA + i < to) glds16(srcW[i] + koff, dW + NT * 16 * i);
   };
+  auto stage = [&](int kt) { stage_part(kt, kt % NS, 0, LPT); };
 
   v16f acc[TM][TN];
 #pragma unroll
@@ -181,13 +185,13 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const FluxmiGemm
     w_lo = A_BYTES + rw * 64 + (((hi * 2) ^ kw) << 4);
     w_hi = A_BYTES + rw * 64 + (((hi * 2 + 1) ^ kw) << 4);
   }
-  auto read_a = [&](int kt, int i) -> v8i {
-    const unsigned char* sb = smem + (kt & (NS - 1)) * STAGE + i * 2048;
+  auto read_a = [&](int slot, int i) -> v8i {
+    const unsigned char* sb = smem + slot * STAGE + i * 2048;
     const v4i lo = *(const v4i*)(sb + a_lo), h4 = *(const v4i*)(sb + a_hi);
     return (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
   };
-  auto read_w = [&](int kt, int j) -> v8i {
-    const unsigned char* sb = smem + (kt & (NS - 1)) * STAGE + j * 2048;
+  auto read_w = [&](int slot, int j) -> v8i {
+    const unsigned char* sb = smem + slot * STAGE + j * 2048;
     const v4i lo = *(const v4i*)(sb + w_lo), h4 = *(const v4i*)(sb + w_hi);
     return (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
   };
@@ -211,8 +215,8 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const FluxmiGemm
   // ---- prologue: three K-steps in flight; W fragments + first A fragment of step 0 in registers ------------------------
   stage(0);
   if (nk > 1) stage(1);
-  if (nk > 2) stage(2);
-  if (nk > 2) wait_vmcnt<2 * LPT>(); else if (nk > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+  if (D > 2 && nk > 2) stage(2);
+  if (D > 2 && nk > 2) wait_vmcnt<2 * LPT>(); else if (nk > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   struct Head { v8i fw[TN]; v8i fa0; };
   Head h0, h1;
@@ -223,24 +227,31 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const FluxmiGemm
   // One K-step.  Entry: `cur` = W fragments + A fragment 0 of step kt (LDS reads possibly still in flight); LDS-DMA of
   // steps kt+1, kt+2 in flight.  Wait ONLY for step kt+1, barrier, refill the slot step kt-1 vacated with step kt+3.
   // A fragments stream one MFMA row ahead; the head of step kt+1 is fetched under the last row.
-  auto kstep = [&](Head& cur, Head& nxt, int kt) {
-    if (kt + 2 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (kt + 3 < nk) stage(kt + 3);
+  // `slot` = kt % NS is carried incrementally (no integer division in the loop).
+  auto kstep = [&](Head& cur, Head& nxt, int kt, int slot) {
+    if (!(ABL & 8)) { if (D > 2 && kt + 2 < nk) wait_vmcnt<(D - 2) * LPT>(); else wait_vmcnt<0>(); }
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+    const bool refill = (kt + D < nk) && !(ABL & 1);  // wave-uniform
+    const int rslot = slot == 0 ? NS - 1 : slot - 1;  // the slot K-step kt-1 vacated == (kt + D) % NS
+    if (!SPREAD && refill) stage_part(kt + D, rslot, 0, LPT);
     // branch-free from here on (a conditional around the head reads makes LLVM sink every MFMA below it): on the last
     // step the "next head" is simply re-read from the last tile and never used
-    const int ktn = min(kt + 1, nk - 1);
+    const int nslot = kt + 1 < nk ? (slot + 1 == NS ? 0 : slot + 1) : slot;
     v8i fa = cur.fa0;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       v8i fn = fa;
-      if (i + 1 < TM) {
-        fn = read_a(kt, i + 1);
+      if constexpr (ABL & 2) {
+        // ablation: no LDS reads in the main loop (fragments are recycled; results are garbage, timing only)
+        if (i + 1 == TM) { nxt = cur; }
+        asm volatile("" : "+v"(fn));
+      } else if (i + 1 < TM) {
+        fn = read_a(slot, i + 1);
       } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) nxt.fw[j] = read_w(ktn, j);
-        nxt.fa0 = read_a(ktn, 0);
+        for (int j = 0; j < TN; ++j) nxt.fw[j] = read_w(nslot, j);
+        nxt.fa0 = read_a(nslot, 0);
       }
       // pin the software pipeline: [LDS reads for the next row] | [this row's MFMAs]; without the fences hipcc hoists every
       // read of the K-step above one lgkmcnt(0) and the MFMAs start only after the slowest of them
@@ -249,13 +260,21 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const FluxmiGemm
       mma_row(i, fa, cur.fw);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
+      // SPREAD: the refill of the vacated slot is issued in TM pieces, one behind each MFMA row, so that the two waves of a
+      // SIMD never sit in a burst of LDS-DMA issue (~60 cycles each) at the same time with the matrix pipe idle
+      if (SPREAD && refill) stage_part(kt + D, rslot, (i * LPT) / TM, ((i + 1) * LPT) / TM);
+      if (SPREAD) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
       fa = fn;
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  for (int kt = 0; kt < nk; ++kt) {
-    kstep(h0, h1, kt);
-    h0 = h1;  // 24 register moves per K-step: cheaper than the address/unroll state a 2x-unrolled ping-pong keeps live
+  {
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      kstep(h0, h1, kt, slot);
+      h0 = h1;  // 24 register moves per K-step: cheaper than the address/unroll state a 2x-unrolled ping-pong keeps live
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    }
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
@@ -275,8 +294,194 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_ring_kernel(const FluxmiGemm
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool FP8, int ACT>
-int launch_ring(FluxmiGemmParams& p, hipStream_t s) {
+// -------------------------------------------------------------------------------------------------------------------
+// "ping-pong" kernel: 256x256 tile, 8 waves (2 x 4), 4-slot ring, ONE barrier per 64-byte K-step -- and the two waves
+// that share a SIMD (wave w and w+4 = the two M-halves) run the K-step in OPPOSITE order:
+//     group 0:  barrier | 8 MFMA (fragments already in registers) | LDS-DMA refill | read fragments of step k+1
+//     group 1:  barrier | LDS-DMA refill | read fragments of step k | 8 MFMA
+// so that on every SIMD one wave feeds the matrix pipe while the other sits in VMEM/LDS issue (an LDS-DMA instruction
+// costs 60-180 cycles of issue, a K-step carries 4 per wave): measured on the lock-step ring the DMA issue alone was 19 %
+// of the kernel and the LDS reads 8 % (profiles/r01_gemm_ablation.txt).  No double-buffered fragments, no register moves.
+// LDS hazards with a single barrier: before barrier k every wave has waited for its own DMA of step k+1, so group 1 may
+// read step k and group 0 step k+1 after it; the slot refilled after barrier k held step k-1, last read (by group 1)
+// before that barrier.
+// -------------------------------------------------------------------------------------------------------------------
+template <bool FP8, int ACT_FMT, int VAR>
+__global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams P) {
+  constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NT = 512, TM = 4, TN = 2, NS = 4, D = 3;
+  constexpr int WTM = 128, WTN = 64;
+  constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
+  constexpr int IA = 2, IW = 2, LPT = 4;
+  constexpr int EB = FP8 ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int tiles_n = P.N / BN;
+  const int nblk = P.tiles_m_total * tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nblk);
+  const int width = P.group_m * tiles_n;
+  const int first_m = (lid / width) * P.group_m;
+  const int gsz = min(P.tiles_m_total - first_m, P.group_m);
+  const int tm = first_m + (lid % width) % gsz;
+  const int tn = (lid % width) / gsz;
+  int gi = 0;
+  for (int i = 1; i < P.n_groups; ++i) gi = (tm >= P.g[i].m_tile_start) ? i : gi;
+  const FluxmiGemmGroup& G = P.g[gi];
+  const int M = G.M;
+  const int m0 = (tm - G.m_tile_start) * BM;
+  const int n0 = tn * BN;
+  const int nk = (P.K * EB) / 64;
+
+  const unsigned char* srcA[IA];
+  const unsigned char* srcW[IW];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
+    const int gr = min(m0 + row, M - 1);
+    srcA[i] = (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < IW; ++i) {
+    const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
+    srcW[i] = (const unsigned char*)G.W + ((long long)(n0 + row) * P.K) * EB + slot * 16;
+  }
+  auto stage = [&](int kt, int slot) {
+    unsigned char* dA = smem + slot * STAGE + wave * 1024;
+    unsigned char* dW = dA + A_BYTES;
+    const long long koff = (long long)kt * 64;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) glds16(srcA[i] + koff, dA + NT * 16 * i);
+#pragma unroll
+    for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, dW + NT * 16 * i);
+  };
+
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int a_lo, a_hi, w_lo, w_hi;
+  {
+    const int ra = wm * WTM + l31, ka = (ra >> 2) & 3;
+    a_lo = ra * 64 + (((hi * 2) ^ ka) << 4);
+    a_hi = ra * 64 + (((hi * 2 + 1) ^ ka) << 4);
+    const int rw = wn * WTN + l31, kw = (rw >> 2) & 3;
+    w_lo = A_BYTES + rw * 64 + (((hi * 2) ^ kw) << 4);
+    w_hi = A_BYTES + rw * 64 + (((hi * 2 + 1) ^ kw) << 4);
+  }
+  v8i fa[TM], fw[TN];
+  auto read_frags = [&](int slot) {
+    const unsigned char* sb = smem + slot * STAGE;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const v4i lo = *(const v4i*)(sb + j * 2048 + w_lo), h4 = *(const v4i*)(sb + j * 2048 + w_hi);
+      fw[j] = (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const v4i lo = *(const v4i*)(sb + i * 2048 + a_lo), h4 = *(const v4i*)(sb + i * 2048 + a_hi);
+      fa[i] = (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
+    }
+  };
+  auto mma_all = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (FP8) {
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[j], fa[i], acc[i][j], FLUXMI_FMT_E4M3, ACT_FMT, 0, 0x7f7f7f7f, 0,
+                                                                    0x7f7f7f7f);
+        } else {
+          const v4i alo = (v4i){fa[i][0], fa[i][1], fa[i][2], fa[i][3]}, ahi = (v4i){fa[i][4], fa[i][5], fa[i][6], fa[i][7]};
+          const v4i wlo = (v4i){fw[j][0], fw[j][1], fw[j][2], fw[j][3]}, whi = (v4i){fw[j][4], fw[j][5], fw[j][6], fw[j][7]};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, wlo), __builtin_bit_cast(v8bf, alo), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, whi), __builtin_bit_cast(v8bf, ahi), acc[i][j], 0, 0, 0);
+        }
+      }
+  };
+  auto fence = []() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: three K-steps in flight ---------------------------------------------------------------------------
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  if (nk > 2) stage(2, 2);
+  if (nk > 2) wait_vmcnt<2 * LPT>(); else if (nk > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  if (wm == 0) {
+    read_frags(0);
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      fence();
+      if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+      mma_all();
+      if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+      fence();
+      const int rslot = slot == 0 ? NS - 1 : slot - 1;
+      if (kt + D < nk) stage(kt + D, rslot);
+      fence();
+      slot = slot + 1 == NS ? 0 : slot + 1;
+      read_frags(kt + 1 < nk ? slot : (slot == 0 ? NS - 1 : slot - 1));  // last step: harmless re-read of the same slot
+      fence();
+    }
+  } else {
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      fence();
+      const int rslot = slot == 0 ? NS - 1 : slot - 1;
+      if (VAR & 2) {
+        read_frags(slot);
+        fence();
+        if (kt + D < nk) stage(kt + D, rslot);
+      } else {
+        if (kt + D < nk) stage(kt + D, rslot);
+        fence();
+        read_frags(slot);
+      }
+      fence();
+      if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+      mma_all();
+      if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+      fence();
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------------
+  const float s = load_scale(G.sa_recip) * load_scale(G.sb_recip);
+  const float qs = G.q_scale ? *G.q_scale : 1.0f;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the ring before it is reused as epilogue scratch
+  unsigned char* wbuf = smem + wave * (WTM * WTN * 2);
+  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+  switch (P.epi) {
+    case FLUXMI_EPI_BF16: lds_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_GELU_QUANT: lds_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_GATE_RESID: lds_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_SPLIT: lds_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_QUANT: lds_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_SILU_QUANT: lds_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    default: break;
+  }
+}
+
+template <bool FP8, int ACT, int VAR>
+int launch_pp(FluxmiGemmParams& p, hipStream_t s) {
+  constexpr int BM = 256, BN = 256;
   int t = 0;
   for (int i = 0; i < p.n_groups; ++i) {
     p.g[i].m_tile_start = t;
@@ -285,7 +490,30 @@ int launch_ring(FluxmiGemmParams& p, hipStream_t s) {
   p.tiles_m_total = t;
   p.group_m = 8;
   constexpr int SMEM = 4 * (BM + BN) * 64;
-  auto kern = gemm_ring_kernel<BM, BN, WM, WN, FP8, ACT>;
+  auto kern = gemm_pp_kernel<FP8, ACT, VAR>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  const int nblk = t * (p.N / BN);
+  if (nblk == 0) return 0;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), SMEM, s, p);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool SPREAD, bool FP8, int ACT, int ABL = 0>
+int launch_ring(FluxmiGemmParams& p, hipStream_t s) {
+  int t = 0;
+  for (int i = 0; i < p.n_groups; ++i) {
+    p.g[i].m_tile_start = t;
+    t += (p.g[i].M + BM - 1) / BM;
+  }
+  p.tiles_m_total = t;
+  p.group_m = 8;
+  constexpr int SMEM = NS * (BM + BN) * 64;
+  auto kern = gemm_ring_kernel<BM, BN, WM, WN, NS, SPREAD, FP8, ACT, ABL>;
   static bool attr_set = false;
   if (!attr_set) {
     FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -301,9 +529,30 @@ int launch_ring(FluxmiGemmParams& p, hipStream_t s) {
 template <bool FP8, int ACT>
 int launch_ring_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
   switch (cfg) {
-    case 4: return launch_ring<256, 256, 2, 4, FP8, ACT>(p, s);
-    case 5: return launch_ring<256, 128, 4, 2, FP8, ACT>(p, s);
-    case 6: return launch_ring<128, 128, 2, 2, FP8, ACT>(p, s);
+    case 4: return launch_ring<256, 256, 2, 4, 4, false, FP8, ACT>(p, s);
+    case 5: return launch_ring<256, 128, 4, 2, 4, false, FP8, ACT>(p, s);
+    case 6: return launch_ring<128, 128, 2, 2, 4, false, FP8, ACT>(p, s);
+    case 7: return launch_ring<256, 256, 2, 4, 4, true, FP8, ACT>(p, s);
+    case 8: return launch_ring<256, 128, 2, 2, 3, true, FP8, ACT>(p, s);   // 72 KiB LDS, 4 waves: 2 blocks per CU
+    case 9: return launch_ring<128, 256, 2, 2, 3, true, FP8, ACT>(p, s);
+    case 10: return launch_ring<256, 128, 2, 2, 3, false, FP8, ACT>(p, s);
+    case 11: return launch_pp<FP8, ACT, 0>(p, s);
+    case 12: return launch_pp<FP8, ACT, 1>(p, s);
+    case 13: return launch_pp<FP8, ACT, 2>(p, s);
+    case 14: return launch_pp<FP8, ACT, 3>(p, s);
+    default: break;
+  }
+  // timing-only ablations of the 256x256 ring (tools/gemm_probe.py): cfg = 20 + mask, 1 = no LDS-DMA refill, 2 = no LDS reads,
+  // 4 = no barrier, 8 = no vmcnt wait.  Results are wrong by construction.
+  if constexpr (FP8 && ACT == FLUXMI_FMT_E5M2) {
+    switch (cfg) {
+#define ABL_CASE(m) case 20 + m: return launch_ring<256, 256, 2, 4, 4, false, FP8, ACT, m>(p, s);
+      ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(7) ABL_CASE(9) ABL_CASE(13) ABL_CASE(15)
+#undef ABL_CASE
+      default: break;
+    }
+  }
+  switch (cfg) {
     default: fluxmi_set_error("gemm_ring: unknown tile config %d", cfg); return 1;
   }
 }

@@ -110,13 +110,13 @@ def make_f8_problem(M, N, K, fmt, seed):
     return a8, w8, sa.reciprocal(), sbr, bias
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 100])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 100])
 @pytest.mark.parametrize("shape", [(256, 256, 64), (256, 256, 128), (512, 768, 256), (300, 512, 384), (37, 256, 3072), (1024, 1024, 1024)])
 @pytest.mark.parametrize("fmt", [E5M2, E4M3])
 def test_f8_gemm(ops, dev, cfg, shape, fmt):
     """K1: fp8 GEMM on identical quantised operands vs fp64 (float8_quantize.py:284-292): <= 1 bf16 ulp."""
     M, N, K = shape
-    if fmt == E4M3 and (cfg not in (0, 4, 100) or shape != (512, 768, 256)):
+    if fmt == E4M3 and (cfg not in (0, 4, 8, 11, 100) or shape != (512, 768, 256)):
         pytest.skip("e4m3 activations: one representative case per kernel")
     if K % 128 and cfg in (0, 1, 2, 3):
         pytest.skip("double-buffered kernels step K by 128 bytes")
@@ -137,10 +137,12 @@ def accum_noise(a, w, s):
     a common exponent before adding).  Passed as `mag` so that assert_close_mag allows 1 bf16 ulp OR this noise;
     the bit-exact-fraction requirement is what keeps the test sharp."""
     S = (a.double().abs() @ w.double().abs().T) * float(s)
-    return 16.0 * math.sqrt(a.shape[1]) * 2.0 ** -24 * S * 2.0 ** 7
+    # floor at K = 256: a single 32x32x64 MX MFMA aligns its 64 products to the block's largest exponent before adding, so
+    # even one K-step carries that much truncation (measured on gfx950: K = 64 reaches 1.85x the sqrt(K) model)
+    return 16.0 * math.sqrt(max(a.shape[1], 256)) * 2.0 ** -24 * S * 2.0 ** 7
 
 
-@pytest.mark.parametrize("cfg", [0, 2, 4, 6, 100])
+@pytest.mark.parametrize("cfg", [0, 2, 4, 6, 7, 8, 9, 11, 100])
 def test_bf16_gemm(ops, dev, cfg):
     torch.manual_seed(5)
     M, N, K = 320, 512, 192
@@ -153,7 +155,7 @@ def test_bf16_gemm(ops, dev, cfg):
     assert_close_mag(out, ref, mag=accum_noise(a, w, 1.0), ulps=1, min_exact=0.99, what=f"bf16 gemm cfg={cfg}")
 
 
-@pytest.mark.parametrize("cfg", [0, 2, 4, 5, 6, 100])
+@pytest.mark.parametrize("cfg", [0, 2, 4, 5, 6, 7, 8, 9, 11, 100])
 def test_gemm_epilogues(ops, dev, cfg):
     """K8/K9/K2 fused epilogues == the reference's eager chain applied to the GEMM's own bf16 output."""
     from fluxmi import _lib
