@@ -30,34 +30,57 @@ FP8_PEAK_TFLOPS = 5000.0  # MI355X dense fp8 MFMA (MX-scaled K=128/64 opcodes), 
 
 
 def flux_dev_gemm_shapes(Li=4096, Lt=512, H=3072):
-    """(name, M, N, K, launches/step, fused epilogue) for the tiled-GEMM launches of one step."""
+    """(name, Ms, N, K, launches/step, fused epilogue) of the six grouped F8Linear GEMM launches of one step:
+    exactly what engine.hip issues in fused mode -- txt+img streams of a double block share one grouped launch."""
     L, Hm = Li + Lt, 4 * H
     return [
-        ("double.qkv(img+txt)", (Li, Lt), 3 * H, H, 19), ("double.proj(img+txt)", (Li, Lt), H, H, 19),
-        ("double.mlp0(img+txt)", (Li, Lt), Hm, H, 19), ("double.mlp2(img+txt)", (Li, Lt), H, Hm, 19),
-        ("single.linear1", (L,), 3 * H + Hm, H, 38), ("single.linear2", (L,), H, H + Hm, 38),
+        ("double.qkv(txt+img)", (Lt, Li), 3 * H, H, 19, "bf16"), ("double.proj(txt+img)", (Lt, Li), H, H, 19, "gate_resid"),
+        ("double.mlp0(txt+img)", (Lt, Li), Hm, H, 19, "gelu_quant"), ("double.mlp2(txt+img)", (Lt, Li), H, Hm, 19, "gate_resid"),
+        ("single.linear1", (L,), 3 * H + Hm, H, 38, "split"), ("single.linear2", (L,), H, H + Hm, 38, "gate_resid"),
     ]
 
 
 def linear_flops_per_step(Li=4096, Lt=512, H=3072):
-    return sum(2.0 * sum(Ms) * N * K * cnt for _, Ms, N, K, cnt in flux_dev_gemm_shapes(Li, Lt, H))
+    return sum(2.0 * sum(Ms) * N * K * cnt for _, Ms, N, K, cnt, _e in flux_dev_gemm_shapes(Li, Lt, H))
 
 
 def measure_gemm_roofline(torch, ops, dev, iters=10):
-    """Average duration of one fp8 GEMM launch of the step, HIP events on the launch stream, random operands."""
+    """Average duration of one F8Linear GEMM launch of the step: the six launch shapes WITH their fused epilogues (GELU+quantise,
+    gate*y+x in place, qkv|mlp split), weighted by their count per step; HIP events on the launch stream, random operands.
+    Returns (flops per launch, seconds per launch, per-shape table)."""
     from fluxmi import _lib
 
     one = torch.tensor(1.0, device=dev)
-    tot_t, tot_f, n_launch = 0.0, 0.0, 0
-    for name, Ms, N, K, cnt in flux_dev_gemm_shapes():
+    H = 3072
+    tot_t, tot_f, n_launch, table = 0.0, 0.0, 0, []
+    for name, Ms, N, K, cnt, epi in flux_dev_gemm_shapes():
         groups, keep = [], []
         for M in Ms:
             a = (torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2)
             w = (torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn)
-            o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-            keep += [a, w, o]
-            groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), None, one.data_ptr(), one.data_ptr(), o.data_ptr(), M, K, N))
-        fn = lambda: ops.gemm_grouped(groups, N, K, True, _lib.E5M2, _lib.EPI_BF16, -1)
+            bias = torch.randn(N, device=dev).bfloat16()
+            keep += [a, w, bias]
+            kw = {}
+            if epi == "bf16":
+                o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+                code = _lib.EPI_BF16
+            elif epi == "gelu_quant":
+                o = torch.empty(M, N, dtype=torch.float8_e5m2, device=dev)
+                code, kw = _lib.EPI_GELU_QUANT, dict(q_scale=one.data_ptr())
+            elif epi == "gate_resid":
+                o = torch.randn(M, N, device=dev).bfloat16()  # residual stream, updated in place
+                gate = torch.randn(N, device=dev).bfloat16()
+                keep.append(gate)
+                code, kw = _lib.EPI_GATE_RESID, dict(gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N)
+            else:  # split: q|k|v bf16 to C, gelu(mlp) fp8 into the [attn | mlp] buffer at column H
+                o = torch.empty(M, 3 * H, dtype=torch.bfloat16, device=dev)
+                o2 = torch.empty(M, 5 * H, dtype=torch.float8_e5m2, device=dev)
+                keep.append(o2)
+                code, kw = _lib.EPI_SPLIT, dict(C2=o2.data_ptr(), ldc2=5 * H, split_n=3 * H, c2_col0=H, q_scale=one.data_ptr())
+            keep.append(o)
+            groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr(), one.data_ptr(), o.data_ptr(), M, K,
+                                         o.stride(0), **kw))
+        fn = lambda: ops.gemm_grouped(groups, N, K, True, _lib.E5M2, code, -1)
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -67,10 +90,23 @@ def measure_gemm_roofline(torch, ops, dev, iters=10):
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / iters
+        f = 2.0 * sum(Ms) * N * K
+        table.append({"launch": name, "epilogue": epi, "per_step": cnt, "us": round(t * 1e6, 1), "tflops": round(f / t / 1e12, 1)})
         tot_t += t * cnt
-        tot_f += 2.0 * sum(Ms) * N * K * cnt
+        tot_f += f * cnt
         n_launch += cnt
-    return tot_f / n_launch, tot_t / n_launch  # flops per launch, seconds per launch
+        del groups, keep
+    return tot_f / n_launch, tot_t / n_launch, table
+
+
+def gemm_traffic_bytes():
+    """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    MI355X_MICROARCH.md "HBM"); collected offline by tools/traffic.sh and committed as profiles/r01_gemm_traffic.json."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as f:
+            return json.load(f)["bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(torch, budget_s=25.0):
@@ -207,7 +243,8 @@ def main():
             ms_per_step = elapsed / args.steps * 1e3
             its = world * args.steps / elapsed
             lin_flops = linear_flops_per_step(Li)
-            flops_per_launch, sec_per_launch = measure_gemm_roofline(torch, ops, dev) if (args.height, args.width) == (1024, 1024) else (0.0, 1.0)
+            flops_per_launch, sec_per_launch, gemm_table = (measure_gemm_roofline(torch, ops, dev) if (args.height, args.width) == (1024, 1024)
+                                                            else (0.0, 1.0, []))
             achieved = flops_per_launch / sec_per_launch / 1e12
             result = {
                 "metric": "denoise it/s at 1024x1024, Flux-dev, fp8 F8Linear + bf16 flow",
@@ -223,10 +260,12 @@ def main():
                 "vs_h100_compiled": round(its / world / H100_COMPILED_ITS, 3),
                 "fp8_mfma_fraction_whole_step": round(lin_flops / (ms_per_step * 1e-3) / (FP8_PEAK_TFLOPS * 1e12), 4),
                 "setup_s": round(setup_s, 1),
-                "roofline": {"bound": "mfma", "kernel": "gemm_tile_kernel<fp8 MX-MFMA 32x32x64> (all F8Linear GEMMs of the step)",
+                "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<fp8 MX-MFMA 32x32x64, 256x256 ping-pong ring> (the 152 grouped "
+                                                            "F8Linear GEMM launches of a step, fused epilogues included)",
                              "achieved": round(achieved, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(achieved / FP8_PEAK_TFLOPS, 4), "traffic": None,
-                             "flops_per_launch": flops_per_launch, "avg_launch_us": round(sec_per_launch * 1e6, 2)},
+                             "frac": round(achieved / FP8_PEAK_TFLOPS, 4), "traffic": gemm_traffic_bytes(),
+                             "flops_per_launch": flops_per_launch, "avg_launch_us": round(sec_per_launch * 1e6, 2),
+                             "launches": gemm_table},
             }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

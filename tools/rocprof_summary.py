@@ -22,19 +22,47 @@ def main():
     ap.add_argument("path")
     ap.add_argument("-o", "--out", default=None)
     ap.add_argument("--header", default="")
+    ap.add_argument("--steady", action="store_true",
+                    help="only the fused (frozen-scale) denoise steps: dispatches after the last calibration kernel up to the last "
+                         "euler_kernel; prints per-step time and launch count per kernel")
     args = ap.parse_args()
     dbs = glob.glob(os.path.join(args.path, "**", "*.db"), recursive=True) if os.path.isdir(args.path) else [args.path]
     if not dbs:
         sys.exit("no .db found under " + args.path)
     rows = {}
+    steps = 0
+    span_ns = 0
     for db in dbs:
         cur = sqlite3.connect(db).cursor()
+        if args.steady:
+            ks = list(cur.execute("select name, start, end from kernels order by start"))
+            calib_end = max([e for n, s_, e in ks if "amax_kernel" in n or "calib_update" in n] or [0])
+            eul = [e for n, s_, e in ks if "euler_kernel" in n and s_ > calib_end]
+            if not eul:
+                continue
+            # drop the first fused step (runs eagerly before the graph capture)
+            t0 = eul[0] if len(eul) > 1 else calib_end
+            t1 = eul[-1]
+            steps += len(eul) - 1 if len(eul) > 1 else 1
+            span_ns += t1 - t0
+            for n, s_, e in ks:
+                if s_ >= t0 and e <= t1:
+                    k = short(n)
+                    c, t = rows.get(k, (0, 0.0))
+                    rows[k] = (c + 1, t + (e - s_))
+            continue
         for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
             k = short(name)
             c, t = rows.get(k, (0, 0.0))
             rows[k] = (c + calls, t + total)
     tot = sum(t for _, t in rows.values())
     lines = [args.header] if args.header else []
+    if args.steady and steps:
+        lines.append(f"# steady state: {steps} fused graph-replayed denoise steps, wall {span_ns / steps / 1e6:.3f} ms/step, "
+                     f"kernel time {tot / steps / 1e6:.3f} ms/step, {sum(c for c, _ in rows.values()) / steps:.0f} launches/step; "
+                     "columns are totals over those steps (ns resolution -> us)")
+        rows = {k: (c, t / 1e3) for k, (c, t) in rows.items()}
+        tot /= 1e3
     lines.append(f"{'kernel':112s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'%':>6s}")
     for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
         lines.append(f"{k:112s} {c:7d} {t:12.1f} {t / c:10.2f} {100 * t / tot:6.2f}")
