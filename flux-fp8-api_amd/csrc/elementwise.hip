@@ -262,6 +262,29 @@ __global__ void __launch_bounds__(256) add_kernel(const u16* __restrict__ a, con
   }
 }
 
+// z[r, :] = a[r, :] + b[r % nb, :]  (rows of n8*8 bf16): the step-invariant parts of `vec` added to every step's time embedding
+__global__ void __launch_bounds__(256) add_bcast_kernel(const u16* __restrict__ a, const u16* __restrict__ b, u16* __restrict__ z,
+                                                        long long rows, int nb, int cols) {
+  const int cpr = cols >> 3;
+  const long long total = rows * cpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpr;
+    const int c = (int)(i % cpr) * 8;
+    float fa[8], fb[8];
+    unpack8(*(const uint4*)(a + r * cols + c), fa);
+    unpack8(*(const uint4*)(b + (r % nb) * cols + c), fb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] += fb[j];
+    *(uint4*)(z + r * cols + c) = pack8(fa);
+  }
+}
+// dst[0..n) = table[(*step - step0) * n ..]: the modulation vectors of the current denoise step out of the per-request table
+__global__ void __launch_bounds__(256) select_step_kernel(const uint4* __restrict__ table, const int* __restrict__ step, int step0,
+                                                          uint4* __restrict__ dst, long long n16) {
+  const uint4* src = table + (long long)(*step - step0) * n16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // sinusoidal timestep embedding                                           flux_model.py:95-116
 //   t' = bf16(1000 * t);  out[b, i] = bf16(cos(t' * f_i)),  out[b, half+i] = bf16(sin(t' * f_i))
@@ -479,6 +502,21 @@ int fluxmi_k_add(const void* a, const void* b, void* z, long long n, hipStream_t
   FLUXMI_REQUIRE(n % 8 == 0, "add: n must be a multiple of 8");
   if (n == 0) return 0;
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const u16*)a, (const u16*)b, (u16*)z, n);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+int fluxmi_k_add_bcast(const void* a, const void* b, void* z, long long rows, int nb, int cols, hipStream_t s) {
+  FLUXMI_REQUIRE(cols % 8 == 0 && nb >= 1, "add_bcast: cols must be a multiple of 8");
+  if (rows * cols == 0) return 0;
+  hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, s, (const u16*)a, (const u16*)b, (u16*)z, rows, nb, cols);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+int fluxmi_k_select_step(const void* table, const int* step, int step0, void* dst, long long bytes, hipStream_t s) {
+  FLUXMI_REQUIRE(bytes % 16 == 0, "select_step: size must be a multiple of 16 bytes");
+  if (bytes == 0) return 0;
+  hipLaunchKernelGGL(select_step_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, s, (const uint4*)table, step, step0, (uint4*)dst, bytes / 16);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }

@@ -51,6 +51,12 @@ struct fluxmi_engine {
   std::vector<FluxmiCalibLayer> h_calib_mod;  // modulation layers that share silu(vec)
   FluxmiCalibLayer* d_calib_mod = nullptr;
   int gemv_blocks = 0, gemv_maxK = 0;
+  // step-ahead modulation table (frozen scales): every modulation vector of every remaining step of a request, computed
+  // before the loop in batches of 8 steps so that the 3.2 GB of modulation weights are streamed once per 8 steps, not per step
+  char* mods_all = nullptr;
+  size_t mods_all_bytes = 0;
+  int mods_step0 = 0;
+  bool mods_table = false;  // the step being sequenced takes its modulations from the table
   hipGraphExec_t exec = nullptr;
   bool graph_ok = false;
   bool txt_emb_valid = false;
@@ -63,6 +69,14 @@ typedef fluxmi_engine E;
 template <class T> T* buf(E* e, const char* name) {
   auto it = e->bufs.find(name);
   return it == e->bufs.end() ? nullptr : (T*)it->second.p;
+}
+
+static u16 host_f2bf(double v) {
+  float f = (float)v;
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
 }
 
 int lin_count(const fluxmi_model_desc_t& d) { return 6 + (d.guidance_embed ? 2 : 0) + d.depth * 10 + d.depth_single * 3 + 2; }
@@ -186,6 +200,45 @@ int build_gemv_table(E* e, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Every Modulation.lin + LastLayer.adaLN_modulation of the model applied to R rows of silu(vec) (row stride H) -> out (row stride
+// mod_cols): grouped MFMA GEMMs, up to 16 layers per launch, M = R padded to one tile.  Weight-stream bound (3.2 GB fp8 at
+// Flux-dev).  Used both per step (R = B) and for the step-ahead table (R = steps x B): an output element's K-order of
+// accumulation does not depend on M or on the tile shape, so the two are bit-identical.        flux_model.py:251-257,499-500
+// a8: scratch for the per-layer quantised activations, FLUXMI_MAX_GROUPS slices of a8_stride bytes.
+// ---------------------------------------------------------------------------------------------------------
+int mods_gemm(E* e, const u16* sv, int R, u16* out, uint8_t* a8, size_t a8_stride, hipStream_t s) {
+  const int H = e->d.hidden;
+  const long long MC = e->mod_cols;
+  u16* mod0 = buf<u16>(e, "mod");
+  const size_t n = e->h_gemv.size();
+  size_t i = 0;
+  while (i < n) {
+    const FluxmiGemvLayer& g0 = e->h_gemv[i];
+    std::vector<FluxmiGemmGroup> gs;
+    size_t j = i;
+    for (; j < n && gs.size() < FLUXMI_MAX_GROUPS; ++j) {
+      const FluxmiGemvLayer& g = e->h_gemv[j];
+      if (g.N != g0.N || g.K != g0.K || g.w_fp8 != g0.w_fp8 || g.act_fmt != g0.act_fmt) break;
+      FluxmiGemmGroup gg;
+      memset(&gg, 0, sizeof(gg));
+      if (g.w_fp8) {
+        uint8_t* aq = a8 + gs.size() * a8_stride;
+        FLUXMI_TRY(fluxmi_k_quantize_act(sv, aq, g.in_scale, R, g.K, H, g.K, g.act_fmt, s));
+        gg.A = aq; gg.sa_recip = g.sa_recip; gg.sb_recip = g.sb_recip;
+      } else {
+        gg.A = sv;
+      }
+      gg.W = g.W; gg.bias = g.bias; gg.lda = g.K;
+      gg.C = out + ((u16*)g.out - mod0); gg.ldc = MC; gg.M = R;
+      gs.push_back(gg);
+    }
+    FLUXMI_TRY(run_gemm(gs, g0.N, g0.K, g0.w_fp8, g0.act_fmt, FLUXMI_EPI_BF16, s));
+    i = j;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // vec = time_in(temb(t)) + guidance_in(temb(g)) + vector_in(y)  and all modulations      flux_model.py:687-697, 251-257
 // ---------------------------------------------------------------------------------------------------------
 int compute_vec_and_mods(E* e, const u16* t_vec, const u16* g_vec, const u16* y, bool calib, int trial, hipStream_t s) {
@@ -215,7 +268,8 @@ int compute_vec_and_mods(E* e, const u16* t_vec, const u16* g_vec, const u16* y,
     FLUXMI_TRY(fluxmi_k_amax(svec, e->d_amax, B, H, H, s));
     FLUXMI_TRY(fluxmi_k_calib_update_many(e->d_amax, e->d_calib_mod, (int)e->h_calib_mod.size(), trial, e->d.num_trials, 57344.f, s));
   }
-  return fluxmi_launch_gemv(e->d_gemv, nullptr, (int)e->h_gemv.size(), B, e->gemv_blocks, e->gemv_maxK, s);
+  const size_t a8_stride = ((size_t)B * e->gemv_maxK + 255) & ~(size_t)255;
+  return mods_gemm(e, svec, B, buf<u16>(e, "mod"), buf<uint8_t>(e, "mods_a8"), a8_stride, s);
 }
 
 int embed_txt(E* e, const u16* txt, bool calib, int trial, u16* dst, long long dst_bstride, hipStream_t s) {
@@ -228,6 +282,82 @@ int embed_txt(E* e, const u16* txt, bool calib, int trial, u16* dst, long long d
     gs.push_back(mk_group(l, l.kind ? (const void*)(in8 + (long long)b * Lt * C) : (const void*)(txt + (long long)b * Lt * C), C,
                           dst + b * dst_bstride, H, Lt));
   return run_gemm(gs, H, C, l.kind, l.in_fmt, FLUXMI_EPI_BF16, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Step-ahead modulations (frozen scales only).  `vec` depends on the timestep, the guidance and y -- never on the latents -- so
+// the rows of every remaining step r = (step - step0) * B + b are known before the loop:
+//   vec[r] = (time_in(temb(t_step)) + guidance_in(temb(g))[b]) + vector_in(y)[b]            flux_model.py:687-697
+//   mods[r] = Modulation.lin(silu(vec[r])) for the 76 modulation layers + LastLayer.adaLN    flux_model.py:251-257,499-500
+// computed with the SAME kernels as the per-step path (each row's dot products do not depend on how many rows share a launch,
+// so the table is bit-identical to what compute_vec_and_mods produces step by step), 8 rows per weight pass.
+// ---------------------------------------------------------------------------------------------------------
+int precompute_mods(E* e, const std::vector<float>& ts, int step0, int n_steps, const u16* g_vec, const u16* y, hipStream_t s) {
+  const int H = e->d.hidden, B = e->B;
+  const long long MC = e->mod_cols;
+  const int R = (n_steps - step0) * B;
+  if (R <= 0) return 0;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  // sized for at least 64 steps so that requests of different length reuse the allocation (and the captured graph, which reads
+  // the table through its address).  Layout: [table | t | temb | hidden | vec_t | vec | silu(vec)]
+  const size_t Rc = (size_t)std::max(R, 64 * B);
+  const size_t sz_mod = al(Rc * MC * 2), sz_t = al(Rc * 2), sz_temb = al(Rc * 512), sz_h = al(Rc * H * 2);
+  const size_t total = sz_mod + sz_t + sz_temb + 4 * sz_h + FLUXMI_MAX_GROUPS * al(Rc * (size_t)e->gemv_maxK);
+  if (total > e->mods_all_bytes) {
+    FLUXMI_CHECK_HIP(hipStreamSynchronize(s));
+    if (e->mods_all) hipFree(e->mods_all);
+    e->mods_all = nullptr; e->mods_all_bytes = 0;
+    if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+    e->graph_ok = false;
+    if (hipMalloc((void**)&e->mods_all, total) != hipSuccess) { fluxmi_set_error("precompute_mods: hipMalloc(%zu) failed", total); return 2; }
+    e->mods_all_bytes = total;
+  }
+  char* base = e->mods_all;
+  u16* mod_all = (u16*)base;
+  u16* tv = (u16*)(base + sz_mod);
+  u16* temb = (u16*)(base + sz_mod + sz_t);
+  u16* hbuf = (u16*)(base + sz_mod + sz_t + sz_temb);
+  u16* vt = (u16*)((char*)hbuf + sz_h);
+  u16* vec = (u16*)((char*)vt + sz_h);
+  u16* sv = (u16*)((char*)vec + sz_h);
+  std::vector<u16> htv(R);
+  for (int r = 0; r < R; ++r) htv[r] = host_f2bf((double)ts[step0 + r / B]);
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(tv, htv.data(), (size_t)R * 2, hipMemcpyHostToDevice, s));
+  FLUXMI_CHECK_HIP(hipStreamSynchronize(s));  // htv goes out of scope
+  FLUXMI_TRY(fluxmi_k_timestep_embedding(tv, e->d_freqs, temb, R, 128, 1000.0f, s));
+  auto rows_linear = [&](int li, const u16* x, long long ldx, u16* out, int pre_silu, int r0, int nr) -> int {
+    const fluxmi_linear_t& l = e->lin[li];
+    FluxmiGemvLayer g;
+    memset(&g, 0, sizeof(g));
+    g.W = l.weight; g.bias = l.bias; g.in_scale = l.in_scale; g.sa_recip = l.in_scale_recip; g.sb_recip = l.w_scale_recip;
+    g.out = out; g.x = x; g.ld_out = H; g.ldx = ldx; g.N = l.N; g.K = l.K; g.w_fp8 = l.kind; g.pre_silu = pre_silu;
+    g.act_fmt = l.in_fmt;
+    return fluxmi_launch_gemv(nullptr, &g, 1, nr, 0, 0, s, r0);
+  };
+  for (int r0 = 0; r0 < R; r0 += 8) {
+    const int nr = std::min(8, R - r0);
+    FLUXMI_TRY(rows_linear(e->i_time_in, temb, 256, hbuf, 0, r0, nr));
+    FLUXMI_TRY(rows_linear(e->i_time_in + 1, hbuf, H, vt, 1, r0, nr));
+  }
+  // step-invariant parts, B rows (same launches as compute_vec_and_mods)
+  u16 *temb_b = buf<u16>(e, "temb"), *emb_h = buf<u16>(e, "emb_h"), *emb_s = buf<u16>(e, "emb_s");
+  u16 *vec_g = buf<u16>(e, "vec_g"), *vec_y = buf<u16>(e, "vec_y");
+  const u16* acc = vt;
+  if (e->d.guidance_embed) {
+    FLUXMI_REQUIRE(g_vec, "Didn't get guidance strength for guidance distilled model.");
+    FLUXMI_TRY(fluxmi_k_timestep_embedding(g_vec, e->d_freqs, temb_b, B, 128, 1000.0f, s));
+    FLUXMI_TRY(small_linear(e, e->i_guid_in, temb_b, 256, emb_h, H, 0, false, 0, emb_s, s));
+    FLUXMI_TRY(small_linear(e, e->i_guid_in + 1, emb_h, H, vec_g, H, 1, false, 0, emb_s, s));
+    FLUXMI_TRY(fluxmi_k_add_bcast(vt, vec_g, vec, R, B, H, s));
+    acc = vec;
+  }
+  FLUXMI_TRY(small_linear(e, e->i_vec_in, y, e->d.vec_in, emb_h, H, 0, false, 0, emb_s, s));
+  FLUXMI_TRY(small_linear(e, e->i_vec_in + 1, emb_h, H, vec_y, H, 1, false, 0, emb_s, s));
+  FLUXMI_TRY(fluxmi_k_add_bcast(acc, vec_y, vec, R, B, H, s));
+  FLUXMI_TRY(fluxmi_k_act(vec, sv, R, H, H, H, 1, s));
+  FLUXMI_TRY(mods_gemm(e, sv, R, mod_all, (uint8_t*)((char*)sv + sz_h), al(Rc * (size_t)e->gemv_maxK), s));
+  e->mods_step0 = step0;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -268,7 +398,11 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
   } else {
     FLUXMI_TRY(embed_txt(e, txt, calib, trial, x, XB, s));
   }
-  FLUXMI_TRY(compute_vec_and_mods(e, t_vec, g_vec, y, calib, trial, s));
+  if (e->mods_table) {
+    FLUXMI_TRY(fluxmi_k_select_step(e->mods_all, e->d_step, e->mods_step0, mod, (long long)B * MC * 2, s));
+  } else {
+    FLUXMI_TRY(compute_vec_and_mods(e, t_vec, g_vec, y, calib, trial, s));
+  }
 
   // ---- double blocks                                                              flux_model.py:356-400
   for (int i = 0; i < e->d.depth; ++i) {
@@ -468,6 +602,7 @@ int fluxmi_engine_create(const fluxmi_model_desc_t* desc, const fluxmi_linear_t*
 int fluxmi_engine_destroy(fluxmi_engine_t* e) {
   if (!e) return 0;
   free_ws(e);
+  if (e->mods_all) hipFree(e->mods_all);
   if (e->consts) hipFree(e->consts);
   delete e;
   return 0;
@@ -515,6 +650,7 @@ int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void*
         {"vec", (size_t)B * H * 2}, {"svec", (size_t)B * H * 2}, {"temb", (size_t)B * 256 * 2}, {"emb_h", (size_t)B * H * 2},
         {"emb_s", (size_t)B * std::max(H, 1024) * 2}, {"vec_t", (size_t)B * H * 2}, {"vec_g", (size_t)B * H * 2}, {"vec_y", (size_t)B * H * 2},
         {"tvec", 256}, {"gvec", 256}, {"ids", BL * 3 * 2},
+        {"mods_a8", (size_t)FLUXMI_MAX_GROUPS * (((size_t)B * std::max(H, 4096) + 255) & ~(size_t)255)},
         // static request buffers (make the captured graph independent of caller pointers)
         {"img_s", (size_t)B * Li * e->d.in_channels * 2}, {"txt_s", (size_t)B * Lt * e->d.ctx_in * 2}, {"y_s", (size_t)B * e->d.vec_in * 2},
         {"pred_s", (size_t)B * Li * e->d.in_channels * 2}, {"txt_emb", (size_t)B * Lt * H * 2},
@@ -554,13 +690,6 @@ int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, 
                       mode, trial_index, false, (hipStream_t)stream);
 }
 
-static u16 host_f2bf(double v) {
-  float f = (float)v;
-  unsigned u;
-  memcpy(&u, &f, 4);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (u16)(u >> 16);
-}
 
 int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const void* y, float guidance,
                           const double* timesteps_host, int n_steps, int* trial_index_inout, int use_graph, void* stream) {
@@ -614,9 +743,16 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
       FLUXMI_TRY(embed_txt(e, txt_s, false, 0, buf<u16>(e, "txt_emb"), (long long)Lt * e->d.hidden, s));
       e->txt_emb_valid = true;
     }
+    // modulation table for steps [step, n_steps); a captured graph stays valid as long as the table does not move and
+    // starts at the same step index
+    const int old_step0 = e->mods_step0;
+    FLUXMI_TRY(precompute_mods(e, ts, step, n_steps, g_arg, y_s, s));
+    if (old_step0 != e->mods_step0) e->graph_ok = false;
     auto one_step = [&](hipStream_t st) -> int {
-      FLUXMI_TRY(fluxmi_k_set_timestep(tvec, e->d_ts, e->d_step, B, st));
-      FLUXMI_TRY(forward_impl(e, img_s, txt_s, y_s, tvec, g_arg, pred_s, mode, 0, mode == 1, st));
+      e->mods_table = true;
+      int rc = forward_impl(e, img_s, txt_s, y_s, tvec, g_arg, pred_s, mode, 0, mode == 1, st);
+      e->mods_table = false;
+      FLUXMI_TRY(rc);
       FLUXMI_TRY(fluxmi_k_euler(img_s, pred_s, e->d_dts, e->d_step, n_img, st));
       return fluxmi_k_advance_step(e->d_step, st);
     };

@@ -63,7 +63,7 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int tile_cf
 int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
 int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8);
 int fluxmi_launch_gemv(const FluxmiGemvLayer* layers_dev, FluxmiGemvLayer* layers_host, int n_layers, int B, int total_blocks,
-                       int max_K, hipStream_t s);
+                       int max_K, hipStream_t s, int row0 = 0);
 int fluxmi_gemv_blocks(const FluxmiGemvLayer* layers_host, int n_layers);
 
 int fluxmi_k_quantize_act(const void* x, void* q, const float* scale, int rows, int cols, long long ld_in, long long ld_out, int fmt, hipStream_t s);
@@ -82,6 +82,8 @@ int fluxmi_k_act(const void* x, void* y, int rows, int cols, long long ld_in, lo
 int fluxmi_k_gate_residual(const void* x, const void* y, const void* gate, void* out, int B, int L, int H, long long ldx,
                            long long ldy, long long ldo, long long gate_bstride, hipStream_t s);
 int fluxmi_k_add(const void* a, const void* b, void* z, long long n, hipStream_t s);
+int fluxmi_k_add_bcast(const void* a, const void* b, void* z, long long rows, int nb, int cols, hipStream_t s);
+int fluxmi_k_select_step(const void* table, const int* step, int step0, void* dst, long long bytes, hipStream_t s);
 int fluxmi_k_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, hipStream_t s);
 int fluxmi_k_rope_table(const void* ids, const float* omega, const int* axis, void* pe, long long rows, int n_axes, int pairs, hipStream_t s);
 int fluxmi_k_euler(void* img, const void* pred, const float* dts, const int* step, long long n, hipStream_t s);

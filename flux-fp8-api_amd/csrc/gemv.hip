@@ -22,7 +22,7 @@ template <int FMT> __device__ __forceinline__ float quant_dequant(float x, float
 }
 
 __global__ void __launch_bounds__(256) gemv_kernel(const FluxmiGemvLayer* __restrict__ layers, int n_layers,
-                                                   const FluxmiGemvLayer single, int B) {
+                                                   const FluxmiGemvLayer single, int B, int xrow0) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [B][K]
   // ---- locate layer ------------------------------------------------------------------------
   FluxmiGemvLayer L = single;
@@ -31,6 +31,9 @@ __global__ void __launch_bounds__(256) gemv_kernel(const FluxmiGemvLayer* __rest
     for (int i = 1; i < n_layers; ++i) li = ((int)blockIdx.x >= layers[i].blk_start) ? i : li;
     L = layers[li];
   }
+  // xrow0: first of the B activation / output rows this launch handles (step-ahead batches of the modulation table)
+  L.x = (const u16*)L.x + (long long)xrow0 * L.ldx;
+  L.out = (u16*)L.out + (long long)xrow0 * L.ld_out;
   const int K = L.K;
   const int row0 = ((int)blockIdx.x - L.blk_start) * GEMV_ROWS;
   // ---- stage activations: silu -> (quantise -> dequantise) -> fp32 in LDS ---------------------
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(256) gemv_kernel(const FluxmiGemvLayer* __rest
 // layers_host: the same descriptors on the host (to size the grid); layers_dev may be nullptr when
 // n_layers == 1 (the single descriptor then travels as a kernel argument).
 int fluxmi_launch_gemv(const FluxmiGemvLayer* layers_dev, FluxmiGemvLayer* layers_host, int n_layers, int B, int total_blocks,
-                       int max_K, hipStream_t s) {
+                       int max_K, hipStream_t s, int row0) {
   FLUXMI_REQUIRE(B >= 1 && B <= GEMV_MAXB, "gemv: batch %d unsupported (1..8)", B);
   FLUXMI_REQUIRE(n_layers >= 1, "gemv: no layers");
   if (layers_host) {
@@ -122,7 +125,7 @@ int fluxmi_launch_gemv(const FluxmiGemvLayer* layers_dev, FluxmiGemvLayer* layer
     attr = 160 * 1024;
   }
   FluxmiGemvLayer single = layers_host ? layers_host[0] : FluxmiGemvLayer{};
-  hipLaunchKernelGGL(gemv_kernel, dim3(total_blocks), dim3(256), smem, s, layers_dev, n_layers, single, B);
+  hipLaunchKernelGGL(gemv_kernel, dim3(total_blocks), dim3(256), smem, s, layers_dev, n_layers, single, B, row0);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }
