@@ -157,19 +157,28 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const LnModArgs a) {
   const int b = row / a.L, l = row % a.L, st = (l < a.split) ? 0 : 1;
   const u16* xr = a.x + (long long)b * a.x_bstride + (long long)l * a.ldx;
   const long long orow = (long long)b * a.out_bstride + (long long)l * a.ldo;
-  float v[NCH][8];
-  float sum = 0.f;
+  // everything the row needs is requested up front (x, scale, shift: 3 x NCH independent 16 B loads per lane) and kept packed, so
+  // one memory latency covers all of it; a wave per row means the kernel is latency-, not bandwidth-shaped (18 waves per CU).
+  const u16* sh = a.shift[st] + (long long)b * a.mod_bstride;
+  const u16* sc = a.scale[st] + (long long)b * a.mod_bstride;
+  uint4 xr4[NCH], sc4[NCH], sh4[NCH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int c = (lane + 64 * k) * 8;
-    if (c < a.H) {
-      unpack8(*(const uint4*)(xr + c), v[k]);
+    const bool ok = c < a.H;
+    xr4[k] = ok ? *(const uint4*)(xr + c) : make_uint4(0, 0, 0, 0);
+    sc4[k] = ok ? *(const uint4*)(sc + c) : make_uint4(0, 0, 0, 0);
+    sh4[k] = ok ? *(const uint4*)(sh + c) : make_uint4(0, 0, 0, 0);
+  }
+  float qs = 1.f;
+  if (OUT_FP8) qs = *a.q_scale[st];
+  float sum = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sum += v[k][j];
-    } else {
+  for (int k = 0; k < NCH; ++k) {
+    float v[8];
+    unpack8(xr4[k], v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
-    }
+    for (int j = 0; j < 8; ++j) sum += v[j];
   }
   const float mean = wave_sum(sum) / (float)a.H;
   float sq = 0.f;
@@ -177,26 +186,25 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const LnModArgs a) {
   for (int k = 0; k < NCH; ++k) {
     const int c = (lane + 64 * k) * 8;
     if (c < a.H) {
+      float v[8];
+      unpack8(xr4[k], v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; sq += d * d; }
+      for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; sq += d * d; }
     }
   }
   const float var = wave_sum(sq) / (float)a.H;
   const float rstd = 1.0f / sqrtf(var + 1e-6f);
-  const u16* sh = a.shift[st] + (long long)b * a.mod_bstride;
-  const u16* sc = a.scale[st] + (long long)b * a.mod_bstride;
-  float qs = 1.f;
-  if (OUT_FP8) qs = *a.q_scale[st];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int c = (lane + 64 * k) * 8;
     if (c < a.H) {
-      float fs[8], fh[8], y[8];
-      unpack8(*(const uint4*)(sc + c), fs);
-      unpack8(*(const uint4*)(sh + c), fh);
+      float v[8], fs[8], fh[8], y[8];
+      unpack8(xr4[k], v);
+      unpack8(sc4[k], fs);
+      unpack8(sh4[k], fh);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float n = rbf((v[k][j] - mean) * rstd);
+        const float n = rbf((v[j] - mean) * rstd);
         const float m1 = rbf(1.0f + fs[j]);
         y[j] = rbf(rbf(m1 * n) + fh[j]);
       }

@@ -110,7 +110,7 @@ def make_f8_problem(M, N, K, fmt, seed):
     return a8, w8, sa.reciprocal(), sbr, bias
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 100])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 100])
 @pytest.mark.parametrize("shape", [(256, 256, 64), (256, 256, 128), (512, 768, 256), (300, 512, 384), (37, 256, 3072), (1024, 1024, 1024)])
 @pytest.mark.parametrize("fmt", [E5M2, E4M3])
 def test_f8_gemm(ops, dev, cfg, shape, fmt):
@@ -118,7 +118,7 @@ def test_f8_gemm(ops, dev, cfg, shape, fmt):
     M, N, K = shape
     if fmt == E4M3 and (cfg not in (0, 4, 8, 11, 100) or shape != (512, 768, 256)):
         pytest.skip("e4m3 activations: one representative case per kernel")
-    if K % 128 and cfg in (0, 1, 2, 3):
+    if K % 128 and cfg in (0, 1, 2, 3, 15):
         pytest.skip("double-buffered kernels step K by 128 bytes")
     a8, w8, sar, sbr, bias = make_f8_problem(M, N, K, fmt, seed=M + N + K)
     ref = round_fp64_to_bf16(fo.scaled_mm_fp64(a8, w8, sar, sbr, bias))
@@ -142,7 +142,7 @@ def accum_noise(a, w, s):
     return 16.0 * math.sqrt(max(a.shape[1], 256)) * 2.0 ** -24 * S * 2.0 ** 7
 
 
-@pytest.mark.parametrize("cfg", [0, 2, 4, 6, 7, 8, 9, 11, 100])
+@pytest.mark.parametrize("cfg", [0, 2, 4, 6, 7, 8, 9, 11, 15, 100])
 def test_bf16_gemm(ops, dev, cfg):
     torch.manual_seed(5)
     M, N, K = 320, 512, 192
