@@ -142,7 +142,7 @@ int run_gemm(std::vector<FluxmiGemmGroup>& gs, int N, int K, int is_fp8, int act
     if (best_k > 0) {
       std::vector<FluxmiGemmGroup> big, small;
       for (size_t q = 0; q < gs.size(); ++q) (q < (size_t)best_k ? small : big).push_back(gs[order[q]]);
-      FLUXMI_TRY(run_gemm_chunk(big.data(), (int)big.size(), N, K, is_fp8, act_fmt, epi, 13, s));
+      FLUXMI_TRY(run_gemm_chunk(big.data(), (int)big.size(), N, K, is_fp8, act_fmt, epi, -1, s));
       return run_gemm_chunk(small.data(), (int)small.size(), N, K, is_fp8, act_fmt, epi, 2, s);
     }
   }

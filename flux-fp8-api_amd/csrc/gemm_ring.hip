@@ -16,93 +16,6 @@
 
 namespace {
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// phase 2 of the epilogue: lane owns 8 consecutive columns n..n+7 of row m, h[] = bf16(acc*s+bias) values
-template <int EPI, int FMT>
-__device__ __forceinline__ void row_epilogue(const FluxmiGemmGroup& G, float qs, int m, int n, const float* h) {
-  if constexpr (EPI == FLUXMI_EPI_BF16) {
-    *(uint4*)((u16*)G.C + (long long)m * G.ldc + n) = pack8(h);
-  } else if constexpr (EPI == FLUXMI_EPI_GATE_RESID) {
-    float r[8], g[8], o[8];
-    unpack8(*(const uint4*)((const u16*)G.resid + (long long)m * G.ldr + n), r);
-    unpack8(*(const uint4*)((const u16*)G.gate + n), g);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = r[j] + rbf(g[j] * h[j]);
-    *(uint4*)((u16*)G.C + (long long)m * G.ldc + n) = pack8(o);
-  } else {
-    // quantising epilogues (optionally through GELU / SiLU); SPLIT routes by column range
-    unsigned char* dst;
-    bool plain = false;
-    if constexpr (EPI == FLUXMI_EPI_SPLIT) {
-      if (n < G.split_n) {
-        plain = true;
-        dst = nullptr;
-      } else {
-        dst = (unsigned char*)G.C2 + (long long)m * G.ldc2 + G.c2_col0 + (n - G.split_n);
-      }
-    } else {
-      dst = (unsigned char*)G.C + (long long)m * G.ldc + n;
-    }
-    if (plain) {
-      *(uint4*)((u16*)G.C + (long long)m * G.ldc + n) = pack8(h);
-      return;
-    }
-    float g[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if constexpr (EPI == FLUXMI_EPI_GELU_QUANT || EPI == FLUXMI_EPI_SPLIT) g[j] = rbf(gelu_tanh_f(h[j]));
-      else if constexpr (EPI == FLUXMI_EPI_SILU_QUANT) g[j] = rbf(silu_f(h[j]));
-      else g[j] = h[j];
-    }
-    uint2 o;
-    o.x = cvt4_fp8<FMT>(q_prepare<FMT>(g[0], qs), q_prepare<FMT>(g[1], qs), q_prepare<FMT>(g[2], qs), q_prepare<FMT>(g[3], qs));
-    o.y = cvt4_fp8<FMT>(q_prepare<FMT>(g[4], qs), q_prepare<FMT>(g[5], qs), q_prepare<FMT>(g[6], qs), q_prepare<FMT>(g[7], qs));
-    *(uint2*)dst = o;
-  }
-}
-
-template <int EPI, int FMT, int TM, int TN>
-__device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&acc)[TM][TN], float s, float qs, unsigned char* wbuf,
-                                             int m_wave0, int n_wave0, int M, int lane) {
-  // phase 1: h = bf16(acc*s + bias) -> per-wave LDS tile [TM*32 rows][TN*32 cols] bf16, 16-B chunks XOR-swizzled by row
-  constexpr int ROW_B = TN * 64;       // bytes per row (TN*32 bf16)
-  constexpr int CH = ROW_B / 16;       // 16-B chunks per row
-  const int l31 = lane & 31, hi = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int nl = j * 32 + g4 * 8 + hi * 4;  // local column of this lane's 4 values
-      float bias[4] = {0.f, 0.f, 0.f, 0.f};
-      if (G.bias) load_bf<4>(G.bias, n_wave0 + nl, bias);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int ml = i * 32 + l31;
-        uint2 v;
-        v.x = pack_bf2(fmaf(acc[i][j][g4 * 4 + 0], s, bias[0]), fmaf(acc[i][j][g4 * 4 + 1], s, bias[1]));
-        v.y = pack_bf2(fmaf(acc[i][j][g4 * 4 + 2], s, bias[2]), fmaf(acc[i][j][g4 * 4 + 3], s, bias[3]));
-        const int chunk = (nl >> 3) ^ (ml & (CH - 1));
-        *(uint2*)(wbuf + ml * ROW_B + chunk * 16 + (nl & 4) * 2) = v;
-      }
-    }
-  // the tile is private to this wave: no barrier, only the LDS write -> read ordering of one wave
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // phase 2: lane -> (row, 16-B chunk); 64 lanes cover (64/CH) rows x ROW_B bytes per pass
-  constexpr int RPP = 64 / CH;  // rows per pass
-#pragma unroll
-  for (int it = 0; it < (TM * 32) / RPP; ++it) {
-    const int ml = it * RPP + lane / CH, c = lane % CH;
-    const int m = m_wave0 + ml;
-    const uint4 raw = *(const uint4*)(wbuf + ml * ROW_B + ((c ^ (ml & (CH - 1))) * 16));
-    if (m < M) {
-      float h[8];
-      unpack8(raw, h);
-      row_epilogue<EPI, FMT>(G, qs, m, n_wave0 + c * 8, h);
-    }
-  }
-}
-
 template <int BM, int BN, int WM, int WN, int NS, bool SPREAD, bool FP8, int ACT_FMT, int ABL = 0>
 __global__ void __launch_bounds__(WM* WN * 64, (NS == 3 ? 2 : 1) * WM * WN / 4) gemm_ring_kernel(const FluxmiGemmParams P) {
   constexpr int NT = WM * WN * 64;

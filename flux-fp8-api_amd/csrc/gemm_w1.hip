@@ -1,0 +1,244 @@
+// fluxmi -- "w1" GEMM: 256x256 tile, FOUR waves, one per SIMD, each owning a 128x128 accumulator block (gfx950).
+//
+// Same math, operands, grouping and epilogues as gemm.hip / gemm_ring.hip.  Why another shape: on real (non-zero) data the fp8
+// matrix pipe of MI355X is power-limited (tools/probes/mfma_rate.hip: 3.7 PF/s of MFMA-only work on random operands, 5.0 on
+// zeros), so what a GEMM reaches is set by how much energy it spends NOT doing MFMAs.  A 128x128 wave tile reads 8 fragments
+// per 16 MFMAs from LDS instead of 6 per 8 (-33 % LDS read traffic for the same flops), needs no partner wave (one wave per SIMD
+// issues the MX MFMA back to back at the full rate, same probe), and its 256 accumulator + 128 fragment registers fit the
+// 512-register budget of a single wave per SIMD.
+//  * 4-slot LDS ring of 64-byte K-steps (4 x 32 KiB), refilled three steps ahead by LDS-DMA through buffer descriptors
+//    (`buffer_load_dwordx4 ... offen lds`: fixed per-lane offset in a VGPR, tile / K offset in an SGPR -> no address VALU, rows
+//    past M read as zero);
+//  * one barrier per K-step, counted vmcnt (the refill of step k+2 stays in flight across it);
+//  * the step is fully software-pipelined inside the wave: MFMA slot s of step k is followed by the LDS read of fragment half s of
+//    step k+1 (second register set) and, every other slot, by one LDS-DMA piece of step k+3.  The loop is unrolled by four so
+//    that ring slots are immediates;
+//  * epilogue through LDS as in the ring kernels (the idle ring is the transposition scratch, 32 KiB per wave).
+// Requires K*bytes % 256 == 0 (four K-steps per unrolled iteration).
+#include <stdlib.h>
+
+#include "gemm_epilogue.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// one 1 KiB LDS-DMA piece (kept out of the kernel template: a device-only builtin in template-dependent code makes hipcc's host
+// pass drop the kernel stub)
+__device__ __forceinline__ void w1_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff, soff, 0, 0);
+}
+// The descriptor inputs are wave-uniform in fact (they come from the block's tile / problem index) but reach us through a
+// dynamically indexed kernel-argument struct, i.e. in VGPRs: without readfirstlane hipcc wraps EVERY buffer op in a waterfall loop.
+__device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w1_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  const unsigned long long ub = ((unsigned long long)uni((unsigned)(b >> 32)) << 32) | uni((unsigned)b);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, uni(bytes), 0x00020000);
+}
+
+struct W1Frags { v8i fw[4]; v8i fa[4]; };
+
+template <bool FP8, int ACT_FMT, int ABL>
+__global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams P) {
+  constexpr int BM = 256, BN = 256, NT = 256, TM = 4, TN = 4, NS = 4;
+  constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
+  constexpr int LPT = 8;  // LDS-DMA pieces per wave per K-step (4 of A, 4 of W)
+  constexpr int EB = FP8 ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int tiles_n = P.N / BN;
+  const int nblk = P.tiles_m_total * tiles_n;
+  const int lid = xcd_remap(blockIdx.x, nblk);
+  const int width = P.group_m * tiles_n;
+  const int first_m = (lid / width) * P.group_m;
+  const int gsz = min(P.tiles_m_total - first_m, P.group_m);
+  const int tm = first_m + (lid % width) % gsz;
+  const int tn = (lid % width) / gsz;
+  int gi = 0;
+  for (int i = 1; i < P.n_groups; ++i) gi = (tm >= P.g[i].m_tile_start) ? i : gi;
+  const FluxmiGemmGroup& G = P.g[gi];
+  const int M = G.M;
+  const int m0 = (tm - G.m_tile_start) * BM;
+  const int n0 = tn * BN;
+  const int nk = (P.K * EB) / 64;
+  constexpr int abl = ABL;  // timing-only ablations (1 = no LDS-DMA refill, 2 = no LDS reads, 4 = no barrier); 0 in production
+
+  // ---- LDS-DMA: descriptors (SGPRs), per-lane offsets (VGPRs, loop-invariant), tile offsets (SGPRs) ----------------------------
+  const long long a_row_b = (long long)G.lda * EB, w_row_b = (long long)P.K * EB;
+  const __amdgpu_buffer_rsrc_t ars = w1_rsrc(G.A, (unsigned)min((long long)M * a_row_b, 0xffffffffLL));
+  const __amdgpu_buffer_rsrc_t wrs = w1_rsrc(G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
+  unsigned a_voff[4], w_voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
+    a_voff[i] = (unsigned)(row * a_row_b + slot * 16);
+    w_voff[i] = (unsigned)(row * w_row_b + slot * 16);
+  }
+  const unsigned a_soff0 = uni((unsigned)(m0 * a_row_b)), w_soff0 = uni((unsigned)(n0 * w_row_b));
+  // piece q (0..7) of K-step kt into ring slot `slot`
+  auto dma_piece = [&](int q, int slot, int kt) {
+    unsigned char* d = smem + slot * STAGE + wave * 1024;
+    if (q < 4) w1_dma16(ars, d + NT * 16 * q, a_voff[q], a_soff0 + kt * 64);
+    else w1_dma16(wrs, d + A_BYTES + NT * 16 * (q - 4), w_voff[q - 4], w_soff0 + kt * 64);
+  };
+
+  v16f acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read addresses: (row * 64 + swizzled 16-B slot) per operand half; ring slot and 32-row tile index are immediates.
+  // ds_read immediates are 16 bits, so slots 2 and 3 use a second base (+64 KiB).
+  unsigned a_lo[2], a_hi[2], w_lo[2], w_hi[2];
+  {
+    const int ra = wm * 128 + l31, ka = (ra >> 2) & 3;
+    const int rw = wn * 128 + l31, kw = (rw >> 2) & 3;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      a_lo[h2] = (unsigned)(h2 * 2 * STAGE + ra * 64 + (((hi * 2) ^ ka) << 4));
+      a_hi[h2] = (unsigned)(h2 * 2 * STAGE + ra * 64 + (((hi * 2 + 1) ^ ka) << 4));
+      w_lo[h2] = (unsigned)(h2 * 2 * STAGE + A_BYTES + rw * 64 + (((hi * 2) ^ kw) << 4));
+      w_hi[h2] = (unsigned)(h2 * 2 * STAGE + A_BYTES + rw * 64 + (((hi * 2 + 1) ^ kw) << 4));
+    }
+  }
+  // half `hf` (0 = low 16 B, 1 = high 16 B) of fragment `f` (0..3 = W tiles, 4..7 = A tiles) of ring slot `slot`
+  auto read_half = [&](W1Frags& F, int slot, int f, int hf) {
+    const int h2 = slot >> 1, imm = (slot & 1) * STAGE + (f & 3) * 2048;
+    const unsigned base = f < 4 ? (hf ? w_hi[h2] : w_lo[h2]) : (hf ? a_hi[h2] : a_lo[h2]);
+    const v4i v = *(const v4i*)(smem + base + imm);
+    v8i& dst = f < 4 ? F.fw[f] : F.fa[f - 4];
+    dst[hf * 4 + 0] = v[0]; dst[hf * 4 + 1] = v[1]; dst[hf * 4 + 2] = v[2]; dst[hf * 4 + 3] = v[3];
+  };
+  auto mma = [&](const W1Frags& F, int i, int j) {
+    if constexpr (FP8) {
+      acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(F.fw[j], F.fa[i], acc[i][j], FLUXMI_FMT_E4M3, ACT_FMT, 0, 0x7f7f7f7f, 0,
+                                                                0x7f7f7f7f);
+    } else {
+      const v4i alo = (v4i){F.fa[i][0], F.fa[i][1], F.fa[i][2], F.fa[i][3]}, ahi = (v4i){F.fa[i][4], F.fa[i][5], F.fa[i][6], F.fa[i][7]};
+      const v4i wlo = (v4i){F.fw[j][0], F.fw[j][1], F.fw[j][2], F.fw[j][3]}, whi = (v4i){F.fw[j][4], F.fw[j][5], F.fw[j][6], F.fw[j][7]};
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, wlo), __builtin_bit_cast(v8bf, alo), acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, whi), __builtin_bit_cast(v8bf, ahi), acc[i][j], 0, 0, 0);
+    }
+  };
+  auto fence = []() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: K-steps 0..2 in flight, fragments of step 0 in registers ---------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) dma_piece(q, t, t);  // (K offsets past the row end fetch harmless bytes; nk >= 4 anyway)
+  wait_vmcnt<2 * LPT>();
+  __builtin_amdgcn_s_barrier();
+  W1Frags fa_, fb_;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    read_half(fa_, 0, f, 0);
+    read_half(fa_, 0, f, 1);
+  }
+
+  // One K-step with compile-time ring slot S.  Entry: `cur` = fragments of step kt (LDS reads possibly still in flight), LDS-DMA of
+  // steps kt+1, kt+2 in flight.  16 MFMA slots; behind MFMA slot s: LDS read s of the NEXT step's fragments, and behind every even
+  // slot one LDS-DMA piece of step kt+3 (into the slot step kt-1 vacated).  Past the end of K the refill fetches don't-care bytes
+  // into a slot nobody reads any more and the "next" fragments are re-read from a stale slot: no branches in the body.
+  auto step = [&](auto SLOT, W1Frags& cur, W1Frags& nxt, int kt) {
+    constexpr int S = decltype(SLOT)::value, SN = (S + 1) & 3, SR = (S + 3) & 3;
+    wait_vmcnt<LPT>();  // step kt+1 landed (own pieces); step kt+2 stays in flight
+    if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+    fence();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      mma(cur, s >> 2, s & 3);
+      fence();
+      // next fragments: W halves first (needed by every MFMA row), then A
+      if (!(abl & 2)) read_half(nxt, SN, s >> 1, s & 1);
+      if ((s & 1) == 0 && !(abl & 1)) dma_piece(s >> 1, SR, kt + 3);
+      fence();
+    }
+  };
+  for (int kt = 0; kt < nk; kt += 4) {
+    step(std::integral_constant<int, 0>{}, fa_, fb_, kt);
+    step(std::integral_constant<int, 1>{}, fb_, fa_, kt + 1);
+    step(std::integral_constant<int, 2>{}, fa_, fb_, kt + 2);
+    step(std::integral_constant<int, 3>{}, fb_, fa_, kt + 3);
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------------
+  const float s = load_scale(G.sa_recip) * load_scale(G.sb_recip);
+  const float qs = G.q_scale ? *G.q_scale : 1.0f;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing don't-care refills must land before the ring is reused
+  __builtin_amdgcn_s_barrier();
+  unsigned char* wbuf = smem + wave * (128 * 128 * 2);
+  const int mw = m0 + wm * 128, nw = n0 + wn * 128;
+  switch (P.epi) {
+    case FLUXMI_EPI_BF16: lds_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_GELU_QUANT: lds_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_GATE_RESID: lds_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_SPLIT: lds_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_QUANT: lds_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_SILU_QUANT: lds_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    default: break;
+  }
+}
+
+template <bool FP8, int ACT, int ABL = 0>
+int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
+  constexpr int BM = 256, BN = 256;
+  int t = 0;
+  for (int i = 0; i < p.n_groups; ++i) {
+    p.g[i].m_tile_start = t;
+    t += (p.g[i].M + BM - 1) / BM;
+  }
+  p.tiles_m_total = t;
+  p.group_m = 8;
+  constexpr int SMEM = 4 * (BM + BN) * 64;
+  auto kern = gemm_w1_kernel<FP8, ACT, ABL>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  const int nblk = t * (p.N / BN);
+  if (nblk == 0) return 0;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), SMEM, s, p);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+// config 16 = 256x256, one wave per SIMD
+int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {
+  // buffer descriptors address 4 GiB per operand
+  for (int i = 0; i < p.n_groups; ++i)
+    FLUXMI_REQUIRE((long long)p.g[i].M * p.g[i].lda * (is_fp8 ? 1 : 2) < (1LL << 32) && (long long)p.N * p.K * (is_fp8 ? 1 : 2) < (1LL << 32),
+                   "gemm_w1: operand larger than 4 GiB");
+  if (is_fp8) {
+    if (act_fmt == FLUXMI_FMT_E5M2) {
+      static int abl = -1;  // FLUXMI_GEMM_ABL: timing-only ablations for tools/gemm_probe.py
+      if (abl < 0) { const char* e = getenv("FLUXMI_GEMM_ABL"); abl = e ? atoi(e) : 0; }
+      switch (abl) {
+        case 1: return launch_w1<true, FLUXMI_FMT_E5M2, 1>(p, s);
+        case 2: return launch_w1<true, FLUXMI_FMT_E5M2, 2>(p, s);
+        case 3: return launch_w1<true, FLUXMI_FMT_E5M2, 3>(p, s);
+        case 4: return launch_w1<true, FLUXMI_FMT_E5M2, 4>(p, s);
+        case 7: return launch_w1<true, FLUXMI_FMT_E5M2, 7>(p, s);
+        default: break;
+      }
+      return launch_w1<true, FLUXMI_FMT_E5M2>(p, s);
+    }
+    return launch_w1<true, FLUXMI_FMT_E4M3>(p, s);
+  }
+  if (act_fmt == FLUXMI_FMT_E5M2) return launch_w1<false, FLUXMI_FMT_E5M2>(p, s);
+  return launch_w1<false, FLUXMI_FMT_E4M3>(p, s);
+}

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/$OUT
 cd /tmp; export TMPDIR=/tmp
 for c in "$@"; do
-  (cd $R && rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/$OUT/c$c -- python tools/gemm_probe.py --shape $SHAPE --cfg $c --iters 8) > $R/$OUT/c$c.log 2>&1
+  (cd $R && timeout 120 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/$OUT/c$c -- python tools/gemm_probe.py --shape $SHAPE --cfg $c --iters 8) > $R/$OUT/c$c.log 2>&1
 done
 cd $R
 python - "$OUT" "$@" <<'PY'
