@@ -100,6 +100,23 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float t = fmaf(2.0f, s, -1.0f);
   return (0.5f * x) * (1.0f + t);
 }
+// The same GELU on a pair of values with packed f32 VALU ops (v_pk_mul/fma/add: two lanes of work per 4-cycle instruction; the
+// epilogues are VALU-issue bound).  Bit-identical to gelu_tanh_f per element: identical operations in identical order.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_t gelu_tanh_f2(v2f_t x) {
+  const v2f_t c1 = {-2.3022081981f, -2.3022081981f}, c2 = {-0.10294323958f, -0.10294323958f};
+  const v2f_t one = {1.0f, 1.0f}, two = {2.0f, 2.0f}, mone = {-1.0f, -1.0f}, half = {0.5f, 0.5f};
+  const v2f_t z = x * __builtin_elementwise_fma(x * x, c2, c1);
+  const v2f_t d = one + (v2f_t){__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+  const v2f_t sg = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const v2f_t t = __builtin_elementwise_fma(two, sg, mone);
+  return (half * x) * (one + t);
+}
+// round a pair through bf16: one v_cvt_pk_bf16_f32 + two unpacks
+__device__ __forceinline__ v2f_t rbf2(v2f_t x) {
+  const unsigned u = pack_bf2(x[0], x[1]);
+  return (v2f_t){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
 __device__ __forceinline__ float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }

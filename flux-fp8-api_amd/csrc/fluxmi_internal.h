@@ -62,6 +62,8 @@ int fluxmi_gemm_tile_bm(int cfg);
 int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int tile_cfg, hipStream_t s);
 int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
 int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8);
+// tile choice + (when it pays) the split of a grouped launch into a 256x256 and a 128x128 launch; any number of groups
+int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs, int n, int N, int K, int is_fp8, int act_fmt, int epi, hipStream_t s);
 int fluxmi_launch_gemv(const FluxmiGemvLayer* layers_dev, FluxmiGemvLayer* layers_host, int n_layers, int B, int total_blocks,
                        int max_K, hipStream_t s, int row0 = 0);
 int fluxmi_gemv_blocks(const FluxmiGemvLayer* layers_host, int n_layers);

@@ -105,16 +105,28 @@ __device__ __forceinline__ void row_epilogue(const FluxmiGemmGroup& G, float qs,
       *(uint4*)((u16*)G.C + (long long)m * G.ldc + n) = pack8(h);
       return;
     }
-    float g[8];
+    // pairs of values through packed f32 math (the epilogue is VALU-issue bound: 4 cycles per wave64 instruction whatever it does)
+    float t[8];
+    const v2f_t qs2 = {qs, qs};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if constexpr (EPI == FLUXMI_EPI_GELU_QUANT || EPI == FLUXMI_EPI_SPLIT) g[j] = rbf(gelu_tanh_f(h[j]));
-      else if constexpr (EPI == FLUXMI_EPI_SILU_QUANT) g[j] = rbf(silu_f(h[j]));
-      else g[j] = h[j];
+    for (int j = 0; j < 8; j += 2) {
+      v2f_t g = {h[j], h[j + 1]};
+      if constexpr (EPI == FLUXMI_EPI_GELU_QUANT || EPI == FLUXMI_EPI_SPLIT) g = rbf2(gelu_tanh_f2(g));
+      else if constexpr (EPI == FLUXMI_EPI_SILU_QUANT) g = (v2f_t){rbf(silu_f(g[0])), rbf(silu_f(g[1]))};
+      // q_prepare: bf16(x * scale), clamp (NaN-propagating), then the RNE fp8 convert              float8_quantize.py:217-218
+      const v2f_t p = rbf2(g * qs2);
+      const float mx = fp8_max<FMT>();
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float v = p[e];
+        v = (v > mx) ? mx : v;
+        v = (v < -mx) ? -mx : v;
+        t[j + e] = v;
+      }
     }
     uint2 o;
-    o.x = cvt4_fp8<FMT>(q_prepare<FMT>(g[0], qs), q_prepare<FMT>(g[1], qs), q_prepare<FMT>(g[2], qs), q_prepare<FMT>(g[3], qs));
-    o.y = cvt4_fp8<FMT>(q_prepare<FMT>(g[4], qs), q_prepare<FMT>(g[5], qs), q_prepare<FMT>(g[6], qs), q_prepare<FMT>(g[7], qs));
+    o.x = cvt4_fp8<FMT>(t[0], t[1], t[2], t[3]);
+    o.y = cvt4_fp8<FMT>(t[4], t[5], t[6], t[7]);
     *(uint2*)dst = o;
   }
 }

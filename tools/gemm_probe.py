@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="lin1")
     ap.add_argument("--cfg", type=int, default=4)
-    ap.add_argument("--epi", default="bf16", choices=["bf16", "gelu", "gate"])
+    ap.add_argument("--epi", default="bf16", choices=["bf16", "gelu", "gate", "quant"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fill", default="rand", choices=["rand", "zero"])
     ap.add_argument("--ab", default=None, help="comma list of configs to A/B interleaved")
@@ -47,6 +47,8 @@ def main():
     def run(cfg):
         if args.epi == "bf16":
             ops.linear(a, w, bias, one, one, out=out, tile_cfg=cfg)
+        elif args.epi == "quant":
+            ops.linear(a, w, bias, one, one, out=out8, epilogue=_lib.EPI_QUANT, q_scale=one, tile_cfg=cfg)
         elif args.epi == "gelu":
             ops.linear(a, w, bias, one, one, out=out8, epilogue=_lib.EPI_GELU_QUANT, q_scale=one, tile_cfg=cfg)
         else:
