@@ -217,6 +217,12 @@ int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, lo
                      const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream) {
   return fluxmi_k_attention(Q, K, VT, out, ld_out, col_off, out_fp8, q_scale0, q_scale1, split, B, L, Lp, H, fmt, (hipStream_t)stream);
 }
+int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, const void* qn_scale0, const void* qn_scale1, const void* K,
+                          const void* VT, void* out, long long ld_out, int col_off, int out_fp8, const float* q_scale0,
+                          const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream) {
+  return fluxmi_k_attention(nullptr, K, VT, out, ld_out, col_off, out_fp8, q_scale0, q_scale1, split, B, L, Lp, H, fmt, (hipStream_t)stream,
+                            qkv, ld_qkv, pe, qn_scale0, qn_scale1);
+}
 int fluxmi_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, void* stream) {
   return fluxmi_k_timestep_embedding(t, freqs, out, B, half, time_factor, (hipStream_t)stream);
 }

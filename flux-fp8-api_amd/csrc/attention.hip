@@ -33,6 +33,9 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
 
 struct AttnArgs {
   const u16* Q; const u16* K; const u16* VT;
+  // raw-Q mode (Q == nullptr): query rows come straight from the qkv GEMM output; QKNorm + RoPE are applied while the Q fragments
+  // are loaded (flux_model.py:158-176,60-65), so the normalised/rotated Q tensor is never written to or re-read from HBM
+  const u16* qraw; long long ldq; const u16* pe; const u16* qn[2];
   void* out; long long ld_out; int col_off; int out_fp8;
   const float* q_scale[2]; int split;
   int B, L, Lp, H;
@@ -71,12 +74,47 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_kernel(const AttnArgs a)
   const int qld = min(qrow, a.L - 1);
   const long long bh = (long long)b * a.H + h;
 
-  // ---- Q fragments (MFMA B operand): 8 x (8 bf16) ------------------------------------------------
+  // ---- Q fragments (MFMA B operand): 8 x (8 bf16); lane (l31, hi) holds d = c*16 + hi*8 + [0,8) of query row l31 --------------
   v8bf qf[8];
-  {
+  if (a.Q) {
     const u16* qp = a.Q + (bh * a.L + qld) * 128 + hi * 8;
 #pragma unroll
     for (int c = 0; c < 8; ++c) qf[c] = *(const v8bf*)(qp + c * 16);
+  } else {
+    const long long tok = (long long)b * a.L + qld;
+    const u16* qp = a.qraw + tok * a.ldq + (long long)h * 128 + hi * 8;
+    const u16* pp = a.pe + (tok * 64 + hi * 4) * 2;  // (cos, sin) of pairs d/2
+    const u16* wn = a.qn[qld < a.split ? 0 : 1] + hi * 8;
+    float x[8][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      unpack8(*(const uint4*)(qp + c * 16), x[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += x[c][j] * x[c][j];
+    }
+    {  // the other 64 values of the row sit in lane ^ 32
+      const unsigned u = __float_as_uint(ss);
+      const auto sw2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      ss = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+    }
+    const float rinv = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float w[8], cs[8], y[8];
+      unpack8(*(const uint4*)(wn + c * 16), w);
+      unpack8(*(const uint4*)(pp + c * 16), cs);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[c][j] = rbf((x[c][j] * rinv) * w[j]);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float cc = cs[2 * p], sn = cs[2 * p + 1];
+        y[2 * p] = rbf(rbf(cc * x[c][2 * p]) + rbf((-sn) * x[c][2 * p + 1]));
+        y[2 * p + 1] = rbf(rbf(sn * x[c][2 * p]) + rbf(cc * x[c][2 * p + 1]));
+      }
+      const uint4 pk = pack8(y);
+      qf[c] = __builtin_bit_cast(v8bf, pk);
+    }
   }
   // ---- LDS-DMA sources: one buffer descriptor per operand (head base, SGPRs), a fixed 32-bit per-lane offset and the tile offset
   // in an SGPR -> `buffer_load_dwordx4 v, s[rsrc], s_off offen lds`: no address arithmetic in the tile loop, and rows past L of a
@@ -310,12 +348,14 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_kernel(const AttnArgs a)
 
 int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
                        const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt,
-                       hipStream_t s) {
+                       hipStream_t s, const void* qraw, long long ldq, const void* pe, const void* qn0, const void* qn1) {
+  FLUXMI_REQUIRE(Q || (qraw && pe && qn0 && qn1 && ldq % 8 == 0), "attention: need Q, or raw q + pe + both q-norm scales (ld %% 8 == 0)");
   FLUXMI_REQUIRE(Lp % 64 == 0 && Lp >= L, "attention: Lp=%d must be a multiple of 64 and >= L=%d", Lp, L);
   FLUXMI_REQUIRE(!out_fp8 || (q_scale0 && q_scale1), "attention: fp8 output needs q_scale pointers");
   if (B * L * H == 0) return 0;
   AttnArgs a;
   a.Q = (const u16*)Q; a.K = (const u16*)K; a.VT = (const u16*)VT;
+  a.qraw = (const u16*)qraw; a.ldq = ldq; a.pe = (const u16*)pe; a.qn[0] = (const u16*)qn0; a.qn[1] = (const u16*)qn1;
   a.out = out; a.ld_out = ld_out; a.col_off = col_off; a.out_fp8 = out_fp8;
   a.q_scale[0] = q_scale0; a.q_scale[1] = q_scale1; a.split = split;
   a.B = B; a.L = L; a.Lp = Lp; a.H = H;

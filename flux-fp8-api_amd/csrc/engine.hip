@@ -430,12 +430,14 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
             gs.push_back(mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H, qkv + r0 * 3 * H, 3 * H, rows[st]));
           }
         FLUXMI_TRY(run_gemm(gs, 3 * H, H, e->lin[li_q[0]].kind, e->lin[li_q[0]].in_fmt, FLUXMI_EPI_BF16, s));
-        FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], Q, K, VT, B, L, e->Lp, heads, Lt, s));
+        // K and V^T are relaid out once (every query block re-reads them); Q is normalised + rotated inside the attention kernel
+        FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, Lt, s));
         if (fused) {
-          FLUXMI_TRY(fluxmi_k_attention(Q, K, VT, attn8, H, 0, 1, e->lin[li_p[0]].in_scale, e->lin[li_p[1]].in_scale, Lt, B, L, e->Lp,
-                                        heads, e->lin[li_p[0]].in_fmt, s));
+          FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attn8, H, 0, 1, e->lin[li_p[0]].in_scale, e->lin[li_p[1]].in_scale, Lt, B, L, e->Lp,
+                                        heads, e->lin[li_p[0]].in_fmt, s, qkv, 3 * H, pe, ns[2], ns[0]));
         } else {
-          FLUXMI_TRY(fluxmi_k_attention(Q, K, VT, attnbf, H, 0, 0, nullptr, nullptr, Lt, B, L, e->Lp, heads, 0, s));
+          FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attnbf, H, 0, 0, nullptr, nullptr, Lt, B, L, e->Lp, heads, 0, s, qkv, 3 * H, pe,
+                                        ns[2], ns[0]));
           for (int st = 0; st < 2; ++st)
             FLUXMI_TRY(stage_input(e, li_p[st], calib, trial, attnbf + (long long)roff[st] * H, H, XB, attn8 + (long long)roff[st] * H, H,
                                    XB, B, rows[st], H, s));
@@ -498,8 +500,9 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
       g.C2 = cat8; g.ldc2 = HC; g.split_n = 3 * H; g.c2_col0 = H; g.q_scale = L2.in_scale;
       gs.push_back(g);
       FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, 1, L2.in_fmt, FLUXMI_EPI_SPLIT, s));
-      FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], Q, K, VT, B, L, e->Lp, heads, L, s));
-      FLUXMI_TRY(fluxmi_k_attention(Q, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s));
+      FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, L, s));
+      FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s, qkv,
+                                    3 * H, pe, ns[0], ns[0]));
     } else {
       u16* lin1 = buf<u16>(e, "lin1");
       FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, ms, ms + H, ms, ms + H, MC, nullptr, nullptr, B, L, L, H, 0, 0, s));
@@ -507,8 +510,9 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
       std::vector<FluxmiGemmGroup> gs;
       gs.push_back(mk_group(L1, L1.kind ? (const void*)a8 : (const void*)abf, H, lin1, 3 * H + Hm, B * L));
       FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, L1.kind, L1.in_fmt, FLUXMI_EPI_BF16, s));
-      FLUXMI_TRY(fluxmi_k_qkv_rope(lin1, 3 * H + Hm, pe, ns[0], ns[1], ns[0], ns[1], Q, K, VT, B, L, e->Lp, heads, L, s));
-      FLUXMI_TRY(fluxmi_k_attention(Q, K, VT, catbf, HC, 0, 0, nullptr, nullptr, L, B, L, e->Lp, heads, 0, s));
+      FLUXMI_TRY(fluxmi_k_qkv_rope(lin1, 3 * H + Hm, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, L, s));
+      FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, catbf, HC, 0, 0, nullptr, nullptr, L, B, L, e->Lp, heads, 0, s, lin1, 3 * H + Hm, pe,
+                                    ns[0], ns[0]));
       FLUXMI_TRY(fluxmi_k_act(lin1 + 3 * H, catbf + H, B * L, Hm, 3 * H + Hm, HC, 0, s));
       FLUXMI_TRY(stage_input(e, l2, calib, trial, catbf, HC, 0, cat8, HC, 0, 1, B * L, HC, s));
     }

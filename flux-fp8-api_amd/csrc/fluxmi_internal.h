@@ -95,4 +95,6 @@ int fluxmi_k_qkv_rope(const void* qkv, long long ld, const void* pe, const void*
                       const void* q_scale1, const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H,
                       int split, hipStream_t s);
 int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
-                       const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, hipStream_t s);
+                       const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, hipStream_t s,
+                       const void* qraw = nullptr, long long ldq = 0, const void* pe = nullptr, const void* qn0 = nullptr,
+                       const void* qn1 = nullptr);

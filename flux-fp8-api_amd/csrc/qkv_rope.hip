@@ -8,7 +8,7 @@
 //   VT[B,H,128,Lp]                    V transposed; inside every 16-key group the key order is
 //                                      bit2<->bit3 swapped, which is exactly the k-slot order the PV
 //                                      MFMA of attention.hip consumes -> no transpose in the hot loop.
-// Rows l < split use norm-scale set 0 (txt stream), the rest set 1 (img stream).
+// Rows l < split use norm-scale set 0 (txt stream), the rest set 1 (img stream).  Q == nullptr: only K and V^T are produced.
 #include "common.h"
 #include "fluxmi_internal.h"
 
@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(256) qkv_rope_kernel(const QkvRopeArgs a) {
     unpack8(pev, cs);
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
+      if (part == 0 && a.Q == nullptr) continue;  // Q is normalised + rotated inside the attention kernel (raw-Q mode)
       float x[8], w[8];
       unpack8(*(const uint4*)(row + part * HD), x);
       unpack8(*(const uint4*)((part == 0 ? a.qs[st] : a.ks[st]) + sub * 8), w);

@@ -67,6 +67,7 @@ _SIGS = {
     "fluxmi_rope_table": ([vp, vp, vp, vp, i64, i32, i32, vp], i32),
     "fluxmi_qkv_rope": ([vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_attention": ([vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "fluxmi_attention_rawq": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_timestep_embedding": ([vp, vp, vp, i32, i32, f32, vp], i32),
     "fluxmi_euler": ([vp, vp, vp, vp, i64, vp], i32),
     "fluxmi_engine_num_linears": ([C.POINTER(ModelDesc)], i32),

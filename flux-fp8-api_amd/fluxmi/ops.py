@@ -201,15 +201,15 @@ def rope_table(ids: torch.Tensor, axes_dim, theta) -> torch.Tensor:
     return pe
 
 
-def qkv_rope(qkv, pe, q_scale0, k_scale0, q_scale1=None, k_scale1=None, split=None, heads=None):
-    """qkv bf16 [B,L,>=3*H*128] -> Q,K [B,H,L,128], VT [B,H,128,Lp]."""
+def qkv_rope(qkv, pe, q_scale0, k_scale0, q_scale1=None, k_scale1=None, split=None, heads=None, skip_q=False):
+    """qkv bf16 [B,L,>=3*H*128] -> Q,K [B,H,L,128], VT [B,H,128,Lp].  skip_q: only K and VT (Q is returned as None)."""
     B, L, _ = qkv.shape
     split = L if split is None else split
     q_scale1 = q_scale0 if q_scale1 is None else q_scale1
     k_scale1 = k_scale0 if k_scale1 is None else k_scale1
     Lp = (L + 63) // 64 * 64
-    Q = torch.empty((B, heads, L, 128), dtype=torch.bfloat16, device=qkv.device)
-    K = torch.empty_like(Q)
+    K = torch.empty((B, heads, L, 128), dtype=torch.bfloat16, device=qkv.device)
+    Q = None if skip_q else torch.empty_like(K)
     VT = torch.empty((B, heads, 128, Lp), dtype=torch.bfloat16, device=qkv.device)
     call("fluxmi_qkv_rope", _p(qkv), qkv.stride(1), _p(pe), _p(q_scale0), _p(k_scale0), _p(q_scale1), _p(k_scale1), _p(Q), _p(K),
          _p(VT), B, L, Lp, heads, split, _stream())
@@ -226,6 +226,21 @@ def attention(Q, K, VT, q_scale0=None, q_scale1=None, split=None, fmt=E5M2, out=
         out = torch.empty((B, L, H * 128), dtype=dtype_of(fmt) if out_fp8 else torch.bfloat16, device=Q.device)
     call("fluxmi_attention", _p(Q), _p(K), _p(VT), _p(out), out.stride(1), col_off, int(out_fp8), _p(q_scale0), _p(q_scale1), split,
          B, L, Lp, H, fmt, _stream())
+    return out
+
+
+def attention_rawq(qkv, pe, qn_scale0, K, VT, qn_scale1=None, q_scale0=None, q_scale1=None, split=None, fmt=E5M2, out=None, col_off=0):
+    """Attention with Q read raw from the qkv GEMM output [B,L,>=H*128] (QKNorm + RoPE applied on load); K, VT from qkv_rope."""
+    B, H, L, _ = K.shape
+    Lp = VT.shape[-1]
+    split = L if split is None else split
+    qn_scale1 = qn_scale0 if qn_scale1 is None else qn_scale1
+    out_fp8 = q_scale0 is not None
+    q_scale1 = q_scale0 if q_scale1 is None else q_scale1
+    if out is None:
+        out = torch.empty((B, L, H * 128), dtype=dtype_of(fmt) if out_fp8 else torch.bfloat16, device=K.device)
+    call("fluxmi_attention_rawq", _p(qkv), qkv.stride(1), _p(pe), _p(qn_scale0), _p(qn_scale1), _p(K), _p(VT), _p(out), out.stride(1),
+         col_off, int(out_fp8), _p(q_scale0), _p(q_scale1), split, B, L, Lp, H, fmt, _stream())
     return out
 
 

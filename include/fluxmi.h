@@ -112,13 +112,20 @@ int fluxmi_add(const void* a, const void* b, void* z, long long n, void* stream)
 /* pe[rows, pairs, (cos,sin)] from position ids                                    flux_model.py:49-57,82-92 */
 int fluxmi_rope_table(const void* ids, const float* omega, const int* axis, void* pe, long long rows, int n_axes, int pairs,
                       void* stream);
-/* qkv split + QKNorm + RoPE + head-major relayout (V transposed)                  flux_model.py:351-354,158-176,60-65,380-382 */
+/* qkv split + QKNorm + RoPE + head-major relayout (V transposed); Q may be NULL      flux_model.py:351-354,158-176,60-65,380-382 */
 int fluxmi_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0,
                     const void* q_scale1, const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H, int split,
                     void* stream);
 /* softmax(QK^T/sqrt(128))V -> [B,L,H*128] (bf16, or fp8 with the consumer's input scale)   flux_model.py:41-45 */
 int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
                      const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream);
+
+/* The same with Q taken RAW from the qkv GEMM output (q at column 0 of `qkv`, row stride ld_qkv): QKNorm (qn_scale0 for rows
+ * < split, qn_scale1 otherwise) + RoPE (pe) are applied while the query fragments are loaded, so Q never round-trips through HBM.
+ * Pair with fluxmi_qkv_rope(..., Q = NULL, ...) which then produces K and V^T only.     flux_model.py:41-45,60-65,158-176 */
+int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, const void* qn_scale0, const void* qn_scale1, const void* K,
+                          const void* VT, void* out, long long ld_out, int col_off, int out_fp8, const float* q_scale0,
+                          const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream);
 
 /* ---- step scalars -------------------------------------------------------------------------------------- */
 /* timestep_embedding(t, 2*half) with host-provided frequency table                 flux_model.py:95-116 */

@@ -378,6 +378,42 @@ def test_attention(ops, dev, B, H, L, Lt):
     assert torch.equal(deq, refq), f"fp8 attention output differs from quantise(bf16 output): {(deq != refq).float().mean().item()}"
 
 
+@pytest.mark.parametrize("L,Lt", [(320, 64), (200, 40)])
+def test_attention_rawq(ops, dev, L, Lt):
+    """Raw-Q mode: QKNorm + RoPE applied to the query rows inside the attention kernel == qkv_rope's Q followed by attention
+    (flux_model.py:158-176,60-65,41-45).  The row sum of squares is accumulated in a different order, so Q may differ by a rare
+    bf16 ulp: compare the attention outputs (and against the oracle path)."""
+    torch.manual_seed(9)
+    B, H = 2, 3
+    qkv = torch.randn(B, L, 3 * H * 128 + 64).bfloat16()
+    s = [(1 + 0.1 * torch.randn(128)).bfloat16() for _ in range(4)]  # txt q,k ; img q,k
+    img_ids = torch.zeros(B, L - Lt, 3, dtype=torch.bfloat16)
+    img_ids[..., 1] = (torch.arange(L - Lt) // 8).bfloat16()
+    img_ids[..., 2] = (torch.arange(L - Lt) % 8).bfloat16()
+    ids = torch.cat((torch.zeros(B, Lt, 3, dtype=torch.bfloat16), img_ids), 1)
+    pe6 = fo.rope_table(ids, [16, 56, 56], 10000, torch.bfloat16)
+    pe = torch.stack((pe6[:, 0, :, :, 0, 0], pe6[:, 0, :, :, 1, 0]), -1).contiguous()
+    d = lambda t: t.to(dev)
+    qkv_d = d(qkv)[..., : 3 * H * 128]
+    Q, K, VT = ops.qkv_rope(qkv_d, d(pe), d(s[0]), d(s[1]), d(s[2]), d(s[3]), split=Lt, heads=H)
+    ref = ops.attention(Q, K, VT)
+    Q2, K2, VT2 = ops.qkv_rope(qkv_d, d(pe), d(s[0]), d(s[1]), d(s[2]), d(s[3]), split=Lt, heads=H, skip_q=True)
+    assert Q2 is None and torch.equal(K2, K) and torch.equal(VT2, VT)
+    got = ops.attention_rawq(qkv_d, d(pe), d(s[0]), K2, VT2, qn_scale1=d(s[2]), split=Lt)
+    torch.cuda.synchronize()
+    diff = (got.float() - ref.float()).abs()
+    vmax = qkv[..., 2 * H * 128 : 3 * H * 128].abs().max().item()
+    assert diff.max().item() <= 1e-2 * vmax, f"raw-Q attention differs from two-kernel path: {diff.max().item()}"
+    assert (got == ref).float().mean().item() >= 0.98
+    # oracle: SDPA on the oracle's normalised + rotated q, k
+    q, k, v = fo.split_heads(qkv[..., : 3 * H * 128], H)
+    qn = torch.cat((fo.rms_norm(q[:, :, :Lt], s[0]), fo.rms_norm(q[:, :, Lt:], s[2])), 2)
+    kn = torch.cat((fo.rms_norm(k[:, :, :Lt], s[1]), fo.rms_norm(k[:, :, Lt:], s[3])), 2)
+    q_ref, k_ref = fo.apply_rope(qn, kn, pe6)
+    o_ref = fo.attention_fp64(q_ref, k_ref, v).transpose(1, 2).reshape(B, L, H * 128)
+    assert (got.double().cpu() - o_ref).abs().max().item() <= 2e-2 * vmax
+
+
 def test_lora_fuse(ops, dev):
     """Config 5: dequant + B@A + requant on device (lora_loading.py:509-577,615-631 -> float8_quantize.py:209-212)."""
     torch.manual_seed(12)
