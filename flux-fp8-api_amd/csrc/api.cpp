@@ -76,6 +76,21 @@ int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs_in, int n_in, int N, int K, i
   std::vector<FluxmiGemmGroup> gs(gs_in, gs_in + n_in);
   static int hybrid = -1;
   if (hybrid < 0) { const char* e = getenv("FLUXMI_GEMM_HYBRID"); hybrid = e ? atoi(e) : 1; }
+  bool fused_attn = false;
+  for (auto& g : gs) fused_attn |= (g.vt_out != nullptr || g.k_out != nullptr);
+  if (fused_attn) {
+    // the attention-layout epilogue lives in the LDS-transposed epilogue of the 256x256 kernels only
+    const bool long_k = (long long)K * (is_fp8 ? 1 : 2) >= 8192;
+    const int cfg = (long_k && fluxmi_gemm_tile_ok(N, K, is_fp8, 16)) ? 16 : 13;
+    FLUXMI_REQUIRE(fluxmi_gemm_tile_ok(N, K, is_fp8, cfg), "gemm: fused K / V^T outputs need N %% 256 == 0 and K*bytes %% 64 == 0 (N=%d K=%d)", N, K);
+    for (auto& g : gs)
+      FLUXMI_REQUIRE(g.heads > 0 && g.kv_col0 % 128 == 0 && g.tok0 % 16 == 0 && g.vt_rows % 8 == 0 && g.vt_ld % 8 == 0 &&
+                         (!g.k_out || (g.kv_col0 % 256 == 0 && (g.heads * 128) % 256 == 0 && g.pe && g.k_norm && g.k_rows > 0)),
+                     "gemm: fused K / V^T outputs need tok0 %% 16 == 0, vt_rows %% 8 == 0, vt_ld %% 8 == 0 (K: 256-aligned q|k|v blocks, pe, k_norm)");
+    for (size_t off = 0; off < gs.size(); off += FLUXMI_MAX_GROUPS)
+      FLUXMI_TRY(run_gemm_chunk(gs.data() + off, (int)std::min<size_t>(FLUXMI_MAX_GROUPS, gs.size() - off), N, K, is_fp8, act_fmt, epi, cfg, s));
+    return 0;
+  }
   if (hybrid && gs.size() >= 2 && gs.size() <= FLUXMI_MAX_GROUPS && getenv("FLUXMI_GEMM_CFG") == nullptr &&
       fluxmi_gemm_tile_ok(N, K, is_fp8, 13) && fluxmi_gemm_tile_ok(N, K, is_fp8, 2) &&
       (epi != FLUXMI_EPI_SPLIT || gs[0].split_n % 256 == 0)) {

@@ -80,6 +80,15 @@ static u16 host_f2bf(double v) {
   return (u16)(u >> 16);
 }
 
+// FLUXMI_FUSE_KV: 0 = K / V^T by the relayout kernel, 1 (default) = V^T from the qkv GEMM epilogue, 2 = K and V^T from the epilogue.
+// Measured in one process (profiles/r01_fuse_kv_ab.txt): 52.23 / 51.50 / 51.70 ms per step -- the transposed V store is free in
+// the epilogue, but K's norm + RoPE is VALU work that the GEMM's 8 waves do slower than the memory-bound relayout kernel.
+int fuse_kv_level() {
+  static int lvl = -1;
+  if (lvl < 0) { const char* e = getenv("FLUXMI_FUSE_KV"); lvl = e ? atoi(e) : 1; }
+  return lvl;
+}
+
 int lin_count(const fluxmi_model_desc_t& d) { return 6 + (d.guidance_embed ? 2 : 0) + d.depth * 10 + d.depth_single * 3 + 2; }
 
 // double-block linear slots / single-block linear slots
@@ -423,15 +432,27 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
       if (half == 0) {
         // qkv GEMM (both streams, all batch elements in one grouped launch)
         std::vector<FluxmiGemmGroup> gs;
+        // V^T leaves the qkv GEMM's epilogue directly in the attention kernel's layout when the 256x256 kernels apply
+        const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H, H, e->lin[li_q[0]].kind, 13) && Lt % 16 == 0;
+        const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;  // a 256-column tile must not straddle the q|k|v boundaries
         for (int b = 0; b < B; ++b)
           for (int st = 0; st < 2; ++st) {
             const fluxmi_linear_t& l = e->lin[li_q[st]];
             const long long r0 = (long long)b * L + roff[st];
-            gs.push_back(mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H, qkv + r0 * 3 * H, 3 * H, rows[st]));
+            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H, qkv + r0 * 3 * H, 3 * H, rows[st]);
+            if (fuse_v) {
+              g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = roff[st];
+              g.vt_rows = st == 0 ? Lt : e->Lp - Lt; g.kv_col0 = H; g.heads = heads;
+              if (fuse_k) {  // K: QKNorm (this stream's key scale) + RoPE in the epilogue as well -> no relayout kernel at all
+                g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[st == 0 ? 3 : 1];
+              }
+            }
+            gs.push_back(g);
           }
         FLUXMI_TRY(run_gemm(gs, 3 * H, H, e->lin[li_q[0]].kind, e->lin[li_q[0]].in_fmt, FLUXMI_EPI_BF16, s));
         // K and V^T are relaid out once (every query block re-reads them); Q is normalised + rotated inside the attention kernel
-        FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, Lt, s));
+        if (!fuse_k)
+          FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, Lt, s));
         if (fused) {
           FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attn8, H, 0, 1, e->lin[li_p[0]].in_scale, e->lin[li_p[1]].in_scale, Lt, B, L, e->Lp,
                                         heads, e->lin[li_p[0]].in_fmt, s, qkv, 3 * H, pe, ns[2], ns[0]));
@@ -496,11 +517,21 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
     if (fused) {
       FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, ms, ms + H, ms, ms + H, MC, L1.in_scale, L1.in_scale, B, L, L, H, 1, L1.in_fmt, s));
       std::vector<FluxmiGemmGroup> gs;
-      FluxmiGemmGroup g = mk_group(L1, a8, H, qkv, 3 * H, B * L);
-      g.C2 = cat8; g.ldc2 = HC; g.split_n = 3 * H; g.c2_col0 = H; g.q_scale = L2.in_scale;
-      gs.push_back(g);
+      const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H + Hm, H, 1, 13);
+      const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;
+      for (int b = 0; b < B; ++b) {  // one group per batch element: the fused V^T output is per sequence
+        const long long r0 = (long long)b * L;
+        FluxmiGemmGroup g = mk_group(L1, a8 + r0 * H, H, qkv + r0 * 3 * H, 3 * H, L);
+        g.C2 = cat8 + r0 * HC; g.ldc2 = HC; g.split_n = 3 * H; g.c2_col0 = H; g.q_scale = L2.in_scale;
+        if (fuse_v) {
+          g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = 0; g.vt_rows = e->Lp; g.kv_col0 = H; g.heads = heads;
+          if (fuse_k) { g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[1]; }
+        }
+        gs.push_back(g);
+      }
       FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, 1, L2.in_fmt, FLUXMI_EPI_SPLIT, s));
-      FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, L, s));
+      if (!fuse_k)
+        FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, L, s));
       FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s, qkv,
                                     3 * H, pe, ns[0], ns[0]));
     } else {

@@ -308,6 +308,9 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
   FLUXMI_REQUIRE(fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, cfg), "gemm: shape N=%d K=%d not tileable with cfg %d", p.N, p.K, cfg);
   if (p.epi == FLUXMI_EPI_SPLIT)
     FLUXMI_REQUIRE(p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0, "gemm: split_n=%d must be a multiple of the N tile", p.g[0].split_n);
+  for (int i = 0; i < p.n_groups; ++i)
+    if (p.g[i].vt_out || p.g[i].k_out)
+      FLUXMI_REQUIRE((cfg >= 11 && cfg <= 14) || cfg == 16, "gemm: fused K / V^T outputs exist only in tile configs 11-14 and 16 (got %d)", cfg);
   if (cfg == 16) return fluxmi_launch_gemm_w1(p, is_fp8, act_fmt, s);
   if (cfg >= 4 && cfg != 15) return fluxmi_launch_gemm_ring(p, is_fp8, act_fmt, cfg, s);
   if (is_fp8) {

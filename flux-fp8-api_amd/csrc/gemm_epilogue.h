@@ -133,11 +133,51 @@ __device__ __forceinline__ void row_epilogue(const FluxmiGemmGroup& G, float qs,
 
 template <int EPI, int FMT, int TM, int TN>
 __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&acc)[TM][TN], float s, float qs, unsigned char* wbuf,
-                                             int m_wave0, int n_wave0, int M, int lane) {
+                                             int m_wave0, int n_wave0, int M, int lane, float* xchg = nullptr, int wave = 0) {
   // phase 1: h = bf16(acc*s + bias) -> per-wave LDS tile [TM*32 rows][TN*32 cols] bf16, 16-B chunks XOR-swizzled by row
   constexpr int ROW_B = TN * 64;       // bytes per row (TN*32 bf16)
   constexpr int CH = ROW_B / 16;       // 16-B chunks per row
   const int l31 = lane & 31, hi = lane >> 5;
+  if constexpr (EPI == FLUXMI_EPI_BF16 || EPI == FLUXMI_EPI_SPLIT) {
+    // ---- fused V^T: this wave's tile is [128 keys][TN*32 d] of ONE head's V; it goes to LDS transposed ([d][128 keys], keys in
+    // the PV MFMA's k-slot order) and leaves as 256-byte runs of one d-row of vt_out                       (wave-uniform branch)
+    const int vcol0 = G.kv_col0 + G.heads * 128;
+    if (G.vt_out && n_wave0 >= vcol0 && n_wave0 < vcol0 + G.heads * 128) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int dl = j * 32 + g4 * 8 + hi * 4;  // local d of this lane's 4 values
+          float bias[4] = {0.f, 0.f, 0.f, 0.f};
+          if (G.bias) load_bf<4>(G.bias, n_wave0 + dl, bias);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int ml = i * 32 + l31;
+            // storage position of key ml: bits 2 and 3 swapped inside its 16-key group
+            const int pos = (ml & ~12) | ((ml & 4) << 1) | ((ml & 8) >> 1);
+            const bool live = m_wave0 + ml < M;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const u16 v = live ? f2bf(fmaf(acc[i][j][g4 * 4 + e], s, bias[e])) : (u16)0;
+              *(u16*)(wbuf + (dl + e) * (TM * 64) + pos * 2) = v;
+            }
+          }
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int KROW_B = TM * 64;        // bytes per d-row (TM*32 keys)
+      constexpr int KCH = KROW_B / 16;       // 16-B chunks (8 keys) per d-row
+      constexpr int DPP = 64 / KCH;          // d-rows per pass
+      const int d0 = n_wave0 - vcol0;        // first d-row of the tile in vt_out (= head*128 + d)
+#pragma unroll
+      for (int it = 0; it < (TN * 32) / DPP; ++it) {
+        const int dl = it * DPP + lane / KCH, c = lane % KCH;
+        const uint4 raw = *(const uint4*)(wbuf + dl * KROW_B + c * 16);
+        const int key = m_wave0 + c * 8;  // group-relative position of the 8 keys
+        if (key < G.vt_rows) *(uint4*)((u16*)G.vt_out + (long long)(d0 + dl) * G.vt_ld + G.tok0 + key) = raw;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -159,6 +199,66 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // phase 2: lane -> (row, 16-B chunk); 64 lanes cover (64/CH) rows x ROW_B bytes per pass
   constexpr int RPP = 64 / CH;  // rows per pass
+  if constexpr (EPI == FLUXMI_EPI_BF16 || EPI == FLUXMI_EPI_SPLIT) {
+    // ---- fused K: QKNorm (fp32 rms over the head's 128 columns, learnable scale) + RoPE (bf16 arithmetic) + head-major store.
+    // A 64-column wave tile holds half a head: the two waves of a head swap their per-row sums of squares through `xchg`
+    // (block-uniform branch: a 256-column tile lies entirely inside the K range).            flux_model.py:158-176,60-65
+    if (G.k_out && n_wave0 >= G.kv_col0 && n_wave0 < G.kv_col0 + G.heads * 128) {
+      constexpr int NP = (TM * 32) / RPP;
+      uint4 raw[NP];
+      float ssr[NP];
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int ml = it * RPP + lane / CH, c = lane % CH;
+        raw[it] = *(const uint4*)(wbuf + ml * ROW_B + ((c ^ (ml & (CH - 1))) * 16));
+        float x[8];
+        unpack8(raw[it], x);
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+#pragma unroll
+        for (int o = CH / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, CH);
+        ssr[it] = ss;
+      }
+      if constexpr (TN * 32 < 128) {
+        float* mine = xchg + wave * (TM * 32);
+#pragma unroll
+        for (int it = 0; it < NP; ++it)
+          if (lane % CH == 0) mine[it * RPP + lane / CH] = ssr[it];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const float* other = xchg + (wave ^ 1) * (TM * 32);
+#pragma unroll
+        for (int it = 0; it < NP; ++it) ssr[it] += other[it * RPP + lane / CH];
+      }
+      const int hcol = n_wave0 - G.kv_col0;           // column inside the K block of the row
+      const int head = hcol >> 7, d0 = hcol & 127;
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int ml = it * RPP + lane / CH, c = lane % CH;
+        const int m = m_wave0 + ml;
+        if (m < M) {
+          const int d = d0 + c * 8;
+          const long long tok = (long long)G.tok0 + m;
+          float x[8], w[8], cs[8], y[8];
+          unpack8(raw[it], x);
+          unpack8(*(const uint4*)((const u16*)G.k_norm + d), w);
+          unpack8(*(const uint4*)((const u16*)G.pe + (tok * 64 + (d >> 1)) * 2), cs);
+          const float rinv = 1.0f / sqrtf(ssr[it] * (1.0f / 128.0f) + 1e-6f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = rbf((x[j] * rinv) * w[j]);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float cc = cs[2 * p], sn = cs[2 * p + 1];
+            y[2 * p] = rbf(rbf(cc * x[2 * p]) + rbf((-sn) * x[2 * p + 1]));
+            y[2 * p + 1] = rbf(rbf(sn * x[2 * p]) + rbf(cc * x[2 * p + 1]));
+          }
+          *(uint4*)((u16*)G.k_out + ((long long)head * G.k_rows + tok) * 128 + d) = pack8(y);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int it = 0; it < (TM * 32) / RPP; ++it) {
     const int ml = it * RPP + lane / CH, c = lane % CH;

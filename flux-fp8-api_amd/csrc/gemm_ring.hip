@@ -382,12 +382,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
   unsigned char* wbuf = smem + wave * (WTM * WTN * 2);
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
   switch (P.epi) {
-    case FLUXMI_EPI_BF16: lds_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_GELU_QUANT: lds_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_GATE_RESID: lds_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_SPLIT: lds_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_QUANT: lds_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_SILU_QUANT: lds_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+    case FLUXMI_EPI_BF16: lds_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave); break;
+    case FLUXMI_EPI_GELU_QUANT: lds_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave); break;
+    case FLUXMI_EPI_GATE_RESID: lds_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave); break;
+    case FLUXMI_EPI_SPLIT: lds_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave); break;
+    case FLUXMI_EPI_QUANT: lds_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave); break;
+    case FLUXMI_EPI_SILU_QUANT: lds_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave); break;
     default: break;
   }
 }
@@ -402,7 +402,7 @@ int launch_pp(FluxmiGemmParams& p, hipStream_t s) {
   }
   p.tiles_m_total = t;
   p.group_m = 8;
-  constexpr int SMEM = 4 * (BM + BN) * 64;
+  constexpr int SMEM = 4 * (BM + BN) * 64 + 8 * 128 * 4;  // ring + the K-epilogue's row-sum exchange (8 waves x 128 rows)
   auto kern = gemm_pp_kernel<FP8, ACT, VAR>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -8,7 +8,7 @@
 //   VT[B,H,128,Lp]                    V transposed; inside every 16-key group the key order is
 //                                      bit2<->bit3 swapped, which is exactly the k-slot order the PV
 //                                      MFMA of attention.hip consumes -> no transpose in the hot loop.
-// Rows l < split use norm-scale set 0 (txt stream), the rest set 1 (img stream).  Q == nullptr: only K and V^T are produced.
+// Rows l < split use norm-scale set 0 (txt stream), the rest set 1 (img stream).  Q == nullptr / VT == nullptr: that output is skipped (produced elsewhere).
 #include "common.h"
 #include "fluxmi_internal.h"
 
@@ -64,10 +64,13 @@ __global__ void __launch_bounds__(256) qkv_rope_kernel(const QkvRopeArgs a) {
         *(uint4*)dst = pack8(y);
       }
     }
-    uint4 vv = *(const uint4*)(row + 2 * HD);
-    if (!ok) vv = make_uint4(0, 0, 0, 0);
-    *(uint4*)(&vt[r][sub * 8]) = vv;
+    if (a.VT) {
+      uint4 vv = *(const uint4*)(row + 2 * HD);
+      if (!ok) vv = make_uint4(0, 0, 0, 0);
+      *(uint4*)(&vt[r][sub * 8]) = vv;
+    }
   }
+  if (a.VT == nullptr) return;  // V^T was produced by the GEMM epilogue (fluxmi_gemm_group_t.vt_out)
   __syncthreads();
   // transposed, key-permuted write of V: item = (d, 8-position group)
 #pragma unroll

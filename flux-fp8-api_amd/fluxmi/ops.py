@@ -98,8 +98,11 @@ def lora_fuse_f8(w8: torch.Tensor, w_scale: torch.Tensor, w_scale_recip: torch.T
 
 # ---- linear ----------------------------------------------------------------------------------------
 def make_group(A, W, bias, sa_recip, sb_recip, Cout, M, lda, ldc, *, C2=None, ldc2=0, gate=None, resid=None, ldr=0,
-               q_scale=None, split_n=0, c2_col0=0) -> GemmGroup:
+               q_scale=None, split_n=0, c2_col0=0, vt_out=None, vt_ld=0, tok0=0, vt_rows=0, kv_col0=0, heads=0, k_out=None, pe=None,
+               k_norm=None, k_rows=0) -> GemmGroup:
     g = GemmGroup()
+    g.vt_out, g.k_out, g.pe, g.k_norm = vt_out, k_out, pe, k_norm
+    g.vt_ld, g.k_rows, g.tok0, g.vt_rows, g.kv_col0, g.heads = vt_ld, k_rows, tok0, vt_rows, kv_col0, heads
     g.A, g.W, g.bias, g.sa_recip, g.sb_recip = A, W, bias, sa_recip, sb_recip
     g.C, g.C2, g.gate, g.resid, g.q_scale = Cout, C2, gate, resid, q_scale
     g.lda, g.ldc, g.ldc2, g.ldr, g.M, g.split_n, g.c2_col0 = lda, ldc, ldc2, ldr, M, split_n, c2_col0

@@ -56,6 +56,19 @@ typedef struct fluxmi_gemm_group {
   int M;
   int m_tile_start;       /* internal, filled by the launcher */
   int split_n, c2_col0;
+  /* Optional fused attention-layout outputs (FLUXMI_EPI_BF16 / FLUXMI_EPI_SPLIT, 256x256 LDS-epilogue tile configs 13 and 16 only;
+   * all NULL / 0 = off).  The N columns are [q | k | v | ...] with heads*128 columns each (the qkv Linear of a DoubleStreamBlock,
+   * or the first 3*hidden columns of SingleStreamBlock.linear1).  V columns are written TRANSPOSED into vt_out
+   * [heads*128][vt_ld] (key position = tok0 + row, key order inside every 16-key group bit2<->bit3 swapped = the k-slot order of
+   * the attention kernel's PV MFMA; positions tok0+M .. tok0+vt_rows-1 are zero filled) instead of into C; K columns are
+   * RMS-normalised (k_norm), rotated (pe) and written to k_out [heads][k_rows][128] instead of into C.
+   * Replaces the V / K halves of fluxmi_qkv_rope.                       flux_model.py:351-354,158-176,60-65,380-382 */
+  void* vt_out;
+  void* k_out;
+  const void* pe;         /* (cos, sin) bf16 [k_rows][64][2] of this batch element */
+  const void* k_norm;     /* bf16 [128] */
+  long long vt_ld;
+  int k_rows, tok0, vt_rows, kv_col0, heads, _pad;
 } fluxmi_gemm_group_t;
 
 const char* fluxmi_last_error(void);

@@ -414,6 +414,51 @@ def test_attention_rawq(ops, dev, L, Lt):
     assert (got.double().cpu() - o_ref).abs().max().item() <= 2e-2 * vmax
 
 
+@pytest.mark.parametrize("cfg", [13, 16])
+def test_gemm_fused_kv_epilogue(ops, dev, cfg):
+    """The qkv GEMM writing K (QKNorm + RoPE) and V^T (transposed, k-slot key order) straight from its epilogue
+    (fluxmi_gemm_group_t.k_out / vt_out) == the plain GEMM followed by fluxmi_qkv_rope, two streams (txt rows, img rows)."""
+    from fluxmi import _lib
+
+    torch.manual_seed(12)
+    Hh, Lt, Li, K = 2, 48, 272, 256     # heads, txt rows, img rows, in features
+    HD, L = Hh * 128, Lt + Li
+    Lp = (L + 63) // 64 * 64
+    d = lambda t: t.to(dev)
+    ws, bs, a8s = [], [], []
+    sar = None
+    for M, seed in ((Lt, 1), (Li, 2)):
+        a8, w8, sar, sbr, bias = make_f8_problem(M, 3 * HD, K, E5M2, seed=seed)
+        a8s.append(d(a8)); ws.append((d(w8), d(sbr))); bs.append(d(bias))
+    sar = d(sar)
+    s = [d((1 + 0.1 * torch.randn(128)).bfloat16()) for _ in range(4)]  # txt q,k ; img q,k
+    ids = torch.zeros(1, L, 3, dtype=torch.bfloat16)
+    ids[0, Lt:, 1] = (torch.arange(Li) // 16).bfloat16()
+    ids[0, Lt:, 2] = (torch.arange(Li) % 16).bfloat16()
+    pe6 = fo.rope_table(ids, [16, 56, 56], 10000, torch.bfloat16)
+    pe = d(torch.stack((pe6[:, 0, :, :, 0, 0], pe6[:, 0, :, :, 1, 0]), -1).contiguous())
+    # reference path: plain GEMM -> qkv buffer -> relayout kernel
+    qkv = torch.zeros(1, L, 3 * HD, dtype=torch.bfloat16, device=dev)
+    for st, (r0, M) in enumerate(((0, Lt), (Lt, Li))):
+        ops.linear(a8s[st], ws[st][0], bs[st], sar, ws[st][1], out=qkv[0, r0 : r0 + M], tile_cfg=cfg)
+    _, K_ref, VT_ref = ops.qkv_rope(qkv, pe, s[0], s[1], s[2], s[3], split=Lt, heads=Hh, skip_q=True)
+    # fused path: one grouped launch, two groups
+    qkv2 = torch.zeros_like(qkv)
+    K_out = torch.zeros(1, Hh, L, 128, dtype=torch.bfloat16, device=dev)
+    VT_out = torch.zeros(1, Hh, 128, Lp, dtype=torch.bfloat16, device=dev)
+    groups = []
+    for st, (r0, M) in enumerate(((0, Lt), (Lt, Li))):
+        groups.append(ops.make_group(a8s[st].data_ptr(), ws[st][0].data_ptr(), bs[st].data_ptr(), sar.data_ptr(), ws[st][1].data_ptr(),
+                                     qkv2[0, r0:].data_ptr(), M, K, 3 * HD, vt_out=VT_out.data_ptr(), vt_ld=Lp, tok0=r0,
+                                     vt_rows=Lt if st == 0 else Lp - Lt, kv_col0=HD, heads=Hh, k_out=K_out.data_ptr(), pe=pe.data_ptr(),
+                                     k_norm=s[1 if st == 0 else 3].data_ptr(), k_rows=L))
+    ops.gemm_grouped(groups, 3 * HD, K, True, E5M2, _lib.EPI_BF16, cfg)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv2[..., :HD], qkv[..., :HD])            # q columns still go to C
+    assert torch.equal(VT_out, VT_ref)                            # V^T: same bf16 values, same layout, zero padded
+    assert_bf16_close(K_out, K_ref, max_ulp=1, min_exact=0.999, what="fused K")  # row sums of squares in another order
+
+
 def test_lora_fuse(ops, dev):
     """Config 5: dequant + B@A + requant on device (lora_loading.py:509-577,615-631 -> float8_quantize.py:209-212)."""
     torch.manual_seed(12)
