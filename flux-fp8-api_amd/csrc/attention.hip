@@ -220,6 +220,8 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_kernel(const AttnArgs a)
   if (n_issued == (2 * RD - 1) * LPW) wait_vm<(2 * RD - 2) * LPW>();
   else wait_vm<0>();
   __builtin_amdgcn_s_barrier();
+  // FLUXMI_ATTN_ABL & 4: static priority for the second-dispatched half of the workgroup (it loses VALU arbitration by age otherwise)
+  if ((a.abl & 4) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   v16f sa[2], sb[2];
   qk(0, sa);
   if (ragged && ntiles == 1) mask_tile(sa, 0);

@@ -296,7 +296,11 @@ int fluxmi_gemm_tile_bn(int cfg) { return (cfg >= 0 && cfg < FLUXMI_N_CFG) ? kTi
 int fluxmi_gemm_tile_bm(int cfg) { return (cfg >= 0 && cfg < FLUXMI_N_CFG) ? kTileBM[cfg] : 0; }
 
 int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg) {
+#ifdef FLUXMI_EXPERIMENTS
   if (cfg >= 20 && cfg < 36) cfg = 4;  // ablation variants of the 256x256 ring
+#else
+  if (cfg == 7 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 12 || cfg == 14) return 0;  // experimental variants, not built
+#endif
   if (cfg < 0 || cfg >= FLUXMI_N_CFG) return 0;
   const int kb = K * (is_fp8 ? 1 : 2);
   const int kstep = cfg == 16 ? 256 : (cfg >= 4 && cfg != 15) ? 64 : 128;
@@ -310,7 +314,7 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
     FLUXMI_REQUIRE(p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0, "gemm: split_n=%d must be a multiple of the N tile", p.g[0].split_n);
   for (int i = 0; i < p.n_groups; ++i)
     if (p.g[i].vt_out || p.g[i].k_out)
-      FLUXMI_REQUIRE((cfg >= 11 && cfg <= 14) || cfg == 16, "gemm: fused K / V^T outputs exist only in tile configs 11-14 and 16 (got %d)", cfg);
+      FLUXMI_REQUIRE((cfg >= 11 && cfg <= 14) || cfg == 16, "gemm: fused K / V^T outputs exist only in tile configs 13 and 16 (got %d)", cfg);
   if (cfg == 16) return fluxmi_launch_gemm_w1(p, is_fp8, act_fmt, s);
   if (cfg >= 4 && cfg != 15) return fluxmi_launch_gemm_ring(p, is_fp8, act_fmt, cfg, s);
   if (is_fp8) {

@@ -445,18 +445,21 @@ int launch_ring_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
     case 4: return launch_ring<256, 256, 2, 4, 4, false, FP8, ACT>(p, s);
     case 5: return launch_ring<256, 128, 4, 2, 4, false, FP8, ACT>(p, s);
     case 6: return launch_ring<128, 128, 2, 2, 4, false, FP8, ACT>(p, s);
-    case 7: return launch_ring<256, 256, 2, 4, 4, true, FP8, ACT>(p, s);
     case 8: return launch_ring<256, 128, 2, 2, 3, true, FP8, ACT>(p, s);   // 72 KiB LDS, 4 waves: 2 blocks per CU
+    case 13: return launch_pp<FP8, ACT, 2>(p, s);
+#ifdef FLUXMI_EXPERIMENTS  // variants measured and rejected in round 1 (profiles/r01_gemm_ablation*.txt); not built by default
+    case 7: return launch_ring<256, 256, 2, 4, 4, true, FP8, ACT>(p, s);
     case 9: return launch_ring<128, 256, 2, 2, 3, true, FP8, ACT>(p, s);
     case 10: return launch_ring<256, 128, 2, 2, 3, false, FP8, ACT>(p, s);
     case 11: return launch_pp<FP8, ACT, 0>(p, s);
     case 12: return launch_pp<FP8, ACT, 1>(p, s);
-    case 13: return launch_pp<FP8, ACT, 2>(p, s);
     case 14: return launch_pp<FP8, ACT, 3>(p, s);
+#endif
     default: break;
   }
   // timing-only ablations of the 256x256 ring (tools/gemm_probe.py): cfg = 20 + mask, 1 = no LDS-DMA refill, 2 = no LDS reads,
   // 4 = no barrier, 8 = no vmcnt wait.  Results are wrong by construction.
+#ifdef FLUXMI_EXPERIMENTS
   if constexpr (FP8 && ACT == FLUXMI_FMT_E5M2) {
     switch (cfg) {
 #define ABL_CASE(m) case 20 + m: return launch_ring<256, 256, 2, 4, 4, false, FP8, ACT, m>(p, s);
@@ -465,6 +468,7 @@ int launch_ring_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
       default: break;
     }
   }
+#endif
   switch (cfg) {
     default: fluxmi_set_error("gemm_ring: unknown tile config %d", cfg); return 1;
   }

@@ -225,6 +225,7 @@ int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStrea
                    "gemm_w1: operand larger than 4 GiB");
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) {
+#ifdef FLUXMI_EXPERIMENTS
       static int abl = -1;  // FLUXMI_GEMM_ABL: timing-only ablations for tools/gemm_probe.py
       if (abl < 0) { const char* e = getenv("FLUXMI_GEMM_ABL"); abl = e ? atoi(e) : 0; }
       switch (abl) {
@@ -235,6 +236,7 @@ int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStrea
         case 7: return launch_w1<true, FLUXMI_FMT_E5M2, 7>(p, s);
         default: break;
       }
+#endif
       return launch_w1<true, FLUXMI_FMT_E5M2>(p, s);
     }
     return launch_w1<true, FLUXMI_FMT_E4M3>(p, s);
