@@ -260,7 +260,7 @@ def main():
                 "vs_h100_compiled": round(its / world / H100_COMPILED_ITS, 3),
                 "fp8_mfma_fraction_whole_step": round(lin_flops / (ms_per_step * 1e-3) / (FP8_PEAK_TFLOPS * 1e12), 4),
                 "setup_s": round(setup_s, 1),
-                "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel<fp8 MX-MFMA 32x32x64, 256x256 ping-pong ring> (the 152 grouped "
+                "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_w1_kernel <fp8 MX-MFMA 32x32x64, 256x256 tiles> (the 152 grouped "
                                                             "F8Linear GEMM launches of a step, fused epilogues included)",
                              "achieved": round(achieved, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / FP8_PEAK_TFLOPS, 4), "traffic": gemm_traffic_bytes(),

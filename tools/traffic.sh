@@ -21,7 +21,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     calib_end = max([int(r["End_Timestamp"]) for r in rows if "amax_kernel" in r["Kernel_Name"] or "calib_update" in r["Kernel_Name"]] or [0])
     eul = [int(r["End_Timestamp"]) for r in rows if "euler_kernel" in r["Kernel_Name"] and int(r["Start_Timestamp"]) > calib_end]
     t1 = eul[-1]
-    ids = {r["Dispatch_Id"] for r in rows if "gemm_pp_kernel" in r["Kernel_Name"] and calib_end < int(r["Start_Timestamp"]) < t1}
+    ids = {r["Dispatch_Id"] for r in rows if ("gemm_pp_kernel" in r["Kernel_Name"] or "gemm_w1_kernel" in r["Kernel_Name"]) and calib_end < int(r["Start_Timestamp"]) < t1}
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(cc[0])) if r["Dispatch_Id"] in ids and r["Counter_Name"] == C]
     res[C] = {"launches": len(vals), "mean_raw": sum(vals) / max(1, len(vals))}
     print(C, res[C])
