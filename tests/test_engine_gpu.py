@@ -114,6 +114,40 @@ def test_forward_matches_oracle_through_calibration(dev, qname, shape):
     print(f"[{qname} {shape}] worst rel-L2 over 15 calls: {worst:.3e}")
 
 
+def test_full_width_blocks_match_oracle(dev):
+    """Flux-dev's real widths (hidden 3072 = 24 heads x 128, mlp 12288, single-block K = 15360) on 1 + 1 blocks: exercises the
+    production tile configs (ping-pong for K = 3072, one-wave-per-SIMD for K >= 8192), the fused V^T epilogue with 24 heads, the
+    raw-Q attention and the modulation GEMM at the shapes of BASELINE.json configs[1]; sequence kept short for the CPU oracle."""
+    import util
+    from fluxmi import synth
+
+    cfg = util.load_config(util.ModelVersion.flux_dev, flow_dtype="bfloat16")
+    p = cfg.params
+    p.depth, p.depth_single_blocks = 1, 1
+    quant = QUANTS["fp8"]
+    model, oracle, _ = build(cfg, quant, dev, seed=1)
+    H, W, Lt, B = 256, 256, 64, 1   # Li = 256, L = 320
+    inp = synth.make_inputs(p, H, W, Lt, batch=B, seed=4, real_tokens=16)
+    dinp = to_dev(inp, dev)
+    g = torch.full((B,), 3.5, dtype=torch.bfloat16)
+    worst = 0.0
+    for step in range(15):
+        t = torch.full((B,), 1.0 - 0.05 * step, dtype=torch.bfloat16)
+        ref = oracle.forward(inp["img"], inp["img_ids"], inp["txt"], inp["txt_ids"], t, inp["y"], g)
+        got = model(dinp["img"], dinp["img_ids"], dinp["txt"], dinp["txt_ids"], t.to(dev), dinp["y"], g.to(dev))
+        assert torch.isfinite(got).all()
+        e = rel_l2(got, ref)
+        worst = max(worst, e)
+        assert e <= 6e-2, f"full-width call {step}: rel-L2 vs fp8 oracle {e:.3e}"
+    assert model.calibration_state()[0]
+    # fused (mode 1) == unfused-frozen (mode 2) at these widths too
+    t = torch.full((B,), 0.3, dtype=torch.bfloat16, device=dev)
+    args = (dinp["img"], dinp["img_ids"], dinp["txt"], dinp["txt_ids"], t, dinp["y"], g.to(dev))
+    a, b = model(*args, mode=1), model(*args, mode=2)
+    assert rel_l2(a, b) <= 2e-3
+    print(f"[full width] worst rel-L2 over 15 calls: {worst:.3e}; fused vs unfused rel-L2 {rel_l2(a, b):.3e}")
+
+
 def test_fused_equals_unfused_and_graph_equals_eager(dev):
     from fluxmi import synth
 
