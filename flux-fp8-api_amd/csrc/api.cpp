@@ -232,6 +232,9 @@ int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, lo
                      const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream) {
   return fluxmi_k_attention(Q, K, VT, out, ld_out, col_off, out_fp8, q_scale0, q_scale1, split, B, L, Lp, H, fmt, (hipStream_t)stream);
 }
+int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void* stream) {
+  return fluxmi_k_build_qlut(scale, fmt, act, lut, (hipStream_t)stream);
+}
 int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, const void* qn_scale0, const void* qn_scale1, const void* K,
                           const void* VT, void* out, long long ld_out, int col_off, int out_fp8, const float* q_scale0,
                           const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream) {

@@ -293,6 +293,16 @@ __global__ void __launch_bounds__(256) select_step_kernel(const uint4* __restric
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// lut[b] = fp8( clamp( bf16( bf16(act(bf16 b)) * scale ) ) ) for all 65536 bf16 bit patterns b: the quantising GEMM epilogues as a
+// table (same helpers as gemm_epilogue.h -> bit-identical).  act: 0 none, 1 gelu-tanh, 2 silu.
+template <int FMT>
+__global__ void __launch_bounds__(256) build_qlut_kernel(const float* __restrict__ scale, int act, unsigned char* __restrict__ lut) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float h = bf2f((u16)i);
+  const float g = act == 1 ? rbf(gelu_tanh_f(h)) : act == 2 ? rbf(silu_f(h)) : h;
+  lut[i] = (unsigned char)(cvt2_fp8<FMT>(q_prepare<FMT>(g, *scale), 0.f) & 0xff);
+}
+
 // ---------------------------------------------------------------------------------------------
 // sinusoidal timestep embedding                                           flux_model.py:95-116
 //   t' = bf16(1000 * t);  out[b, i] = bf16(cos(t' * f_i)),  out[b, half+i] = bf16(sin(t' * f_i))
@@ -514,6 +524,13 @@ int fluxmi_k_add(const void* a, const void* b, void* z, long long n, hipStream_t
   return 0;
 }
 
+int fluxmi_k_build_qlut(const float* scale, int fmt, int act, void* lut, hipStream_t s) {
+  FLUXMI_REQUIRE(scale && lut && act >= 0 && act <= 2, "build_quant_lut: bad arguments");
+  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL(build_qlut_kernel<FLUXMI_FMT_E5M2>, dim3(256), dim3(256), 0, s, scale, act, (unsigned char*)lut);
+  else hipLaunchKernelGGL(build_qlut_kernel<FLUXMI_FMT_E4M3>, dim3(256), dim3(256), 0, s, scale, act, (unsigned char*)lut);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
 int fluxmi_k_add_bcast(const void* a, const void* b, void* z, long long rows, int nb, int cols, hipStream_t s) {
   FLUXMI_REQUIRE(cols % 8 == 0 && nb >= 1, "add_bcast: cols must be a multiple of 8");
   if (rows * cols == 0) return 0;

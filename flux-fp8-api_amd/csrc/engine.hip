@@ -360,6 +360,31 @@ int precompute_mods(E* e, const std::vector<float>& ts, int step0, int n_steps, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Quantising-epilogue tables (frozen scales): one 64 KiB bf16 -> fp8 table per GELU -> F8Linear hand-off (double-block mlp.0 -> mlp.2
+// per stream, single-block linear1 -> linear2), see fluxmi_gemm_group_t.q_lut.  Rebuilt (77 tiny launches) whenever a fused
+// sequence starts, so they always reflect the current input scales.  FLUXMI_QLUT=0 turns them off.
+// ---------------------------------------------------------------------------------------------------------
+bool qlut_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("FLUXMI_QLUT"); on = e ? atoi(e) : 1; }
+  return on != 0;
+}
+int build_qluts(E* e, hipStream_t s) {
+  uint8_t* lut = buf<uint8_t>(e, "qlut");
+  if (!lut || !qlut_enabled()) return 0;
+  for (int i = 0; i < e->d.depth; ++i)
+    for (int st = 0; st < 2; ++st) {
+      const fluxmi_linear_t& l = e->lin[DLi(e, i, st == 0 ? D_TXT_MLP2 : D_IMG_MLP2)];
+      if (l.kind) FLUXMI_TRY(fluxmi_k_build_qlut(l.in_scale, l.in_fmt, 1, lut + (size_t)(i * 2 + st) * 65536, s));
+    }
+  for (int i = 0; i < e->d.depth_single; ++i) {
+    const fluxmi_linear_t& l = SL(e, i, S_LIN2);
+    if (l.kind) FLUXMI_TRY(fluxmi_k_build_qlut(l.in_scale, l.in_fmt, 1, lut + (size_t)(e->d.depth * 2 + i) * 65536, s));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* t_vec, const u16* g_vec, u16* pred, int mode,
                  int trial, bool txt_cached, hipStream_t s) {
   const int H = e->d.hidden, Hm = e->d.mlp_hidden, B = e->B, L = e->L, Lt = e->Lt, Li = e->Li, heads = e->d.heads;
@@ -484,6 +509,7 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
             FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H,
                                          fused ? (void*)(h8 + r0 * Hm) : (void*)(hbf + r0 * Hm), Hm, rows[st]);
             g.q_scale = e->lin[li_m2[st]].in_scale;
+            if (fused && qlut_enabled()) g.q_lut = buf<uint8_t>(e, "qlut") + (size_t)(i * 2 + st) * 65536;
             gs.push_back(g);
           }
         FLUXMI_TRY(run_gemm(gs, Hm, H, e->lin[li_m0[0]].kind, e->lin[li_m2[0]].in_fmt, fused ? FLUXMI_EPI_GELU_QUANT : FLUXMI_EPI_BF16, s));
@@ -523,6 +549,7 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
         const long long r0 = (long long)b * L;
         FluxmiGemmGroup g = mk_group(L1, a8 + r0 * H, H, qkv + r0 * 3 * H, 3 * H, L);
         g.C2 = cat8 + r0 * HC; g.ldc2 = HC; g.split_n = 3 * H; g.c2_col0 = H; g.q_scale = L2.in_scale;
+        if (qlut_enabled()) g.q_lut = buf<uint8_t>(e, "qlut") + (size_t)(e->d.depth * 2 + i) * 65536;
         if (fuse_v) {
           g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = 0; g.vt_rows = e->Lp; g.kv_col0 = H; g.heads = heads;
           if (fuse_k) { g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[1]; }
@@ -675,6 +702,7 @@ int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void*
         {"vec", (size_t)B * H * 2}, {"svec", (size_t)B * H * 2}, {"temb", (size_t)B * 256 * 2}, {"emb_h", (size_t)B * H * 2},
         {"emb_s", (size_t)B * std::max(H, 1024) * 2}, {"vec_t", (size_t)B * H * 2}, {"vec_g", (size_t)B * H * 2}, {"vec_y", (size_t)B * H * 2},
         {"tvec", 256}, {"gvec", 256}, {"ids", BL * 3 * 2},
+        {"qlut", (size_t)(e->d.depth * 2 + e->d.depth_single) * 65536},
         {"mods_a8", (size_t)FLUXMI_MAX_GROUPS * (((size_t)B * std::max(H, 4096) + 255) & ~(size_t)255)},
         // static request buffers (make the captured graph independent of caller pointers)
         {"img_s", (size_t)B * Li * e->d.in_channels * 2}, {"txt_s", (size_t)B * Lt * e->d.ctx_in * 2}, {"y_s", (size_t)B * e->d.vec_in * 2},
@@ -711,6 +739,7 @@ int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, 
   FLUXMI_REQUIRE(img && txt && y && timesteps && pred, "engine_forward: NULL tensor");
   FLUXMI_REQUIRE(mode >= 0 && mode <= 2, "engine_forward: bad mode %d", mode);
   if (mode == 0) FLUXMI_REQUIRE(trial_index >= 0 && trial_index <= e->d.num_trials, "engine_forward: trial_index %d out of range", trial_index);
+  if (mode == 1) FLUXMI_TRY(build_qluts(e, (hipStream_t)stream));
   return forward_impl(e, (const u16*)img, (const u16*)txt, (const u16*)y, (const u16*)timesteps, (const u16*)guidance, (u16*)pred,
                       mode, trial_index, false, (hipStream_t)stream);
 }
@@ -770,6 +799,7 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
     }
     // modulation table for steps [step, n_steps); a captured graph stays valid as long as the table does not move and
     // starts at the same step index
+    if (mode == 1) FLUXMI_TRY(build_qluts(e, s));
     const int old_step0 = e->mods_step0;
     FLUXMI_TRY(precompute_mods(e, ts, step, n_steps, g_arg, y_s, s));
     if (old_step0 != e->mods_step0) e->graph_ok = false;

@@ -84,6 +84,7 @@ int fluxmi_k_act(const void* x, void* y, int rows, int cols, long long ld_in, lo
 int fluxmi_k_gate_residual(const void* x, const void* y, const void* gate, void* out, int B, int L, int H, long long ldx,
                            long long ldy, long long ldo, long long gate_bstride, hipStream_t s);
 int fluxmi_k_add(const void* a, const void* b, void* z, long long n, hipStream_t s);
+int fluxmi_k_build_qlut(const float* scale, int fmt, int act, void* lut, hipStream_t s);
 int fluxmi_k_add_bcast(const void* a, const void* b, void* z, long long rows, int nb, int cols, hipStream_t s);
 int fluxmi_k_select_step(const void* table, const int* step, int step0, void* dst, long long bytes, hipStream_t s);
 int fluxmi_k_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, hipStream_t s);

@@ -33,6 +33,7 @@ class GemmGroup(C.Structure):
         ("M", i32), ("m_tile_start", i32), ("split_n", i32), ("c2_col0", i32),
         ("vt_out", vp), ("k_out", vp), ("pe", vp), ("k_norm", vp), ("vt_ld", i64),
         ("k_rows", i32), ("tok0", i32), ("vt_rows", i32), ("kv_col0", i32), ("heads", i32), ("_pad", i32),
+        ("q_lut", vp),
     ]
 
 
@@ -68,6 +69,7 @@ _SIGS = {
     "fluxmi_add": ([vp, vp, vp, i64, vp], i32),
     "fluxmi_rope_table": ([vp, vp, vp, vp, i64, i32, i32, vp], i32),
     "fluxmi_qkv_rope": ([vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "fluxmi_build_quant_lut": ([vp, i32, i32, vp, vp], i32),
     "fluxmi_attention": ([vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_attention_rawq": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_timestep_embedding": ([vp, vp, vp, i32, i32, f32, vp], i32),

@@ -99,8 +99,9 @@ def lora_fuse_f8(w8: torch.Tensor, w_scale: torch.Tensor, w_scale_recip: torch.T
 # ---- linear ----------------------------------------------------------------------------------------
 def make_group(A, W, bias, sa_recip, sb_recip, Cout, M, lda, ldc, *, C2=None, ldc2=0, gate=None, resid=None, ldr=0,
                q_scale=None, split_n=0, c2_col0=0, vt_out=None, vt_ld=0, tok0=0, vt_rows=0, kv_col0=0, heads=0, k_out=None, pe=None,
-               k_norm=None, k_rows=0) -> GemmGroup:
+               k_norm=None, k_rows=0, q_lut=None) -> GemmGroup:
     g = GemmGroup()
+    g.q_lut = q_lut
     g.vt_out, g.k_out, g.pe, g.k_norm = vt_out, k_out, pe, k_norm
     g.vt_ld, g.k_rows, g.tok0, g.vt_rows, g.kv_col0, g.heads = vt_ld, k_rows, tok0, vt_rows, kv_col0, heads
     g.A, g.W, g.bias, g.sa_recip, g.sb_recip = A, W, bias, sa_recip, sb_recip
@@ -114,8 +115,15 @@ def gemm_grouped(groups: Sequence[GemmGroup], N: int, K: int, is_fp8: bool, act_
     call("fluxmi_gemm_grouped", arr, len(groups), N, K, int(is_fp8), act_fmt, epilogue, tile_cfg, _stream())
 
 
+def build_quant_lut(scale: torch.Tensor, fmt: int = E5M2, act: int = 1) -> torch.Tensor:
+    """64 KiB table bf16 bit pattern -> fp8 byte of quantise(act(x)) (act: 0 none, 1 gelu-tanh, 2 silu) for a frozen input scale."""
+    lut = torch.empty(65536, dtype=torch.uint8, device=scale.device)
+    call("fluxmi_build_quant_lut", _p(scale), fmt, act, _p(lut), _stream())
+    return lut
+
+
 def linear(x, W, bias=None, sa_recip=None, sb_recip=None, *, epilogue=_lib.EPI_BF16, gate=None, resid=None, q_scale=None,
-           out=None, out2=None, split_n=0, c2_col0=0, tile_cfg=-1, out_fmt=E5M2):
+           out=None, out2=None, split_n=0, c2_col0=0, tile_cfg=-1, out_fmt=E5M2, q_lut=None):
     """One (F8)Linear: x [M,K] fp8 or bf16, W [N,K].  Returns the primary output tensor."""
     is_fp8 = W.dtype in F8_DTYPES
     M, K = x.shape
@@ -127,7 +135,7 @@ def linear(x, W, bias=None, sa_recip=None, sb_recip=None, *, epilogue=_lib.EPI_B
         out = torch.empty((M, n_primary), dtype=dtype_of(act_fmt) if fp8_out else torch.bfloat16, device=x.device)
     g = make_group(_p(x), _p(W), _p(bias), _p(sa_recip), _p(sb_recip), _p(out), M, x.stride(0), out.stride(0),
                    C2=_p(out2), ldc2=out2.stride(0) if out2 is not None else 0, gate=_p(gate), resid=_p(resid),
-                   ldr=resid.stride(0) if resid is not None else 0, q_scale=_p(q_scale), split_n=split_n, c2_col0=c2_col0)
+                   ldr=resid.stride(0) if resid is not None else 0, q_scale=_p(q_scale), split_n=split_n, c2_col0=c2_col0, q_lut=_p(q_lut))
     gemm_grouped([g], N, K, is_fp8, act_fmt, epilogue, tile_cfg)
     return out
 

@@ -69,6 +69,12 @@ typedef struct fluxmi_gemm_group {
   const void* k_norm;     /* bf16 [128] */
   long long vt_ld;
   int k_rows, tok0, vt_rows, kv_col0, heads, _pad;
+  /* Optional 64 KiB table for the quantising epilogues (FLUXMI_EPI_GELU_QUANT and the mlp columns of FLUXMI_EPI_SPLIT, tile config
+   * 13): q_lut[b] = the fp8 byte the epilogue would compute for the bf16 GEMM output with bit pattern b -- bf16 -> GELU -> bf16 ->
+   * x input_scale -> bf16 -> clamp -> fp8 is a pure function of those 16 bits once the scale is frozen.  Built by
+   * fluxmi_build_quant_lut with the same device code, so results are bit-identical; it replaces ~25 VALU instructions per element
+   * by one LDS gather while the matrix pipe is idle.  NULL = compute.        flux_model.py:301,480 + float8_quantize.py:217-218,274-276 */
+  const void* q_lut;
 } fluxmi_gemm_group_t;
 
 const char* fluxmi_last_error(void);
@@ -120,6 +126,10 @@ int fluxmi_act(const void* x, void* y, int rows, int cols, long long ld_in, long
 int fluxmi_gate_residual(const void* x, const void* y, const void* gate, void* out, int B, int L, int H, long long ldx,
                          long long ldy, long long ldo, long long gate_bstride, void* stream);
 int fluxmi_add(const void* a, const void* b, void* z, long long n, void* stream);
+
+/* lut[b] for every bf16 bit pattern b: the fp8 byte of  to_fp8_saturated(act(bf16 b), *scale)  (act: 0 none, 1 gelu-tanh, 2 silu),
+ * rounded at the same points as the fused epilogues.  65536 bytes.                      float8_quantize.py:217-218 */
+int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void* stream);
 
 /* ---- attention path --------------------------------------------------------------------------------- */
 /* pe[rows, pairs, (cos,sin)] from position ids                                    flux_model.py:49-57,82-92 */

@@ -57,7 +57,7 @@ def test_errors_are_returned_not_thrown():
 def test_struct_layouts_match_the_header():
     from fluxmi import _lib
 
-    assert C.sizeof(_lib.GemmGroup) == 10 * 8 + 4 * 8 + 4 * 4 + 4 * 8 + 8 + 6 * 4
+    assert C.sizeof(_lib.GemmGroup) == 10 * 8 + 4 * 8 + 4 * 4 + 4 * 8 + 8 + 6 * 4 + 8
     assert C.sizeof(_lib.Linear) == 6 * 8 + 4 * 4
     assert C.sizeof(_lib.ModelDesc) == 14 * 4
 

@@ -459,6 +459,34 @@ def test_gemm_fused_kv_epilogue(ops, dev, cfg):
     assert_bf16_close(K_out, K_ref, max_ulp=1, min_exact=0.999, what="fused K")  # row sums of squares in another order
 
 
+def test_quant_lut_epilogue(ops, dev):
+    """Table-driven GELU + quantise epilogue (fluxmi_gemm_group_t.q_lut) == the computed one, bit for bit, for GELU_QUANT and for the
+    mlp columns of SPLIT; the table itself == the oracle's chain over all 65536 bf16 patterns."""
+    from fluxmi import _lib
+
+    M, N, K = 384, 1024, 256
+    a8, w8, sar, sbr, bias = make_f8_problem(M, N, K, E5M2, seed=21)
+    d = lambda t: t.to(dev)
+    qs = torch.tensor(41.0, dtype=torch.float32)
+    lut = ops.build_quant_lut(d(qs), E5M2, act=1)
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
+    ref_lut = fo.to_fp8_saturated(F.gelu(bits, approximate="tanh"), qs, 57344.0).to(torch.float8_e5m2).view(torch.uint8)
+    same = lut.cpu() == ref_lut
+    nan = torch.isnan(bits.float())
+    assert same[~nan].float().mean().item() >= 0.999  # (rare 1-ulp GELU flips, as in test_gelu_table)
+    args = (d(a8), d(w8), d(bias), d(sar), d(sbr))
+    ref = ops.linear(*args, epilogue=_lib.EPI_GELU_QUANT, q_scale=d(qs), tile_cfg=13)
+    got = ops.linear(*args, epilogue=_lib.EPI_GELU_QUANT, q_scale=d(qs), tile_cfg=13, q_lut=lut)
+    assert torch.equal(got.view(torch.uint8), ref.view(torch.uint8))
+    # split: first 512 columns plain bf16, the rest GELU + quantise into a wider buffer at a column offset
+    split = 512
+    o1, o2 = (torch.zeros(M, split, dtype=torch.bfloat16, device=dev) for _ in range(2))
+    w1_, w2_ = (torch.zeros(M, 128 + N - split, dtype=torch.float8_e5m2, device=dev) for _ in range(2))
+    ops.linear(*args, epilogue=_lib.EPI_SPLIT, q_scale=d(qs), out=o1, out2=w1_, split_n=split, c2_col0=128, tile_cfg=13)
+    ops.linear(*args, epilogue=_lib.EPI_SPLIT, q_scale=d(qs), out=o2, out2=w2_, split_n=split, c2_col0=128, tile_cfg=13, q_lut=lut)
+    assert torch.equal(o1, o2) and torch.equal(w1_.view(torch.uint8), w2_.view(torch.uint8))
+
+
 def test_lora_fuse(ops, dev):
     """Config 5: dequant + B@A + requant on device (lora_loading.py:509-577,615-631 -> float8_quantize.py:209-212)."""
     torch.manual_seed(12)
