@@ -52,6 +52,9 @@ def measure_gemm_roofline(torch, ops, dev, iters=10):
 
     one = torch.tensor(1.0, device=dev)
     H = 3072
+    # the engine hands frozen-scale GELU -> F8Linear epilogues a 64 KiB bf16 -> fp8 table (fluxmi_gemm_group_t.q_lut), so do we
+    lut = ops.build_quant_lut(one, _lib.E5M2, act=1) if os.environ.get("FLUXMI_QLUT", "1") != "0" else None
+    lut_ptr = lut.data_ptr() if lut is not None else None
     tot_t, tot_f, n_launch, table = 0.0, 0.0, 0, []
     for name, Ms, N, K, cnt, epi in flux_dev_gemm_shapes():
         groups, keep = [], []
@@ -66,7 +69,7 @@ def measure_gemm_roofline(torch, ops, dev, iters=10):
                 code = _lib.EPI_BF16
             elif epi == "gelu_quant":
                 o = torch.empty(M, N, dtype=torch.float8_e5m2, device=dev)
-                code, kw = _lib.EPI_GELU_QUANT, dict(q_scale=one.data_ptr())
+                code, kw = _lib.EPI_GELU_QUANT, dict(q_scale=one.data_ptr(), q_lut=lut_ptr)
             elif epi == "gate_resid":
                 o = torch.randn(M, N, device=dev).bfloat16()  # residual stream, updated in place
                 gate = torch.randn(N, device=dev).bfloat16()
@@ -76,7 +79,7 @@ def measure_gemm_roofline(torch, ops, dev, iters=10):
                 o = torch.empty(M, 3 * H, dtype=torch.bfloat16, device=dev)
                 o2 = torch.empty(M, 5 * H, dtype=torch.float8_e5m2, device=dev)
                 keep.append(o2)
-                code, kw = _lib.EPI_SPLIT, dict(C2=o2.data_ptr(), ldc2=5 * H, split_n=3 * H, c2_col0=H, q_scale=one.data_ptr())
+                code, kw = _lib.EPI_SPLIT, dict(C2=o2.data_ptr(), ldc2=5 * H, split_n=3 * H, c2_col0=H, q_scale=one.data_ptr(), q_lut=lut_ptr)
             keep.append(o)
             groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr(), one.data_ptr(), o.data_ptr(), M, K,
                                          o.stride(0), **kw))
