@@ -58,6 +58,7 @@ struct fluxmi_engine {
   size_t mods_all_bytes = 0;
   int mods_step0 = 0;
   bool mods_table = false;  // the step being sequenced takes its modulations from the table
+  bool qlut_valid = false;  // the quantising-epilogue tables reflect the current input scales
   hipGraphExec_t exec = nullptr;
   bool graph_ok = false;
   bool txt_emb_valid = false;
@@ -371,7 +372,8 @@ bool qlut_enabled() {
 }
 int build_qluts(E* e, hipStream_t s) {
   uint8_t* lut = buf<uint8_t>(e, "qlut");
-  if (!lut || !qlut_enabled()) return 0;
+  if (!lut || !qlut_enabled() || e->qlut_valid) return 0;
+  e->qlut_valid = true;
   for (int i = 0; i < e->d.depth; ++i)
     for (int st = 0; st < 2; ++st) {
       const fluxmi_linear_t& l = e->lin[DLi(e, i, st == 0 ? D_TXT_MLP2 : D_IMG_MLP2)];
@@ -600,6 +602,7 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
 void free_ws(E* e) {
   if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
   e->graph_ok = false;
+  e->qlut_valid = false;
   if (e->ws) { hipFree(e->ws); e->ws = nullptr; }
   e->bufs.clear();
   e->ws_bytes = 0;
@@ -665,6 +668,7 @@ int fluxmi_engine_rebind(fluxmi_engine_t* e, const fluxmi_linear_t* linears, int
   e->lin.assign(linears, linears + n_linears);
   e->graph_ok = false;
   e->txt_emb_valid = false;
+  e->qlut_valid = false;
   if (e->ws) return build_gemv_table(e, 0);
   return 0;
 }
@@ -739,6 +743,7 @@ int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, 
   FLUXMI_REQUIRE(img && txt && y && timesteps && pred, "engine_forward: NULL tensor");
   FLUXMI_REQUIRE(mode >= 0 && mode <= 2, "engine_forward: bad mode %d", mode);
   if (mode == 0) FLUXMI_REQUIRE(trial_index >= 0 && trial_index <= e->d.num_trials, "engine_forward: trial_index %d out of range", trial_index);
+  if (mode == 0) e->qlut_valid = false;  // input scales move during calibration
   if (mode == 1) FLUXMI_TRY(build_qluts(e, (hipStream_t)stream));
   return forward_impl(e, (const u16*)img, (const u16*)txt, (const u16*)y, (const u16*)timesteps, (const u16*)guidance, (u16*)pred,
                       mode, trial_index, false, (hipStream_t)stream);
@@ -785,6 +790,7 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
   // -- calibrating steps: the reference's first num_trials+1 calls of every F8Linear ----------------------
   while (step < n_steps && any_f8 && trial <= e->d.num_trials) {
     FLUXMI_TRY(fluxmi_k_set_timestep(tvec, e->d_ts, e->d_step, B, s));
+    e->qlut_valid = false;
     FLUXMI_TRY(forward_impl(e, img_s, txt_s, y_s, tvec, g_arg, pred_s, 0, trial, false, s));
     FLUXMI_TRY(fluxmi_k_euler(img_s, pred_s, e->d_dts, e->d_step, n_img, s));
     FLUXMI_TRY(fluxmi_k_advance_step(e->d_step, s));
