@@ -220,6 +220,9 @@ def main():
         # calibration (untimed): 13 unfused steps freeze every F8Linear input scale
         lat = model.denoise(img, img_ids, txt, txt_ids, vec, sched(13), guidance=3.5, use_graph=False)
         assert model.calibration_state()[0]
+        if world > 1:  # the reference calibrates on the whole batch: share the running amax values, then re-freeze (float8_quantize.py:227)
+            fdist.sync_calibration(model.f8_modules())
+            model.rebind_weights()
         if args.warmup > 0:
             model.denoise(img, img_ids, txt, txt_ids, vec, sched(max(args.warmup, 2)), guidance=3.5, use_graph=not args.no_graph)
         torch.cuda.synchronize()

@@ -79,6 +79,26 @@ def allreduce_amax(amax: torch.Tensor) -> torch.Tensor:
     return amax
 
 
+def sync_calibration(f8_modules) -> int:
+    """Make the frozen F8Linear input scales identical on every replica: MAX all-reduce of every layer's 12 running-amax trials
+    (one [n_layers, n_trials] tensor, ~15 KB), then input_scale = amax_to_scale(max(trials)) exactly as the reference computes it
+    (float8_quantize.py:214-215,237-246: python_float / tensor, clamped at the format maximum).  The reference takes amax over the
+    whole batch (float8_quantize.py:227); with one sample per GPU this is what makes a batch of N on N GPUs calibrate like a batch of
+    N on one GPU.  Call after the calibration steps; a no-op (returns 0) outside a process group.  Returns the number of layers."""
+    mods = [m for m in f8_modules if getattr(m, "input_amax_trials", None) is not None and m.input_scale is not None]
+    if not mods or not is_dist():
+        return 0
+    trials = torch.stack([m.input_amax_trials.float() for m in mods])
+    td.all_reduce(trials, op=td.ReduceOp.MAX)
+    for m, t in zip(mods, trials):
+        m.input_amax_trials.copy_(t)
+        max_val = float(m.input_max_value)
+        scale = (max_val / torch.clamp(t.max(), min=1e-12)).clamp(max=max_val)
+        m.input_scale.copy_(scale)
+        m.input_scale_reciprocal.copy_(scale.reciprocal())
+    return len(mods)
+
+
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """torchrun-style bootstrap: returns (rank, world, local_rank)."""
     import os

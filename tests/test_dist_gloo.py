@@ -49,6 +49,22 @@ def _worker(rank, world, port, batch, q):
     am = torch.tensor([1.0 + rank, 5.0 - rank, 0.5])
     fdist.allreduce_amax(am)
     ok = ok and am.tolist() == [float(world), 5.0, 0.5]
+
+    # calibration sync: every replica ends with the scales of the union of the batch (float8_quantize.py:227,237-246)
+    class L:  # the attributes sync_calibration touches on an F8Linear
+        def __init__(self, trials, max_value):
+            self.input_amax_trials = trials
+            self.input_scale = torch.ones(())
+            self.input_scale_reciprocal = torch.ones(())
+            self.input_max_value = max_value
+
+    layers = [L(torch.tensor([0.5, 3.0 + rank, 1.0]), 57344.0), L(torch.tensor([1e-14 * (rank + 1), 0.0, 0.0]), 448.0)]
+    ok = ok and fdist.sync_calibration(layers) == 2
+    top = 3.0 + (world - 1)
+    ok = ok and layers[0].input_amax_trials.tolist() == [0.5, top, 1.0]
+    ok = ok and layers[0].input_scale.item() == (torch.tensor(57344.0) / torch.tensor(top)).item()
+    ok = ok and layers[0].input_scale_reciprocal.item() == layers[0].input_scale.reciprocal().item()
+    ok = ok and layers[1].input_scale.item() == 448.0  # clamped at the format maximum
     q.put((rank, bool(ok), (lo, hi)))
     td.barrier()
     td.destroy_process_group()
