@@ -232,6 +232,16 @@ int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, lo
                      const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream) {
   return fluxmi_k_attention(Q, K, VT, out, ld_out, col_off, out_fp8, q_scale0, q_scale1, split, B, L, Lp, H, fmt, (hipStream_t)stream);
 }
+int fluxmi_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int upsample, void* stream) {
+  return fluxmi_k_im2col3x3(x, col, B, H, W, C, upsample, (hipStream_t)stream);
+}
+int fluxmi_groupnorm(const void* x, const void* gamma, const void* beta, void* y, float* work, int B, int P, int C, int swish, float eps,
+                     void* stream) {
+  return fluxmi_k_groupnorm(x, gamma, beta, y, work, B, P, C, swish, eps, (hipStream_t)stream);
+}
+int fluxmi_softmax_rows(const void* S, void* P, int rows, int cols, long long ld, float scale, void* stream) {
+  return fluxmi_k_softmax_rows(S, P, rows, cols, ld, scale, (hipStream_t)stream);
+}
 int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void* stream) {
   return fluxmi_k_build_qlut(scale, fmt, act, lut, (hipStream_t)stream);
 }

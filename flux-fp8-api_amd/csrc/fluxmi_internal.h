@@ -92,6 +92,10 @@ int fluxmi_k_rope_table(const void* ids, const float* omega, const int* axis, vo
 int fluxmi_k_euler(void* img, const void* pred, const float* dts, const int* step, long long n, hipStream_t s);
 int fluxmi_k_set_timestep(void* t_vec, const float* ts, const int* step, int B, hipStream_t s);
 int fluxmi_k_advance_step(int* step, hipStream_t s);
+int fluxmi_k_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int up, hipStream_t s);
+int fluxmi_k_groupnorm(const void* x, const void* gamma, const void* beta, void* y, float* work, int B, int P, int C, int swish, float eps,
+                       hipStream_t s);
+int fluxmi_k_softmax_rows(const void* S, void* P, int rows, int cols, long long ld, float scale, hipStream_t s);
 int fluxmi_k_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0,
                       const void* q_scale1, const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H,
                       int split, hipStream_t s);

@@ -267,3 +267,34 @@ def euler_(img: torch.Tensor, pred: torch.Tensor, dt: float) -> torch.Tensor:
     dts = torch.tensor([dt], dtype=torch.float32, device=img.device)
     call("fluxmi_euler", _p(img), _p(pred), _p(dts), None, img.numel(), _stream())
     return img
+
+
+# ---- VAE decoder pieces (NHWC bf16) -------------------------------------------------------------------------------------
+def im2col3x3(x: torch.Tensor, upsample: int = 1) -> torch.Tensor:
+    """x [B, Hin, Win, C] bf16 -> patch matrix [B*H*W, 9*C] (H = Hin*upsample), column order (dy, dx, c)."""
+    _req(x, torch.bfloat16, "x")
+    x = x.contiguous()
+    B, Hi, Wi, Cc = x.shape
+    H, W = Hi * upsample, Wi * upsample
+    col = torch.empty((B * H * W, 9 * Cc), dtype=torch.bfloat16, device=x.device)
+    call("fluxmi_im2col3x3", _p(x), _p(col), B, H, W, Cc, upsample, _stream())
+    return col
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, swish: bool = True, eps: float = 1e-6) -> torch.Tensor:
+    """x [B, P, C] bf16 (P pixels), 32 groups; fp32 statistics, one bf16 rounding at the end."""
+    _req(x, torch.bfloat16, "x")
+    x = x.contiguous()
+    B, P, Cc = x.shape
+    work = torch.empty((B * ((P + 4095) // 4096) + B) * 64, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    call("fluxmi_groupnorm", _p(x), _p(gamma), _p(beta), _p(y), _p(work), B, P, Cc, int(swish), float(eps), _stream())
+    return y
+
+
+def softmax_rows(S: torch.Tensor, scale: float) -> torch.Tensor:
+    _req(S, torch.bfloat16, "S")
+    S = S.contiguous()
+    P = torch.empty_like(S)
+    call("fluxmi_softmax_rows", _p(S), _p(P), S.shape[0], S.shape[1], S.stride(0), float(scale), _stream())
+    return P

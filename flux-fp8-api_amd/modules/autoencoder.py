@@ -1,8 +1,24 @@
-"""VAE parameters of the reference config schema (modules/autoencoder.py:11-21 of aredden/flux-fp8-api).
+"""VAE of the reference config schema (modules/autoencoder.py of aredden/flux-fp8-api) -- decoder on MI355X.
 
-Only the pydantic parameter block is needed by the denoise hot path (every config JSON carries
-`ae_params`).  The VAE encode/decode itself is row 1 of SURVEY.md §8(f) "next": not built yet."""
+SURVEY.md §8(f) row 1: the step right after the denoise loop.  `AutoEncoder(params)` keeps the reference's module tree and
+state-dict keys for the DECODER (`decoder.conv_in`, `decoder.mid.block_1.norm1`, `decoder.up.3.block.0.conv1`,
+`decoder.up.1.upsample.conv`, ... so a BFL `ae.sft` loads with `load_state_dict(strict=False)`); `decode(z)` runs natively:
+
+  * activations NHWC bf16; 3x3 convolutions = `fluxmi_im2col3x3` (the 2x nearest upsample folded into the gather) + the bf16 MFMA
+    GEMM with the weight reordered once to [Cout][dy][dx][Cin]; 1x1 convolutions are plain GEMMs; residual adds ride in the GEMM's
+    gate*y+x epilogue (gate = 1);
+  * GroupNorm(32) + swish in fp32, rounded to bf16 once (`fluxmi_groupnorm`) -- what torch.autocast(bf16) computes
+    (flux_pipeline.py:431-434): convolutions / SDPA in bf16, GroupNorm and the swish behind it in fp32;
+  * the single 512-wide attention head of mid.attn_1: S = Q K^T (GEMM) -> fp32 row softmax (`fluxmi_softmax_rows`) -> P V (GEMM against
+    V^T, which the v-projection GEMM produces directly by swapping its operands; v's bias is added after P V, rows of P sum to 1).
+
+`encode` (img2img only) is not built; there is no CPU / PyTorch fallback.
+"""
+from __future__ import annotations
+
+import torch
 from pydantic import BaseModel
+from torch import Tensor, nn
 
 
 class AutoEncoderParams(BaseModel):
@@ -17,7 +33,168 @@ class AutoEncoderParams(BaseModel):
     shift_factor: float
 
 
-class AutoEncoder:  # placeholder so `from modules.autoencoder import AutoEncoder` keeps importing
+def _gn(c):
+    return nn.GroupNorm(num_groups=32, num_channels=c, eps=1e-6, affine=True)
+
+
+class AttnBlock(nn.Module):  # reference :23-52 (parameters only; the math is AutoEncoder._attn)
+    def __init__(self, c: int):
+        super().__init__()
+        self.norm = _gn(c)
+        self.q, self.k, self.v, self.proj_out = (nn.Conv2d(c, c, kernel_size=1) for _ in range(4))
+
+
+class ResnetBlock(nn.Module):  # reference :55-93
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.norm1, self.conv1 = _gn(cin), nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1)
+        self.norm2, self.conv2 = _gn(cout), nn.Conv2d(cout, cout, kernel_size=3, stride=1, padding=1)
+        if cin != cout:
+            self.nin_shortcut = nn.Conv2d(cin, cout, kernel_size=1, stride=1, padding=0)
+
+
+class Upsample(nn.Module):  # reference :110-120
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, kernel_size=3, stride=1, padding=1)
+
+
+class Decoder(nn.Module):  # reference :203-259 (module tree / state-dict keys)
+    def __init__(self, ch, out_ch, ch_mult, num_res_blocks, in_channels, resolution, z_channels):
+        super().__init__()
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        block_in = ch * ch_mult[-1]
+        self.conv_in = nn.Conv2d(z_channels, block_in, kernel_size=3, stride=1, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block = nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+            up = nn.Module()
+            up.block, up.attn = block, nn.ModuleList()
+            if i_level != 0:
+                up.upsample = Upsample(block_in)
+            self.up.insert(0, up)
+        self.norm_out = _gn(block_in)
+        self.conv_out = nn.Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+
+
+class AutoEncoder(nn.Module):
     def __init__(self, params: AutoEncoderParams):
-        raise NotImplementedError("fluxmi: the VAE is outside the denoise hot path (SURVEY.md §8f row 1); "
-                                  "FluxPipeline returns latents when no autoencoder is attached")
+        super().__init__()
+        self.params = params
+        self.decoder = Decoder(resolution=params.resolution, in_channels=params.in_channels, ch=params.ch, out_ch=params.out_ch,
+                               ch_mult=params.ch_mult, num_res_blocks=params.num_res_blocks, z_channels=params.z_channels)
+        self.scale_factor, self.shift_factor = params.scale_factor, params.shift_factor
+        self._wcache = {}
+
+    # ---- weight preparation (once per module): conv weight -> GEMM weight [N, K] bf16, K ordered (dy, dx, cin) --------------------
+    def _w(self, conv: nn.Conv2d):
+        key = id(conv)
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] is not conv.weight or ent[1].device != conv.weight.device:
+            w = conv.weight.detach()
+            cin = w.shape[1]
+            pad = (-cin) % 8  # the patch gather moves 8 channels at a time
+            if pad:
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad))
+            w2 = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(torch.bfloat16).contiguous()
+            b = conv.bias.detach().to(torch.bfloat16).contiguous()
+            ent = (conv.weight, w2, b, pad)
+            self._wcache[key] = ent
+        return ent[1], ent[2], ent[3]
+
+    def _conv3(self, x: Tensor, conv: nn.Conv2d, upsample: int = 1, resid: Tensor | None = None) -> Tensor:
+        from fluxmi import _lib, ops
+
+        w2, b, pad = self._w(conv)
+        if pad:
+            x = torch.nn.functional.pad(x, (0, pad))
+        B, Hi, Wi, _ = x.shape
+        col = ops.im2col3x3(x, upsample)
+        return self._gemm(col, w2, b, resid).view(B, Hi * upsample, Wi * upsample, -1)
+
+    def _conv1(self, x: Tensor, conv: nn.Conv2d, resid: Tensor | None = None) -> Tensor:
+        w2, b, _ = self._w(conv)
+        return self._gemm(x.reshape(-1, x.shape[-1]), w2, b, resid).view(*x.shape[:-1], -1)
+
+    def _gemm(self, a: Tensor, w2: Tensor, bias: Tensor | None, resid: Tensor | None) -> Tensor:
+        from fluxmi import _lib, ops
+
+        if resid is None:
+            return ops.linear(a, w2, bias)
+        r = resid.reshape(-1, resid.shape[-1])
+        out = torch.empty_like(r)
+        ones = self._ones(w2.shape[0], a.device)
+        return ops.linear(a, w2, bias, epilogue=_lib.EPI_GATE_RESID, gate=ones, resid=r, out=out)  # out = resid + 1 * (a @ w2^T + bias)
+
+    def _ones(self, n, device):
+        key = ("ones", n, str(device))
+        if key not in self._wcache:
+            self._wcache[key] = torch.ones(n, dtype=torch.bfloat16, device=device)
+        return self._wcache[key]
+
+    def _norm(self, x: Tensor, gn: nn.GroupNorm, swish: bool) -> Tensor:
+        from fluxmi import ops
+
+        B, H, W, C = x.shape
+        key = id(gn)
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] is not gn.weight or ent[1].device != x.device:
+            ent = (gn.weight, gn.weight.detach().to(torch.bfloat16).contiguous(), gn.bias.detach().to(torch.bfloat16).contiguous())
+            self._wcache[key] = ent
+        return ops.groupnorm(x.view(B, H * W, C), ent[1], ent[2], swish=swish, eps=gn.eps).view(B, H, W, C)
+
+    def _resnet(self, x: Tensor, blk: ResnetBlock) -> Tensor:  # reference :79-92
+        h = self._conv3(self._norm(x, blk.norm1, True), blk.conv1)
+        if blk.in_channels != blk.out_channels:
+            x = self._conv1(x, blk.nin_shortcut)
+        return self._conv3(self._norm(h, blk.norm2, True), blk.conv2, resid=x)
+
+    def _attn(self, x: Tensor, blk: AttnBlock) -> Tensor:  # reference :37-52
+        from fluxmi import ops
+
+        B, H, W, C = x.shape
+        hn = self._norm(x, blk.norm, False).view(B, H * W, C)
+        wv, bv, _ = self._w(blk.v)
+        out = torch.empty_like(hn)
+        for b in range(B):
+            q = self._conv1(hn[b], blk.q)                       # [P, C]
+            k = self._conv1(hn[b], blk.k)
+            vt = ops.linear(wv, hn[b].contiguous(), None)       # [C, P] = Wv . Xn^T = V^T (bias added after P V)
+            S = ops.linear(q, k, None)                          # [P, P] = Q K^T
+            Pm = ops.softmax_rows(S, float(C) ** -0.5)
+            out[b] = ops.linear(Pm, vt, bv)                     # [P, C] = P V + b_v
+        return self._conv1(out.view(B, H, W, C), blk.proj_out, resid=x)
+
+    @torch.inference_mode()
+    def decode(self, z: Tensor) -> Tensor:
+        """z [B, z_channels, h, w] -> image [B, out_ch, 8h, 8w] (bf16), reference :330-332 + :261-283 under autocast(bf16)."""
+        if not z.is_cuda:
+            raise RuntimeError("fluxmi: AutoEncoder.decode needs the GPU (libfluxmi has no CPU path)")
+        d = self.decoder
+        h = (z.float() / self.scale_factor + self.shift_factor).permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()  # NHWC
+        h = self._conv3(h, d.conv_in)
+        h = self._resnet(h, d.mid.block_1)
+        h = self._attn(h, d.mid.attn_1)
+        h = self._resnet(h, d.mid.block_2)
+        for i_level in reversed(range(d.num_resolutions)):
+            for i_block in range(d.num_res_blocks + 1):
+                h = self._resnet(h, d.up[i_level].block[i_block])
+            if i_level != 0:
+                h = self._conv3(h, d.up[i_level].upsample.conv, upsample=2)
+        h = self._conv3(self._norm(h, d.norm_out, True), d.conv_out)
+        return h.permute(0, 3, 1, 2).contiguous()
+
+    def encode(self, x: Tensor) -> Tensor:
+        raise NotImplementedError("fluxmi: the VAE encoder (img2img, reference modules/autoencoder.py:123-200) is not built")
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.decode(self.encode(x))

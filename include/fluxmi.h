@@ -150,6 +150,18 @@ int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, con
                           const void* VT, void* out, long long ld_out, int col_off, int out_fp8, const float* q_scale0,
                           const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream);
 
+/* ---- VAE decoder pieces (NHWC bf16) ------------------------------------------------------------ */
+/* 3x3 / stride 1 / pad 1 patch matrix: x [B, H/up, W/up, C] -> col [B*H*W, 9*C], column (dy*3+dx)*C + c; up = 2 folds the nearest
+ * 2x upsample of Upsample.forward into the gather.  The convolution is then fluxmi_gemm_grouped(is_fp8=0) with the weight
+ * reordered to [Cout][dy][dx][Cin].                                             modules/autoencoder.py:65-72,110-120,228,259 */
+int fluxmi_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int upsample, void* stream);
+/* GroupNorm(32 groups, affine) in fp32 + optional swish, rounded to bf16 once; x, y [B, P, C]; work: float[(B*ceil(P/4096)+B)*64].
+ *                                                                                modules/autoencoder.py:19-20,28-30,62-70,256 */
+int fluxmi_groupnorm(const void* x, const void* gamma, const void* beta, void* y, float* work, int B, int P, int C, int swish, float eps,
+                     void* stream);
+/* P[r,:] = softmax(scale * S[r,:]) (fp32 inside), bf16 [rows, cols], row stride ld            modules/autoencoder.py:47 */
+int fluxmi_softmax_rows(const void* S, void* P, int rows, int cols, long long ld, float scale, void* stream);
+
 /* ---- step scalars -------------------------------------------------------------------------------------- */
 /* timestep_embedding(t, 2*half) with host-provided frequency table                 flux_model.py:95-116 */
 int fluxmi_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, void* stream);

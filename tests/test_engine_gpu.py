@@ -266,3 +266,29 @@ def test_pipeline_generate_latents(dev):
     assert torch.equal(out, out2)
     with pytest.raises(ValueError):
         pipe.model(torch.zeros(1, 4, dtype=torch.bfloat16, device=dev), None, torch.zeros(1, 4, dtype=torch.bfloat16, device=dev), None, None, None)
+
+
+def test_vae_decoder_matches_reference_fixture(dev):
+    """AutoEncoder.decode (native, NHWC bf16, conv = im2col + MFMA GEMM) vs the unmodified reference decoder's
+    outputs stored in tests/golden/g8_vae.safetensors (fp32, and under torch.autocast(bf16) on CPU).  Tolerance: the native path
+    must be as close to the fp32 result as the reference's own bf16-autocast path is (x1.5)."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from modules.autoencoder import AutoEncoder, AutoEncoderParams
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_vae.safetensors"))
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    ae = AutoEncoder(AutoEncoderParams(resolution=32, in_channels=3, ch=32, out_ch=3, ch_mult=[1, 2], num_res_blocks=1, z_channels=4,
+                                       scale_factor=0.3611, shift_factor=0.1159))
+    ae.load_state_dict(sd, strict=True)
+    ae.to(dev)
+    out = ae.decode(g["z"].to(dev)).float().cpu()
+    assert out.shape == g["ref_fp32"].shape and torch.isfinite(out).all()
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    e_native, e_ref = rel(out, g["ref_fp32"]), rel(g["ref_autocast"], g["ref_fp32"])
+    print(f"VAE decode: native vs fp32 reference {e_native:.3e}; reference autocast vs fp32 {e_ref:.3e}; native vs oracle-autocast "
+          f"{rel(out, g['oracle_autocast']):.3e}")
+    assert e_native <= 1.5 * e_ref
+    assert rel(out, g["oracle_autocast"]) <= 1.5e-2

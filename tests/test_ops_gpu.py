@@ -507,3 +507,42 @@ def test_lora_fuse(ops, dev):
         st.set_weight_tensor(st_ref_w)
         assert abs(sc.item() - st.scale.item()) <= 1e-6 * st.scale.item()
         assert_f8_close(q, st.float8_data, max_ulp=1, min_exact=0.995, what=f"lora fuse chunks={chunks}")
+
+
+# ---- VAE decoder pieces -----------------------------------------------------------------------------
+@pytest.mark.parametrize("up", [1, 2])
+def test_im2col3x3(ops, dev, up):
+    """Patch matrix == F.unfold of the (optionally nearest-upsampled) NCHW image, columns reordered (dy, dx, c)."""
+    torch.manual_seed(31)
+    B, Hi, Wi, C = 2, 6, 10, 16
+    x = torch.randn(B, Hi, Wi, C).bfloat16()
+    col = ops.im2col3x3(x.to(dev), up).cpu()
+    xn = x.permute(0, 3, 1, 2).float()
+    if up == 2:
+        xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    H, W = Hi * up, Wi * up
+    ref = F.unfold(xn, kernel_size=3, padding=1).view(B, C, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * C)
+    assert torch.equal(col.float(), ref)
+
+
+@pytest.mark.parametrize("C,swish", [(32, True), (64, False), (512, True)])
+def test_groupnorm(ops, dev, C, swish):
+    torch.manual_seed(32)
+    B, P = 2, 5000
+    x = (torch.randn(B, P, C) * 2 + 0.5).bfloat16()
+    ga, be = (1 + 0.1 * torch.randn(C)).bfloat16(), (0.1 * torch.randn(C)).bfloat16()
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, ga.float(), be.float(), eps=1e-6)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    ref = ref.permute(0, 2, 1).bfloat16()
+    got = ops.groupnorm(x.to(dev), ga.to(dev), be.to(dev), swish=swish).cpu()
+    # values near zero come out of a cancellation ((x - mean) * rstd * gamma + beta): 1 bf16 ulp at the magnitude of the operands
+    assert_close_mag(got, ref, mag=0.25, ulps=1, min_exact=0.99, what="groupnorm")
+
+
+def test_softmax_rows(ops, dev):
+    torch.manual_seed(33)
+    S = (torch.randn(300, 1024) * 6).bfloat16()
+    ref = torch.softmax(S.float() * 0.125, dim=-1).bfloat16()
+    got = ops.softmax_rows(S.to(dev), 0.125).cpu()
+    assert_bf16_close(got, ref, max_ulp=1, min_exact=0.99, what="softmax rows")

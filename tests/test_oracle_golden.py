@@ -153,3 +153,21 @@ def test_pack_unpack_round_trip_and_ids():
     img_ids, txt_ids = fo.make_ids(2, 6, 4, 5, torch.bfloat16)
     assert img_ids.shape == (2, 24, 3) and txt_ids.shape == (2, 5, 3) and not txt_ids.any()
     assert img_ids[0, 5].tolist() == [0.0, 1.0, 1.0]  # row-major (row, col)
+
+
+def test_g8_vae_decoder_oracle_matches_reference_fixture():
+    """oracle/vae_oracle.py (restatement of modules/autoencoder.py:203-283,330-332) vs the outputs of the
+    unmodified reference stored by oracle/gen_golden_vae.py: fp32 bit-equal; the autocast(bf16) restatement reproducible."""
+    import vae_oracle as vo
+    from safetensors.torch import load_file
+
+    g = load("g8_vae")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    P = dict(ch_mult=[1, 2], num_res_blocks=1, scale_factor=0.3611, shift_factor=0.1159)
+    with torch.no_grad():
+        o32 = vo.decode(sd, P, g["z"], autocast=False)
+        oac = vo.decode(sd, P, g["z"], autocast=True)
+    assert torch.equal(o32, g["ref_fp32"])
+    assert torch.equal(oac.float(), g["oracle_autocast"])
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    assert rel(oac, g["ref_fp32"]) <= 1.5 * rel(g["ref_autocast"], g["ref_fp32"])
