@@ -213,17 +213,18 @@ class FluxPipeline:
             if flow_model_path:
                 config.ckpt_path = flow_model_path
             state_dict = kwargs.pop("state_dict", None)
+            ae_state_dict = kwargs.pop("ae_state_dict", None)
             for k, v in kwargs.items():
                 if hasattr(config, k):
                     setattr(config, k, v)
-            return cls.load_pipeline_from_config(config, debug=debug, state_dict=state_dict)
+            return cls.load_pipeline_from_config(config, debug=debug, state_dict=state_dict, ae_state_dict=ae_state_dict)
 
     @classmethod
-    def load_pipeline_from_config(cls, config: ModelSpec, debug: bool = False, state_dict=None) -> "FluxPipeline":
+    def load_pipeline_from_config(cls, config: ModelSpec, debug: bool = False, state_dict=None, ae_state_dict=None) -> "FluxPipeline":
         from float8_quantize import quantize_flow_transformer_and_dispatch_float8
 
         with torch.inference_mode():
-            models = load_models_from_config(config, state_dict=state_dict)
+            models = load_models_from_config(config, state_dict=state_dict, ae_state_dict=ae_state_dict)
             config = models.config
             flux_device = into_device(config.flux_device)
             flux_dtype = into_dtype(config.flow_dtype)

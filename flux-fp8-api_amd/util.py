@@ -191,9 +191,30 @@ class LoadedModels(BaseModel):
     model_config = {"arbitrary_types_allowed": True, "use_enum_values": True}
 
 
-def load_models_from_config(config: ModelSpec, state_dict=None) -> LoadedModels:
-    """reference util.py:325-333; text encoders and VAE are SURVEY.md §8(f) 'next' rows -> None here."""
-    return LoadedModels(flow=load_flow_model(config, state_dict), ae=None, clip=None, t5=None, config=config)
+def load_autoencoder(config: ModelSpec, state_dict=None):
+    """reference util.py:269-296: AutoEncoder(config.ae_params) + weights from config.ae_path (a BFL `ae.sft`; `encoder.*` keys are
+    ignored, only the decoder is built natively) on config.ae_device in bf16.  Returns None when no weights are available (offline
+    runs): FluxPipeline.generate then returns latents."""
+    import os
+
+    from modules.autoencoder import AutoEncoder
+
+    if state_dict is None:
+        path = getattr(config, "ae_path", None)
+        if not path or not os.path.exists(path):
+            return None
+        state_dict = load_sft(path, device="cpu")
+    ae = AutoEncoder(config.ae_params)
+    dec = {k: v for k, v in state_dict.items() if k.startswith("decoder.")}
+    missing, unexpected = ae.load_state_dict(dec, strict=False)
+    if missing:
+        raise RuntimeError(f"autoencoder checkpoint is missing decoder weights: {missing[:4]} ...")
+    return ae.to(device=into_device(config.ae_device), dtype=torch.bfloat16)
+
+
+def load_models_from_config(config: ModelSpec, state_dict=None, ae_state_dict=None) -> LoadedModels:
+    """reference util.py:325-333; the text encoders are a SURVEY.md §8(f) 'next' row -> None here."""
+    return LoadedModels(flow=load_flow_model(config, state_dict), ae=load_autoencoder(config, ae_state_dict), clip=None, t5=None, config=config)
 
 
 def load_models_from_config_path(path: str) -> LoadedModels:
