@@ -299,7 +299,7 @@ int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg) {
 #ifdef FLUXMI_EXPERIMENTS
   if (cfg >= 20 && cfg < 36) cfg = 4;  // ablation variants of the 256x256 ring
 #else
-  if (cfg == 7 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 12 || cfg == 14) return 0;  // experimental variants, not built
+  if (cfg == 7 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 14) return 0;  // experimental variants, not built
 #endif
   if (cfg < 0 || cfg >= FLUXMI_N_CFG) return 0;
   const int kb = K * (is_fp8 ? 1 : 2);

@@ -72,6 +72,23 @@ __device__ __forceinline__ void epilogue(const FluxmiGemmGroup& G, float qs, int
 
 __device__ __forceinline__ float load_scale(const float* p) { return p ? *p : 1.0f; }
 
+// ---- LDS-DMA through buffer descriptors ------------------------------------------------------------------------------------
+// `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`: fixed per-lane byte offset in a VGPR, tile / K offset in an SGPR, no address
+// VALU in the K loop, bytes past `bytes` read as zero.  Kept out of the kernel templates (a device-only builtin in
+// template-dependent code makes hipcc's host pass drop the kernel stub).  The descriptor inputs are wave-uniform in fact but reach
+// the kernels through a dynamically indexed kernel-argument struct, i.e. in VGPRs: without readfirstlane hipcc wraps EVERY buffer
+// op in a waterfall loop.
+typedef __attribute__((address_space(3))) void* fluxmi_lds_ptr_t;
+__device__ __forceinline__ unsigned uni_u32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  const unsigned long long ub = ((unsigned long long)uni_u32((unsigned)(b >> 32)) << 32) | uni_u32((unsigned)b);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, uni_u32(bytes), 0x00020000);
+}
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (fluxmi_lds_ptr_t)lds, 16, voff, soff, 0, 0);
+}
+
 // ---- LDS-transposed epilogue shared by the ring / ping-pong / one-wave-per-SIMD kernels ---------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

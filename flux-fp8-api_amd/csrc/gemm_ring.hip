@@ -249,27 +249,44 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
   const int n0 = tn * BN;
   const int nk = (P.K * EB) / 64;
 
+  // VAR & 4: LDS-DMA through buffer descriptors (SGPR tile / K offsets, rows past M read as zero) instead of per-lane 64-bit
+  // addresses (4 v_lshl_add_u64 per K-step and a clamped row index)
+  constexpr bool BUF = (VAR & 4) != 0;
   const unsigned char* srcA[IA];
   const unsigned char* srcW[IW];
+  unsigned a_voff[IA], w_voff[IW];
+  const long long a_row_b = (long long)G.lda * EB, w_row_b = (long long)P.K * EB;
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
     const int gr = min(m0 + row, M - 1);
     srcA[i] = (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16;
+    a_voff[i] = (unsigned)(row * a_row_b + slot * 16);
   }
 #pragma unroll
   for (int i = 0; i < IW; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
     srcW[i] = (const unsigned char*)G.W + ((long long)(n0 + row) * P.K) * EB + slot * 16;
+    w_voff[i] = (unsigned)(row * w_row_b + slot * 16);
   }
+  const __amdgpu_buffer_rsrc_t ars = make_rsrc(G.A, (unsigned)min((long long)M * a_row_b, 0xffffffffLL));
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
+  const unsigned a_soff0 = uni_u32((unsigned)(m0 * a_row_b)), w_soff0 = uni_u32((unsigned)(n0 * w_row_b));
   auto stage = [&](int kt, int slot) {
     unsigned char* dA = smem + slot * STAGE + wave * 1024;
     unsigned char* dW = dA + A_BYTES;
-    const long long koff = (long long)kt * 64;
+    if constexpr (BUF) {
 #pragma unroll
-    for (int i = 0; i < IA; ++i) glds16(srcA[i] + koff, dA + NT * 16 * i);
+      for (int i = 0; i < IA; ++i) dma16_buf(ars, dA + NT * 16 * i, a_voff[i], a_soff0 + kt * 64);
 #pragma unroll
-    for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, dW + NT * 16 * i);
+      for (int i = 0; i < IW; ++i) dma16_buf(wrs, dW + NT * 16 * i, w_voff[i], w_soff0 + kt * 64);
+    } else {
+      const long long koff = (long long)kt * 64;
+#pragma unroll
+      for (int i = 0; i < IA; ++i) glds16(srcA[i] + koff, dA + NT * 16 * i);
+#pragma unroll
+      for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, dW + NT * 16 * i);
+    }
   };
 
   v16f acc[TM][TN];
@@ -447,12 +464,12 @@ int launch_ring_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
     case 6: return launch_ring<128, 128, 2, 2, 4, false, FP8, ACT>(p, s);
     case 8: return launch_ring<256, 128, 2, 2, 3, true, FP8, ACT>(p, s);   // 72 KiB LDS, 4 waves: 2 blocks per CU
     case 13: return launch_pp<FP8, ACT, 2>(p, s);
+    case 12: return launch_pp<FP8, ACT, 6>(p, s);  // 13 with buffer-descriptor LDS-DMA
 #ifdef FLUXMI_EXPERIMENTS  // variants measured and rejected in round 1 (profiles/r01_gemm_ablation*.txt); not built by default
     case 7: return launch_ring<256, 256, 2, 4, 4, true, FP8, ACT>(p, s);
     case 9: return launch_ring<128, 256, 2, 2, 3, true, FP8, ACT>(p, s);
     case 10: return launch_ring<256, 128, 2, 2, 3, false, FP8, ACT>(p, s);
     case 11: return launch_pp<FP8, ACT, 0>(p, s);
-    case 12: return launch_pp<FP8, ACT, 1>(p, s);
     case 14: return launch_pp<FP8, ACT, 3>(p, s);
 #endif
     default: break;

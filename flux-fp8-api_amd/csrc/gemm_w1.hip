@@ -21,21 +21,6 @@
 
 namespace {
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-// one 1 KiB LDS-DMA piece (kept out of the kernel template: a device-only builtin in template-dependent code makes hipcc's host
-// pass drop the kernel stub)
-__device__ __forceinline__ void w1_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voff, soff, 0, 0);
-}
-// The descriptor inputs are wave-uniform in fact (they come from the block's tile / problem index) but reach us through a
-// dynamically indexed kernel-argument struct, i.e. in VGPRs: without readfirstlane hipcc wraps EVERY buffer op in a waterfall loop.
-__device__ __forceinline__ unsigned uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t w1_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long b = (unsigned long long)base;
-  const unsigned long long ub = ((unsigned long long)uni((unsigned)(b >> 32)) << 32) | uni((unsigned)b);
-  return __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, uni(bytes), 0x00020000);
-}
-
 struct W1Frags { v8i fw[4]; v8i fa[4]; };
 
 template <bool FP8, int ACT_FMT, int ABL>
@@ -70,8 +55,8 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
 
   // ---- LDS-DMA: descriptors (SGPRs), per-lane offsets (VGPRs, loop-invariant), tile offsets (SGPRs) ----------------------------
   const long long a_row_b = (long long)G.lda * EB, w_row_b = (long long)P.K * EB;
-  const __amdgpu_buffer_rsrc_t ars = w1_rsrc(G.A, (unsigned)min((long long)M * a_row_b, 0xffffffffLL));
-  const __amdgpu_buffer_rsrc_t wrs = w1_rsrc(G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
+  const __amdgpu_buffer_rsrc_t ars = make_rsrc(G.A, (unsigned)min((long long)M * a_row_b, 0xffffffffLL));
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
   unsigned a_voff[4], w_voff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -79,12 +64,12 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
     a_voff[i] = (unsigned)(row * a_row_b + slot * 16);
     w_voff[i] = (unsigned)(row * w_row_b + slot * 16);
   }
-  const unsigned a_soff0 = uni((unsigned)(m0 * a_row_b)), w_soff0 = uni((unsigned)(n0 * w_row_b));
+  const unsigned a_soff0 = uni_u32((unsigned)(m0 * a_row_b)), w_soff0 = uni_u32((unsigned)(n0 * w_row_b));
   // piece q (0..7) of K-step kt into ring slot `slot`
   auto dma_piece = [&](int q, int slot, int kt) {
     unsigned char* d = smem + slot * STAGE + wave * 1024;
-    if (q < 4) w1_dma16(ars, d + NT * 16 * q, a_voff[q], a_soff0 + kt * 64);
-    else w1_dma16(wrs, d + A_BYTES + NT * 16 * (q - 4), w_voff[q - 4], w_soff0 + kt * 64);
+    if (q < 4) dma16_buf(ars, d + NT * 16 * q, a_voff[q], a_soff0 + kt * 64);
+    else dma16_buf(wrs, d + A_BYTES + NT * 16 * (q - 4), w_voff[q - 4], w_soff0 + kt * 64);
   };
 
   v16f acc[TM][TN];
