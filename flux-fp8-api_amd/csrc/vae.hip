@@ -1,9 +1,9 @@
-// fluxmi -- kernels of the VAE decoder (the step right after the denoise loop), gfx950.
+// fluxmi -- kernels of the VAE (decoder = the step right after the denoise loop; encoder = img2img), gfx950.
 //
-// Reference: modules/autoencoder.py:203-283 (Decoder), :55-93 (ResnetBlock), :23-52 (AttnBlock), :110-120 (Upsample), run under
+// Reference: modules/autoencoder.py:203-283 (Decoder), :123-200 (Encoder), :55-93 (ResnetBlock), :23-52 (AttnBlock), :95-120 (Down/Upsample), run under
 // torch.autocast(bf16) by flux_pipeline.py:423-437.  Layout here is NHWC (channels innermost) so that
 //   * a 3x3 convolution is  im2col (this file) + the bf16 MFMA GEMM of gemm*.hip  with K = 9*Cin ordered (dy, dx, c), the 2x
-//     nearest-neighbour upsample of Upsample.forward folded into the gather;
+//     nearest-neighbour upsample of Upsample.forward / the stride-2, right-bottom-padded window of Downsample.forward folded into the gather;
 //   * 1x1 convolutions (nin_shortcut, q/k/v/proj_out) are plain GEMMs on the [pixels, C] matrix;
 //   * residual adds ride in the GEMM's gate*y+x epilogue with gate = 1.
 // GroupNorm(32 groups, eps 1e-6, affine) runs in fp32 like autocast does and is fused with the swish that always follows it in a
@@ -14,12 +14,17 @@
 
 namespace {
 
-// ---- im2col for 3x3 / stride 1 / pad 1 on NHWC, optional nearest 2x upsample of the input ---------------------------------
-// x [B, H/up, W/up, C] -> col [B*H*W, 9*C], column (dy*3+dx)*C + c.  One thread moves 8 channels (16 B).
-__global__ void __launch_bounds__(256) im2col3x3_kernel(const u16* __restrict__ x, u16* __restrict__ col, int B, int H, int W, int C, int up) {
+// ---- im2col for 3x3 convolutions on NHWC -------------------------------------------------------------------------------------
+// x [B, Hi, Wi, C] -> col [B*H*W, 9*C], column (dy*3+dx)*C + c; (H, W) is the OUTPUT grid.  One thread moves 8 channels (16 B).
+//   up = 1 : stride 1, pad 1                                   (Hi = H)
+//   up = 2 : nearest 2x upsample, then stride 1, pad 1          (Hi = H/2;  Upsample.forward, reference :117-119)
+//   up = -2: stride 2, zero pad (0,1,0,1) = right/bottom only   (Hi = 2H;   Downsample.forward, reference :103-107)
+// i.e. source row = (yo*stride + dy - pad) / rep, zero outside [0, Hi*rep).
+__global__ void __launch_bounds__(256) im2col3x3_kernel(const u16* __restrict__ x, u16* __restrict__ col, int B, int H, int W, int C, int Hi, int Wi,
+                                                        int stride, int pad, int rep) {
   const int c8 = C >> 3;
   const long long total = (long long)B * H * W * 9 * c8;
-  const int Hi = H / up, Wi = W / up;
+  const int Hv = Hi * rep, Wv = Wi * rep;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8);
     long long r = i / c8;
@@ -29,9 +34,9 @@ __global__ void __launch_bounds__(256) im2col3x3_kernel(const u16* __restrict__ 
     r /= W;
     const int yo = (int)(r % H);
     const int b = (int)(r / H);
-    const int yy = yo + tap / 3 - 1, xx = xo + tap % 3 - 1;
+    const int yy = yo * stride + tap / 3 - pad, xx = xo * stride + tap % 3 - pad;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *(const uint4*)(x + (((long long)b * Hi + yy / up) * Wi + xx / up) * C + cc * 8);
+    if (yy >= 0 && yy < Hv && xx >= 0 && xx < Wv) v = *(const uint4*)(x + (((long long)b * Hi + yy / rep) * Wi + xx / rep) * C + cc * 8);
     *(uint4*)(col + i * 8) = v;
   }
 }
@@ -158,10 +163,13 @@ int grid1d(long long n) { return (int)((n + 255) / 256 > 65535 * 16 ? 65535 * 16
 }  // namespace
 
 int fluxmi_k_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int up, hipStream_t s) {
-  FLUXMI_REQUIRE(C % 8 == 0 && (up == 1 || up == 2) && H % up == 0 && W % up == 0, "im2col3x3: C %% 8 == 0, up in {1,2}, H/W %% up == 0");
+  FLUXMI_REQUIRE(C % 8 == 0 && (up == 1 || up == 2 || up == -2), "im2col3x3: C %% 8 == 0, mode in {1, 2, -2}");
+  FLUXMI_REQUIRE(up != 2 || (H % 2 == 0 && W % 2 == 0), "im2col3x3: upsampled output dims must be even");
   const long long total = (long long)B * H * W * 9 * (C / 8);
   if (total == 0) return 0;
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid1d(total)), dim3(256), 0, s, (const u16*)x, (u16*)col, B, H, W, C, up);
+  const int Hi = up == 2 ? H / 2 : up == -2 ? H * 2 : H, Wi = up == 2 ? W / 2 : up == -2 ? W * 2 : W;
+  const int stride = up == -2 ? 2 : 1, pad = up == -2 ? 0 : 1, rep = up == 2 ? 2 : 1;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid1d(total)), dim3(256), 0, s, (const u16*)x, (u16*)col, B, H, W, C, Hi, Wi, stride, pad, rep);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }

@@ -5,11 +5,11 @@ Hot path kept here: seed -> noise -> 2x2 patch packi
 shifted schedule -> the Euler denoise loop (natively, hipGraph-replayed) -> unpack.
 Same public names / kwargs / defaults as the reference: FluxPipeline.load_pipeline_from_config_path /
 load_pipeline_from_config / generate / load_lora / unload_lora / compile / set_seed / get_schedule /
-get_noise / prepare / unpack / vae_decode / into_bytes.
+get_noise / prepare / unpack / vae_decode / into_bytes / load_init_image_if_needed / resize_center_crop / preprocess_latent.
 
-Out of scope for this round (SURVEY.md §8f "next" rows): T5/CLIP text conditioning, VAE, JPEG.  Until they
-exist, `generate()` takes the conditioning as pre-computed embeddings (`prompt={"txt": [B,Lt,4096],
-"vec": [B,768]}`) and returns latents unless an autoencoder object is attached.  CPU-offload flags are accepted
+SURVEY.md §8f row 1 is built around it: the native VAE decoder (latents -> JPEG) and encoder (img2img: `init_image`, `strength`).
+Not built (§8f row 2): T5/CLIP text conditioning -- `generate()` takes the conditioning as pre-computed embeddings
+(`prompt={"txt": [B,Lt,4096], "vec": [B,768]}`); it returns latents when no autoencoder is attached.  CPU-offload flags are accepted
 and ignored (meaningless with 288 GB of HBM).  `compile()` keeps the reference's warm-up/calibration protocol
 (flux_pipeline.py:197-212) but never calls torch.compile: the fused kernels + hipGraph replace it.
 """
@@ -91,6 +91,73 @@ class FluxPipeline:
         return torch.randn(num_samples, 16, 2 * math.ceil(height / 16), 2 * math.ceil(width / 16), device=device, dtype=dtype,
                            generator=generator, requires_grad=False)
 
+    # ---- img2img entry (reference flux_pipeline.py:399-420, 450-523) ---------------------------------------------------
+    def load_init_image_if_needed(self, init_image):
+        """str (path or base64 / data-URL) | PIL.Image | np.ndarray -> uint8 HWC tensor; a torch.Tensor is returned as is."""
+        from base64 import standard_b64decode
+
+        from PIL import Image
+
+        if isinstance(init_image, str):
+            try:
+                init_image = Image.open(init_image)
+            except Exception:
+                init_image = Image.open(io.BytesIO(standard_b64decode(init_image.split(",")[-1])))
+            init_image = torch.from_numpy(np.array(init_image)).type(torch.uint8)
+        elif isinstance(init_image, np.ndarray):
+            init_image = torch.from_numpy(init_image).type(torch.uint8)
+        elif isinstance(init_image, Image.Image):
+            init_image = torch.from_numpy(np.array(init_image)).type(torch.uint8)
+        return init_image
+
+    @staticmethod
+    def resize_center_crop(img: torch.Tensor, height: int, width: int) -> torch.Tensor:
+        """[..., C, H, W] -> shorter edge resized to min(width, height), then centre-cropped (zero-padded where still smaller) to
+        (height, width).  The reference calls torchvision's TF.resize / TF.center_crop (flux_pipeline.py:450-457); torchvision is not in
+        this image, so the same arithmetic is restated: antialiased bilinear in fp32 (torchvision upcasts bf16), long edge =
+        int(size * long / short), crop origin = int(round((H - h) / 2))."""
+        size = min(width, height)
+        H, W = img.shape[-2:]
+        short, long_ = (W, H) if W <= H else (H, W)
+        if short != size:
+            new_long = int(size * long_ / short)
+            nh, nw = (new_long, size) if W <= H else (size, new_long)
+            lead = img.shape[:-3]
+            r = torch.nn.functional.interpolate(img.reshape(-1, *img.shape[-3:]).float(), size=(nh, nw), mode="bilinear", align_corners=False,
+                                                antialias=True)
+            img = r.to(img.dtype).reshape(*lead, *r.shape[-3:])
+            H, W = nh, nw
+        if width > W or height > H:
+            pl, pt = (width - W) // 2 if width > W else 0, (height - H) // 2 if height > H else 0
+            pr, pb = (width - W + 1) // 2 if width > W else 0, (height - H + 1) // 2 if height > H else 0
+            img = torch.nn.functional.pad(img, (pl, pr, pt, pb))
+            H, W = img.shape[-2:]
+        top, left = int(round((H - height) / 2.0)), int(round((W - width) / 2.0))
+        return img[..., top:top + height, left:left + width]
+
+    @torch.inference_mode()
+    def preprocess_latent(self, init_image=None, height: int = 720, width: int = 1024, num_steps: int = 20, strength: float = 1.0,
+                          generator: torch.Generator = None, num_images: int = 1, noise: Optional[torch.Tensor] = None):
+        """reference flux_pipeline.py:459-523: noise + schedule; with an init image: VAE-encode it, start the schedule at
+        t_idx = int((1 - strength) * num_steps) and blend x = t * noise + (1 - t) * latent."""
+        if init_image is not None:
+            if self.ae is None:
+                raise RuntimeError("fluxmi: img2img needs an autoencoder (config.ae_path) -- none is attached")
+            if isinstance(init_image, np.ndarray):
+                init_image = torch.from_numpy(init_image)
+            init_image = init_image.permute(2, 0, 1).contiguous().to(self.device_ae, dtype=self.ae_dtype).div(127.5).sub(1)[None, ...]
+            init_image = self.resize_center_crop(init_image, height, width)
+            init_image = self.ae.encode(init_image).to(dtype=self.dtype, device=self.device_flux).repeat(num_images, 1, 1, 1)
+        x = self.get_noise(num_images, height, width, generator=generator) if noise is None else noise
+        x = x.to(device=self.device_flux, dtype=self.dtype)
+        timesteps = self.get_schedule(num_steps, x.shape[-1] * x.shape[-2] // 4, shift=(self.name != "flux-schnell"))
+        if init_image is not None:
+            t_idx = int((1 - strength) * num_steps)
+            t = timesteps[t_idx]
+            timesteps = timesteps[t_idx:]
+            x = t * x + (1.0 - t) * init_image
+        return x, timesteps
+
     # ---- packing / ids (reference flux_pipeline.py:267-292, 440-448) ----------------------------------------------
     @staticmethod
     def pack(img: torch.Tensor) -> torch.Tensor:
@@ -164,16 +231,14 @@ class FluxPipeline:
                  return_seed: bool = False, jpeg_quality: int = 99, output_type: str = "jpeg", noise: Optional[torch.Tensor] = None,
                  use_graph: bool = True):
         num_steps = 4 if self.name == "flux-schnell" else num_steps
-        if init_image is not None:
-            raise NotImplementedError("img2img needs the VAE encoder (SURVEY.md §8f row 1)")
+        init_image = self.load_init_image_if_needed(init_image) if init_image is not None else None
         height, width = 16 * (height // 16), 16 * (width // 16)
         generator, seed = self.set_seed(seed)
         world, rank = fdist.world_size(), fdist.rank()
-        # batch-sharded replicas: every rank denoises its own slice of the batch
-        if noise is None:
-            noise = self.get_noise(num_images, height, width, generator=generator)
-        noise = noise.to(device=self.device_flux, dtype=self.dtype)
-        timesteps = self.get_schedule(num_steps, noise.shape[-1] * noise.shape[-2] // 4, shift=(self.name != "flux-schnell"))
+        # batch-sharded replicas: every rank denoises its own slice of the batch (rank 0's noise / init latent is
+        # what the broadcast below distributes)
+        noise, timesteps = self.preprocess_latent(init_image=init_image, height=height, width=width, num_steps=num_steps, strength=strength,
+                                                  generator=generator, num_images=num_images, noise=noise)
         img, img_ids, vec, txt, txt_ids = map(lambda x: x.contiguous(), self.prepare(noise, prompt))
         if world > 1:
             txt, vec, img = fdist.broadcast_request(txt, vec, img, src=0)

@@ -271,11 +271,17 @@ def euler_(img: torch.Tensor, pred: torch.Tensor, dt: float) -> torch.Tensor:
 
 # ---- VAE decoder pieces (NHWC bf16) -------------------------------------------------------------------------------------
 def im2col3x3(x: torch.Tensor, upsample: int = 1) -> torch.Tensor:
-    """x [B, Hin, Win, C] bf16 -> patch matrix [B*H*W, 9*C] (H = Hin*upsample), column order (dy, dx, c)."""
+    """x [B, Hin, Win, C] bf16 -> patch matrix [B*H*W, 9*C], column order (dy, dx, c).  upsample = 1: H = Hin; 2: nearest 2x upsample
+    first (H = 2*Hin); -2: stride-2 window with zero pad on the right/bottom only (H = Hin/2, the reference's Downsample)."""
     _req(x, torch.bfloat16, "x")
     x = x.contiguous()
     B, Hi, Wi, Cc = x.shape
-    H, W = Hi * upsample, Wi * upsample
+    if upsample == -2:
+        if Hi % 2 or Wi % 2:
+            raise ValueError("im2col3x3: the stride-2 mode needs even input dims")
+        H, W = Hi // 2, Wi // 2
+    else:
+        H, W = Hi * upsample, Wi * upsample
     col = torch.empty((B * H * W, 9 * Cc), dtype=torch.bfloat16, device=x.device)
     call("fluxmi_im2col3x3", _p(x), _p(col), B, H, W, Cc, upsample, _stream())
     return col

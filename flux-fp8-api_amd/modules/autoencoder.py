@@ -1,8 +1,9 @@
-"""VAE of the reference config schema (modules/autoencoder.py of aredden/flux-fp8-api) -- decoder on MI355X.
+"""VAE of the reference config schema (modules/autoencoder.py of aredden/flux-fp8-api) on MI355X.
 
-SURVEY.md §8(f) row 1: the step right after the denoise loop.  `AutoEncoder(params)` keeps the reference's module tree and
-state-dict keys for the DECODER (`decoder.conv_in`, `decoder.mid.block_1.norm1`, `decoder.up.3.block.0.conv1`,
-`decoder.up.1.upsample.conv`, ... so a BFL `ae.sft` loads with `load_state_dict(strict=False)`); `decode(z)` runs natively:
+SURVEY.md §8(f) row 1: `decode` is the step right after the denoise loop, `encode` the img2img entry before it.  `AutoEncoder(params)`
+keeps the reference's module tree and state-dict keys (`decoder.conv_in`, `decoder.mid.block_1.norm1`, `decoder.up.3.block.0.conv1`,
+`decoder.up.1.upsample.conv`, `encoder.down.0.downsample.conv`, ... so a BFL `ae.sft` loads with `load_state_dict`); both directions
+run natively:
 
   * activations NHWC bf16; 3x3 convolutions = `fluxmi_im2col3x3` (the 2x nearest upsample folded into the gather) + the bf16 MFMA
     GEMM with the weight reordered once to [Cout][dy][dx][Cin]; 1x1 convolutions are plain GEMMs; residual adds ride in the GEMM's
@@ -12,7 +13,10 @@ state-dict keys for the DECODER (`decoder.conv_in`, `decoder.mid.block_1.norm1`,
   * the single 512-wide attention head of mid.attn_1: S = Q K^T (GEMM) -> fp32 row softmax (`fluxmi_softmax_rows`) -> P V (GEMM against
     V^T, which the v-projection GEMM produces directly by swapping its operands; v's bias is added after P V, rows of P sum to 1).
 
-`encode` (img2img only) is not built; there is no CPU / PyTorch fallback.
+  * Downsample (encoder): the stride-2 window with zero pad on the right/bottom only is one more gather mode of `fluxmi_im2col3x3`;
+  * DiagonalGaussian: mean + exp(logvar/2) * noise on the [B, 2z, h, w] moments (a 128 KB tensor at 1024^2 -- torch elementwise).
+
+There is no CPU / PyTorch fallback.
 """
 from __future__ import annotations
 
@@ -60,6 +64,52 @@ class Upsample(nn.Module):  # reference :110-120
         self.conv = nn.Conv2d(c, c, kernel_size=3, stride=1, padding=1)
 
 
+class Downsample(nn.Module):  # reference :95-107 (stride 2, zero pad right/bottom only: AutoEncoder._conv3(mode=-2))
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, kernel_size=3, stride=2, padding=0)
+
+
+class Encoder(nn.Module):  # reference :123-174 (module tree / state-dict keys)
+    def __init__(self, resolution, in_channels, ch, ch_mult, num_res_blocks, z_channels):
+        super().__init__()
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.conv_in = nn.Conv2d(in_channels, ch, kernel_size=3, stride=1, padding=1)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block = nn.ModuleList()
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+            down = nn.Module()
+            down.block, down.attn = block, nn.ModuleList()
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in)
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in, block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in, block_in)
+        self.norm_out = _gn(block_in)
+        self.conv_out = nn.Conv2d(block_in, 2 * z_channels, kernel_size=3, stride=1, padding=1)
+
+
+class DiagonalGaussian(nn.Module):  # reference :286-299
+    def __init__(self, sample: bool = True, chunk_dim: int = 1):
+        super().__init__()
+        self.sample, self.chunk_dim = sample, chunk_dim
+
+    def forward(self, z: Tensor, noise: Tensor | None = None) -> Tensor:
+        mean, logvar = torch.chunk(z, 2, dim=self.chunk_dim)
+        if not self.sample:
+            return mean
+        std = torch.exp(0.5 * logvar.float())  # autocast runs exp in fp32; mean (bf16) + fp32 -> fp32
+        return mean + std * (torch.randn_like(mean) if noise is None else noise.to(mean.dtype))
+
+
 class Decoder(nn.Module):  # reference :203-259 (module tree / state-dict keys)
     def __init__(self, ch, out_ch, ch_mult, num_res_blocks, in_channels, resolution, z_channels):
         super().__init__()
@@ -90,9 +140,13 @@ class AutoEncoder(nn.Module):
     def __init__(self, params: AutoEncoderParams):
         super().__init__()
         self.params = params
+        self.encoder = Encoder(resolution=params.resolution, in_channels=params.in_channels, ch=params.ch, ch_mult=params.ch_mult,
+                               num_res_blocks=params.num_res_blocks, z_channels=params.z_channels)
+        self.reg = DiagonalGaussian()
         self.decoder = Decoder(resolution=params.resolution, in_channels=params.in_channels, ch=params.ch, out_ch=params.out_ch,
                                ch_mult=params.ch_mult, num_res_blocks=params.num_res_blocks, z_channels=params.z_channels)
         self.scale_factor, self.shift_factor = params.scale_factor, params.shift_factor
+        self.encoder_loaded = True  # util.load_autoencoder clears it for decoder-only checkpoints
         self._wcache = {}
 
     # ---- weight preparation (once per module): conv weight -> GEMM weight [N, K] bf16, K ordered (dy, dx, cin) --------------------
@@ -118,8 +172,9 @@ class AutoEncoder(nn.Module):
         if pad:
             x = torch.nn.functional.pad(x, (0, pad))
         B, Hi, Wi, _ = x.shape
-        col = ops.im2col3x3(x, upsample)
-        return self._gemm(col, w2, b, resid).view(B, Hi * upsample, Wi * upsample, -1)
+        col = ops.im2col3x3(x, upsample)  # upsample: 1 | 2 (nearest 2x first) | -2 (stride 2, right/bottom zero pad)
+        Ho, Wo = (Hi // 2, Wi // 2) if upsample == -2 else (Hi * upsample, Wi * upsample)
+        return self._gemm(col, w2, b, resid).view(B, Ho, Wo, -1)
 
     def _conv1(self, x: Tensor, conv: nn.Conv2d, resid: Tensor | None = None) -> Tensor:
         w2, b, _ = self._w(conv)
@@ -193,8 +248,35 @@ class AutoEncoder(nn.Module):
         h = self._conv3(self._norm(h, d.norm_out, True), d.conv_out)
         return h.permute(0, 3, 1, 2).contiguous()
 
-    def encode(self, x: Tensor) -> Tensor:
-        raise NotImplementedError("fluxmi: the VAE encoder (img2img, reference modules/autoencoder.py:123-200) is not built")
+    @torch.inference_mode()
+    def encode_moments(self, x: Tensor) -> Tensor:
+        """image [B, in_channels, H, W] in [-1, 1] -> moments [B, 2*z_channels, H/8, W/8] (bf16): Encoder.forward, reference :176-200."""
+        if not x.is_cuda:
+            raise RuntimeError("fluxmi: AutoEncoder.encode needs the GPU (libfluxmi has no CPU path)")
+        if not self.encoder_loaded:
+            raise RuntimeError("fluxmi: this autoencoder was loaded from a decoder-only checkpoint; encode() needs the encoder.* weights")
+        e = self.encoder
+        n_down = e.num_resolutions - 1
+        if x.shape[-2] % (1 << n_down) or x.shape[-1] % (1 << n_down):
+            raise ValueError(f"fluxmi: AutoEncoder.encode needs H and W to be multiples of {1 << n_down}")
+        h = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()  # NHWC
+        h = self._conv3(h, e.conv_in)
+        for i_level in range(e.num_resolutions):
+            for i_block in range(e.num_res_blocks):
+                h = self._resnet(h, e.down[i_level].block[i_block])
+            if i_level != e.num_resolutions - 1:
+                h = self._conv3(h, e.down[i_level].downsample.conv, upsample=-2)
+        h = self._resnet(h, e.mid.block_1)
+        h = self._attn(h, e.mid.attn_1)
+        h = self._resnet(h, e.mid.block_2)
+        h = self._conv3(self._norm(h, e.norm_out, True), e.conv_out)
+        return h.permute(0, 3, 1, 2).contiguous()
+
+    @torch.inference_mode()
+    def encode(self, x: Tensor, noise: Tensor | None = None) -> Tensor:
+        """reference :326-329: z = scale_factor * (reg(encoder(x)) - shift_factor); `noise` replaces the randn_like draw (tests)."""
+        z = self.reg(self.encode_moments(x), noise)
+        return self.scale_factor * (z - self.shift_factor)
 
     def forward(self, x: Tensor) -> Tensor:
         return self.decode(self.encode(x))

@@ -192,9 +192,9 @@ class LoadedModels(BaseModel):
 
 
 def load_autoencoder(config: ModelSpec, state_dict=None):
-    """reference util.py:269-296: AutoEncoder(config.ae_params) + weights from config.ae_path (a BFL `ae.sft`; `encoder.*` keys are
-    ignored, only the decoder is built natively) on config.ae_device in bf16.  Returns None when no weights are available (offline
-    runs): FluxPipeline.generate then returns latents."""
+    """reference util.py:269-296: AutoEncoder(config.ae_params) + weights from config.ae_path (a BFL `ae.sft`) on config.ae_device in
+    bf16.  A decoder-only state dict is accepted (`ae.encoder_loaded = False`: encode() then refuses to run on random weights).
+    Returns None when no weights are available (offline runs): FluxPipeline.generate then returns latents."""
     import os
 
     from modules.autoencoder import AutoEncoder
@@ -205,10 +205,10 @@ def load_autoencoder(config: ModelSpec, state_dict=None):
             return None
         state_dict = load_sft(path, device="cpu")
     ae = AutoEncoder(config.ae_params)
-    dec = {k: v for k, v in state_dict.items() if k.startswith("decoder.")}
-    missing, unexpected = ae.load_state_dict(dec, strict=False)
-    if missing:
-        raise RuntimeError(f"autoencoder checkpoint is missing decoder weights: {missing[:4]} ...")
+    missing, unexpected = ae.load_state_dict(state_dict, strict=False)
+    if any(k.startswith("decoder.") for k in missing):
+        raise RuntimeError(f"autoencoder checkpoint is missing decoder weights: {[k for k in missing if k.startswith('decoder.')][:4]} ...")
+    ae.encoder_loaded = not any(k.startswith("encoder.") for k in missing)
     return ae.to(device=into_device(config.ae_device), dtype=torch.bfloat16)
 
 

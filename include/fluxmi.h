@@ -150,10 +150,12 @@ int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, con
                           const void* VT, void* out, long long ld_out, int col_off, int out_fp8, const float* q_scale0,
                           const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream);
 
-/* ---- VAE decoder pieces (NHWC bf16) ------------------------------------------------------------ */
-/* 3x3 / stride 1 / pad 1 patch matrix: x [B, H/up, W/up, C] -> col [B*H*W, 9*C], column (dy*3+dx)*C + c; up = 2 folds the nearest
- * 2x upsample of Upsample.forward into the gather.  The convolution is then fluxmi_gemm_grouped(is_fp8=0) with the weight
- * reordered to [Cout][dy][dx][Cin].                                             modules/autoencoder.py:65-72,110-120,228,259 */
+/* ---- VAE pieces (NHWC bf16) -------------------------------------------------------------------- */
+/* 3x3 patch matrix: x [B, Hi, Wi, C] -> col [B*H*W, 9*C], column (dy*3+dx)*C + c, (H, W) = the OUTPUT grid.  `upsample`:
+ *   1  stride 1 / pad 1 (Hi = H);   2  nearest 2x upsample folded into the gather (Hi = H/2; Upsample.forward);
+ *  -2  stride 2 with zero pad on the right/bottom only (Hi = 2H; Downsample.forward).
+ * The convolution is then fluxmi_gemm_grouped(is_fp8=0) with the weight reordered to [Cout][dy][dx][Cin].
+ *                                                                            modules/autoencoder.py:65-72,95-120,228,259 */
 int fluxmi_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int upsample, void* stream);
 /* GroupNorm(32 groups, affine) in fp32 + optional swish, rounded to bf16 once; x, y [B, P, C]; work: float[(B*ceil(P/4096)+B)*64].
  *                                                                                modules/autoencoder.py:19-20,28-30,62-70,256 */

@@ -1,21 +1,22 @@
-"""CPU restatement of the reference VAE decoder (TEST INFRASTRUCTURE ONLY -- never imported by the product path).
+"""CPU restatement of the reference VAE decoder and encoder (TEST INFRASTRUCTURE ONLY -- never imported by the product path).
 
 Functional, state-dict driven torch code following modules/autoencoder.py of aredden/flux-fp8-api:
-  swish :19-20 | AttnBlock :23-52 | ResnetBlock :55-93 | Upsample :110-120 | Decoder :203-283 | AutoEncoder.decode :330-332
+  swish :19-20 | AttnBlock :23-52 | ResnetBlock :55-93 | Downsample :95-107 | Upsample :110-120 | Encoder :123-200 | Decoder :203-283 |
+  DiagonalGaussian :286-299 | AutoEncoder.encode / decode :326-332
 `autocast=True` reproduces what flux_pipeline.py:431-434 runs (torch.autocast(bf16) around ae.decode) with explicit casts:
 convolutions and SDPA see bf16 inputs/weights and return bf16; GroupNorm and the swish after it run in fp32.
-Pinned by oracle/gen_golden.py against the unmodified reference module (fp32: bit-equal; autocast: equal to the reference under
+Pinned by oracle/gen_golden_vae.py against the unmodified reference module (fp32: bit-equal; autocast: equal to the reference under
 torch.autocast("cpu", bfloat16) up to the CPU autocast policy) -> tests/golden/g8_vae.safetensors.
 """
 import torch
 import torch.nn.functional as F
 
 
-def _conv(sd, name, x, autocast, padding):
+def _conv(sd, name, x, autocast, padding, stride=1):
     w, b = sd[name + ".weight"], sd[name + ".bias"]
     if autocast:
-        return F.conv2d(x.to(torch.bfloat16), w.to(torch.bfloat16), b.to(torch.bfloat16), padding=padding)
-    return F.conv2d(x.float(), w.float(), b.float(), padding=padding)
+        return F.conv2d(x.to(torch.bfloat16), w.to(torch.bfloat16), b.to(torch.bfloat16), padding=padding, stride=stride)
+    return F.conv2d(x.float(), w.float(), b.float(), padding=padding, stride=stride)
 
 
 def _gn_swish(sd, name, x, swish=True):
@@ -57,3 +58,27 @@ def decode(sd, params, z, autocast=True):
             h = _conv(sd, f"decoder.up.{lvl}.upsample.conv", h, autocast, 1)
     h = _gn_swish(sd, "decoder.norm_out", h)
     return _conv(sd, "decoder.conv_out", h, autocast, 1)
+
+
+def encode_moments(sd, params, x, autocast=True):
+    """Encoder.forward (:176-200): [B, 3, H, W] -> [B, 2*z_channels, H/8, W/8] (mean | logvar)."""
+    nres = len(params["ch_mult"])
+    h = _conv(sd, "encoder.conv_in", x, autocast, 1)
+    for lvl in range(nres):
+        for ib in range(params["num_res_blocks"]):
+            h = resnet_block(sd, f"encoder.down.{lvl}.block.{ib}", h, autocast)
+        if lvl != nres - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)  # :104-105 (asymmetric: right / bottom only)
+            h = _conv(sd, f"encoder.down.{lvl}.downsample.conv", h, autocast, 0, stride=2)
+    h = resnet_block(sd, "encoder.mid.block_1", h, autocast)
+    h = attn_block(sd, "encoder.mid.attn_1", h, autocast)
+    h = resnet_block(sd, "encoder.mid.block_2", h, autocast)
+    h = _gn_swish(sd, "encoder.norm_out", h)
+    return _conv(sd, "encoder.conv_out", h, autocast, 1)
+
+
+def encode(sd, params, x, noise=None, autocast=True):
+    """AutoEncoder.encode (:326-329) with DiagonalGaussian (:292-299); `noise` stands in for torch.randn_like(mean) (None: mean only)."""
+    mean, logvar = torch.chunk(encode_moments(sd, params, x, autocast), 2, dim=1)
+    z = mean if noise is None else mean + torch.exp(0.5 * logvar.float()) * noise.to(mean.dtype)
+    return params["scale_factor"] * (z - params["shift_factor"])

@@ -173,3 +173,22 @@ def test_kohya_lora_keys_convert():
     assert set(out) == {"double_blocks.0.img_attn.qkv.lora_A.weight", "double_blocks.0.img_attn.qkv.lora_B.weight",
                         "double_blocks.0.img_attn.qkv.alpha", "single_blocks.11.linear2.lora_A.weight", "double_blocks.3.txt_mlp.2.lora_B.weight"}
     assert ll._keys_without_ab(out) == ["double_blocks.0.img_attn.qkv", "double_blocks.3.txt_mlp.2", "single_blocks.11.linear2"]
+
+
+def test_resize_center_crop_arithmetic():
+    """FluxPipeline.resize_center_crop restates torchvision's TF.resize(size=int) + TF.center_crop (reference flux_pipeline.py:450-457):
+    shorter edge -> min(width, height), long edge int(size * long / short), centred crop, zero pad where the resized image is smaller."""
+    import torch
+
+    from flux_pipeline import FluxPipeline
+
+    img = torch.arange(3 * 80 * 120, dtype=torch.float32).reshape(1, 3, 80, 120) / (3 * 80 * 120)
+    out = FluxPipeline.resize_center_crop(img, 96, 64)  # short edge 80 -> 64, long 120 -> 96; crop H 64 -> pad to 96
+    assert out.shape == (1, 3, 96, 64)
+    assert torch.all(out[..., :16, :] == 0) and torch.all(out[..., 80:, :] == 0) and out[..., 16:80, :].abs().sum() > 0
+    same = FluxPipeline.resize_center_crop(img, 80, 120)  # already the right size: untouched
+    assert torch.equal(same, img)
+    crop = FluxPipeline.resize_center_crop(img, 80, 100)  # short edge already 80: crop only, origin round((120 - 100) / 2) = 10
+    assert torch.equal(crop, img[..., :, 10:110])
+    up = FluxPipeline.resize_center_crop(img.to(torch.bfloat16), 160, 160)  # bf16 in -> fp32 bilinear -> bf16 out, 160 x 240 -> crop
+    assert up.shape == (1, 3, 160, 160) and up.dtype == torch.bfloat16

@@ -294,6 +294,87 @@ def test_vae_decoder_matches_reference_fixture(dev):
     assert rel(out, g["oracle_autocast"]) <= 1.5e-2
 
 
+def test_vae_encoder_matches_reference_fixture(dev):
+    """AutoEncoder.encode_moments / encode (native; Downsample = stride-2 gather mode of im2col) vs the
+    unmodified reference encoder's outputs in tests/golden/g8_vae.safetensors.  Tolerance: as close to the fp32 moments as the
+    reference's own bf16-autocast path is (x1.5); the sampled latent is checked with the reference's own noise draw."""
+    import os
+
+    from safetensors.torch import load_file
+
+    from modules.autoencoder import AutoEncoder, AutoEncoderParams
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_vae.safetensors"))
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    ae = AutoEncoder(AutoEncoderParams(resolution=32, in_channels=3, ch=32, out_ch=3, ch_mult=[1, 2], num_res_blocks=1, z_channels=4,
+                                       scale_factor=0.3611, shift_factor=0.1159))
+    ae.load_state_dict(sd, strict=True)
+    ae.to(dev)
+    x = g["enc_x"].to(dev)
+    mom = ae.encode_moments(x).float().cpu()
+    assert mom.shape == g["enc_moments_fp32"].shape and torch.isfinite(mom).all()
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    e_native, e_ref = rel(mom, g["enc_moments_fp32"]), rel(g["enc_moments_autocast"], g["enc_moments_fp32"])
+    print(f"VAE encode: native vs fp32 reference {e_native:.3e}; reference autocast vs fp32 {e_ref:.3e}; native vs oracle-autocast "
+          f"{rel(mom, g['enc_oracle_moments_autocast']):.3e}")
+    assert e_native <= 1.5 * e_ref
+    assert rel(mom, g["enc_oracle_moments_autocast"]) <= 2e-2
+    z = ae.encode(x, noise=g["enc_noise"].to(dev)).float().cpu()
+    assert z.shape == g["enc_encode_fp32"].shape
+    assert rel(z, g["enc_encode_fp32"]) <= 1.5 * e_ref + 1e-3
+    # the default path draws its own noise: same mean, different sample
+    z2 = ae.encode(x).float().cpu()
+    assert z2.shape == z.shape and torch.isfinite(z2).all() and not torch.equal(z2, z)
+    # decoder-only checkpoints refuse to encode on random weights
+    ae.encoder_loaded = False
+    with pytest.raises(RuntimeError):
+        ae.encode(x)
+
+
+def test_pipeline_img2img_through_vae_encoder(dev):
+    """generate(init_image=..., strength=...) on the drop-in surface (reference flux_pipeline.py:459-523, 583-603): the init image is
+    resized / centre-cropped, VAE-encoded natively, blended with the noise at t = timesteps[int((1 - strength) * num_steps)] and the
+    loop runs only the remaining steps."""
+    import io
+
+    import numpy as np
+    from PIL import Image
+
+    from flux_pipeline import FluxPipeline
+    from fluxmi import synth
+    from modules.autoencoder import AutoEncoder, AutoEncoderParams
+
+    cfg = tiny_config()
+    cfg.text_enc_max_length = 32
+    cfg.ae_device = str(dev)
+    cfg.ae_params = AutoEncoderParams(resolution=32, in_channels=3, ch=32, out_ch=3, ch_mult=[1, 2, 2, 2], num_res_blocks=1, z_channels=16,
+                                      scale_factor=0.3611, shift_factor=0.1159)
+    torch.manual_seed(0)
+    ae_sd = {k: v.clone() for k, v in AutoEncoder(cfg.ae_params).state_dict().items()}
+    pipe = FluxPipeline.load_pipeline_from_config(cfg, state_dict=synth.make_state_dict(cfg.params, seed=0), ae_state_dict=ae_sd)
+    assert pipe.ae is not None and pipe.ae.encoder_loaded
+    pipe.compile()
+    g = torch.Generator().manual_seed(1)
+    prompt = {"txt": 0.1 * torch.randn(1, 32, 128, generator=g), "vec": torch.randn(1, 64, generator=g)}
+    rng = np.random.default_rng(0)
+    init = rng.integers(0, 256, size=(80, 120, 3), dtype=np.uint8)  # HWC, needs resize + crop to 96 x 64
+    # schedule / blend bookkeeping
+    x, ts = pipe.preprocess_latent(init_image=torch.from_numpy(init), height=96, width=64, num_steps=8, strength=0.5,
+                                   generator=torch.Generator(device=dev).manual_seed(3), num_images=2)
+    full = pipe.get_schedule(8, 12 * 8 // 4, shift=True)
+    assert x.shape == (2, 16, 12, 8) and len(ts) == len(full) - 4 and ts[0] == full[4]
+    # strength 1.0 -> the init image has no weight: identical to txt2img noise
+    x1, ts1 = pipe.preprocess_latent(init_image=torch.from_numpy(init), height=96, width=64, num_steps=8, strength=1.0,
+                                     generator=torch.Generator(device=dev).manual_seed(3), num_images=1)
+    x0, ts0 = pipe.preprocess_latent(height=96, width=64, num_steps=8, generator=torch.Generator(device=dev).manual_seed(3), num_images=1)
+    assert ts1 == ts0 and torch.equal(x1, x0)
+    for src in (init, Image.fromarray(init), torch.from_numpy(init)):
+        buf = pipe.generate(prompt, width=64, height=96, num_steps=8, seed=7, silent=True, init_image=src, strength=0.5)
+        assert isinstance(buf, io.BytesIO)
+        im = Image.open(buf)
+        assert im.size == (64, 96) and im.mode == "RGB"
+
+
 def test_pipeline_generate_jpeg_through_vae(dev):
     """generate() end to end on the drop-in surface: denoise loop -> unpack -> native VAE decode -> JPEG bytes
     (reference flux_pipeline.py:619-663, 423-448, 373-421)."""

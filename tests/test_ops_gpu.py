@@ -510,9 +510,9 @@ def test_lora_fuse(ops, dev):
 
 
 # ---- VAE decoder pieces -----------------------------------------------------------------------------
-@pytest.mark.parametrize("up", [1, 2])
+@pytest.mark.parametrize("up", [1, 2, -2])
 def test_im2col3x3(ops, dev, up):
-    """Patch matrix == F.unfold of the (optionally nearest-upsampled) NCHW image, columns reordered (dy, dx, c)."""
+    """Patch matrix == F.unfold of the (nearest-upsampled / right-bottom-padded, stride 2) NCHW image, columns reordered (dy, dx, c)."""
     torch.manual_seed(31)
     B, Hi, Wi, C = 2, 6, 10, 16
     x = torch.randn(B, Hi, Wi, C).bfloat16()
@@ -520,6 +520,11 @@ def test_im2col3x3(ops, dev, up):
     xn = x.permute(0, 3, 1, 2).float()
     if up == 2:
         xn = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    if up == -2:  # Downsample.forward, reference modules/autoencoder.py:103-107
+        H, W = Hi // 2, Wi // 2
+        ref = F.unfold(F.pad(xn, (0, 1, 0, 1)), kernel_size=3, stride=2).view(B, C, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * C)
+        assert torch.equal(col.float(), ref)
+        return
     H, W = Hi * up, Wi * up
     ref = F.unfold(xn, kernel_size=3, padding=1).view(B, C, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * C)
     assert torch.equal(col.float(), ref)

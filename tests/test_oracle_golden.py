@@ -171,3 +171,23 @@ def test_g8_vae_decoder_oracle_matches_reference_fixture():
     assert torch.equal(oac.float(), g["oracle_autocast"])
     rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
     assert rel(oac, g["ref_fp32"]) <= 1.5 * rel(g["ref_autocast"], g["ref_fp32"])
+
+
+def test_g8_vae_encoder_oracle_matches_reference_fixture():
+    """oracle/vae_oracle.py encode_moments / encode (restatement of modules/autoencoder.py:95-107,
+    123-200,286-299,326-329) vs the unmodified reference: fp32 moments and the sampled latent (same randn draw) bit-equal."""
+    import vae_oracle as vo
+
+    g = load("g8_vae")
+    sd = {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    P = dict(ch_mult=[1, 2], num_res_blocks=1, scale_factor=0.3611, shift_factor=0.1159)
+    with torch.no_grad():
+        m32 = vo.encode_moments(sd, P, g["enc_x"], autocast=False)
+        mac = vo.encode_moments(sd, P, g["enc_x"], autocast=True)
+        e32 = vo.encode(sd, P, g["enc_x"], noise=g["enc_noise"], autocast=False)
+    assert m32.shape == (2, 8, 16, 16)
+    assert torch.equal(m32, g["enc_moments_fp32"])
+    assert torch.equal(e32, g["enc_encode_fp32"])
+    assert torch.equal(mac.float(), g["enc_oracle_moments_autocast"])
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    assert rel(mac, g["enc_moments_fp32"]) <= 1.5 * rel(g["enc_moments_autocast"], g["enc_moments_fp32"])
