@@ -242,6 +242,17 @@ int fluxmi_groupnorm(const void* x, const void* gamma, const void* beta, void* y
 int fluxmi_softmax_rows(const void* S, void* P, int rows, int cols, long long ld, float scale, void* stream) {
   return fluxmi_k_softmax_rows(S, P, rows, cols, ld, scale, (hipStream_t)stream);
 }
+int fluxmi_row_norm(const void* x, const void* weight, const void* bias, void* y, int rows, int D, long long ldx, long long ldy, float eps, int mode,
+                    void* stream) {
+  return fluxmi_k_row_norm(x, weight, bias, y, rows, D, ldx, ldy, eps, mode, (hipStream_t)stream);
+}
+int fluxmi_act_mul(const void* in, void* out, int rows, int F, long long ld_in, long long ld_out, int mode, void* stream) {
+  return fluxmi_k_act_mul(in, out, rows, F, ld_in, ld_out, mode, (hipStream_t)stream);
+}
+int fluxmi_text_attention(const void* q, const void* k, long long ld_qk, const void* vt, long long ld_vt, void* out, long long ld_out,
+                          const float* rel_bias, int bias_ld, const void* v_bias, float scale, int causal, int L, int Lp, int H, void* stream) {
+  return fluxmi_k_text_attention(q, k, ld_qk, vt, ld_vt, out, ld_out, rel_bias, bias_ld, v_bias, scale, causal, L, Lp, H, (hipStream_t)stream);
+}
 int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void* stream) {
   return fluxmi_k_build_qlut(scale, fmt, act, lut, (hipStream_t)stream);
 }

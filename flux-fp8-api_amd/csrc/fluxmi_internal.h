@@ -96,6 +96,11 @@ int fluxmi_k_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int
 int fluxmi_k_groupnorm(const void* x, const void* gamma, const void* beta, void* y, float* work, int B, int P, int C, int swish, float eps,
                        hipStream_t s);
 int fluxmi_k_softmax_rows(const void* S, void* P, int rows, int cols, long long ld, float scale, hipStream_t s);
+int fluxmi_k_row_norm(const void* x, const void* w, const void* b, void* y, int rows, int D, long long ldx, long long ldy, float eps, int mode,
+                      hipStream_t s);
+int fluxmi_k_act_mul(const void* in, void* out, int rows, int F, long long ld_in, long long ld_out, int mode, hipStream_t s);
+int fluxmi_k_text_attention(const void* q, const void* k, long long ld_qk, const void* vt, long long ld_vt, void* out, long long ld_out,
+                            const float* rel_bias, int bias_ld, const void* v_bias, float scale, int causal, int L, int Lp, int H, hipStream_t s);
 int fluxmi_k_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0,
                       const void* q_scale1, const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H,
                       int split, hipStream_t s);

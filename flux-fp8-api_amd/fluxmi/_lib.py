@@ -73,6 +73,9 @@ _SIGS = {
     "fluxmi_im2col3x3": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_groupnorm": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp], i32),
     "fluxmi_softmax_rows": ([vp, vp, i32, i32, i64, C.c_float, vp], i32),
+    "fluxmi_row_norm": ([vp, vp, vp, vp, i32, i32, i64, i64, C.c_float, i32, vp], i32),
+    "fluxmi_act_mul": ([vp, vp, i32, i32, i64, i64, i32, vp], i32),
+    "fluxmi_text_attention": ([vp, vp, i64, vp, i64, vp, i64, vp, i32, vp, C.c_float, i32, i32, i32, i32, vp], i32),
     "fluxmi_attention": ([vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_attention_rawq": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_timestep_embedding": ([vp, vp, vp, i32, i32, f32, vp], i32),

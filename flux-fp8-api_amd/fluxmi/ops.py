@@ -304,3 +304,45 @@ def softmax_rows(S: torch.Tensor, scale: float) -> torch.Tensor:
     P = torch.empty_like(S)
     call("fluxmi_softmax_rows", _p(S), _p(P), S.shape[0], S.shape[1], S.stride(0), float(scale), _stream())
     return P
+
+
+# ---- text-conditioning encoder pieces (bf16) ------------------------------------------------------------------------------
+def row_norm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, eps: float = 1e-6, rms: bool = True) -> torch.Tensor:
+    """x [rows, D] bf16.  rms=True: T5LayerNorm (no mean / bias, weight applied after a bf16 rounding); else LayerNorm."""
+    _req(x, torch.bfloat16, "x")
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.bfloat16, device=x.device)
+    call("fluxmi_row_norm", _p(x), _p(weight), _p(bias) if bias is not None else None, _p(y), x.shape[0], x.shape[1], x.stride(0), y.stride(0),
+         float(eps), 0 if rms else 1, _stream())
+    return y
+
+
+def act_mul(x: torch.Tensor, gated: bool) -> torch.Tensor:
+    """gated: x [rows, 2F] = [a | b] -> bf16(gelu_new(a)) * b [rows, F];  else quick_gelu(x)."""
+    _req(x, torch.bfloat16, "x")
+    x = x.contiguous()
+    F_ = x.shape[1] // 2 if gated else x.shape[1]
+    out = torch.empty((x.shape[0], F_), dtype=torch.bfloat16, device=x.device)
+    call("fluxmi_act_mul", _p(x), _p(out), x.shape[0], F_, x.stride(0), out.stride(0), 0 if gated else 1, _stream())
+    return out
+
+
+def text_attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, L: int, heads: int, scale: float = 1.0, causal: bool = False,
+                   rel_bias: Optional[torch.Tensor] = None, v_bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q, k [Lp, >= heads*64] (views with the same row stride), vt [heads*64, Lp] -> out [Lp, heads*64]; see include/fluxmi.h."""
+    _req(q, torch.bfloat16, "q")
+    _req(k, torch.bfloat16, "k")
+    _req(vt, torch.bfloat16, "vt")
+    Lp = q.shape[0]
+    if q.stride(0) != k.stride(0) or q.stride(1) != 1 or k.stride(1) != 1 or vt.stride(1) != 1:
+        raise ValueError("text_attention: q and k must share the row stride; innermost strides must be 1")
+    if out is None:
+        out = torch.zeros((Lp, heads * 64), dtype=torch.bfloat16, device=q.device)
+    if rel_bias is not None:
+        _req(rel_bias, torch.float32, "rel_bias")
+        rel_bias = rel_bias.contiguous()
+    call("fluxmi_text_attention", _p(q), _p(k), q.stride(0), _p(vt), vt.stride(0), _p(out), out.stride(0),
+         _p(rel_bias) if rel_bias is not None else None, rel_bias.shape[1] if rel_bias is not None else 0,
+         _p(v_bias) if v_bias is not None else None, float(scale), int(causal), int(L), Lp, heads, _stream())
+    return out

@@ -164,6 +164,23 @@ int fluxmi_groupnorm(const void* x, const void* gamma, const void* beta, void* y
 /* P[r,:] = softmax(scale * S[r,:]) (fp32 inside), bf16 [rows, cols], row stride ld            modules/autoencoder.py:47 */
 int fluxmi_softmax_rows(const void* S, void* P, int rows, int cols, long long ld, float scale, void* stream);
 
+/* ---- text-conditioning encoder pieces (bf16) ------------------------------------------------------------
+ * The reference runs transformers' T5EncoderModel / CLIPTextModel (modules/conditioner.py:74-117, flux_emphasis.py:420-429); their
+ * Linear layers map to fluxmi_gemm_grouped(is_fp8=0), the rest to the three entry points below. */
+/* mode 0: T5LayerNorm  y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps)))  (bias ignored);  mode 1: LayerNorm  y = bf16((x - mean) * rstd * w + b).
+ * x, y [rows, D] bf16 with row strides ldx, ldy; fp32 statistics. */
+int fluxmi_row_norm(const void* x, const void* weight, const void* bias, void* y, int rows, int D, long long ldx, long long ldy, float eps, int mode,
+                    void* stream);
+/* mode 0: in [rows, 2F] = [a | b] -> out [rows, F] = bf16(bf16(gelu_new(a)) * b)   (T5 v1.1 gated FF: wi_0 / wi_1 fused into one GEMM)
+ * mode 1: in [rows, F] -> out = bf16(a * sigmoid(1.702 a))                          (CLIP quick_gelu) */
+int fluxmi_act_mul(const void* in, void* out, int rows, int F, long long ld_in, long long ld_out, int mode, void* stream);
+/* Self-attention with head_dim 64 for one sequence: q, k [Lp, ld_qk] (head h at columns h*64..), vt [H*64, ld_vt] = V transposed
+ * (row h*64+d, column = key; keys >= L are ignored), out [Lp, ld_out] (rows < L written).  logits = scale * q.k
+ * + rel_bias[h][key - query + bias_ld/2] (fp32 [H, bias_ld], NULL = none; T5's bucketed relative-position bias) with keys > query
+ * masked when causal (CLIP); fp32 softmax, P rounded to bf16, out = P V + v_bias (bf16 [H*64] or NULL).  Lp %% 32 == 0. */
+int fluxmi_text_attention(const void* q, const void* k, long long ld_qk, const void* vt, long long ld_vt, void* out, long long ld_out,
+                          const float* rel_bias, int bias_ld, const void* v_bias, float scale, int causal, int L, int Lp, int H, void* stream);
+
 /* ---- step scalars -------------------------------------------------------------------------------------- */
 /* timestep_embedding(t, 2*half) with host-provided frequency table                 flux_model.py:95-116 */
 int fluxmi_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, void* stream);

@@ -6,6 +6,7 @@ reachable from the product path and nothing here exists on the GPU box.
 
 Why shims are needed:
   * `loguru` is not installed            -> stub module exposing a no-op `logger`
+  * `pydash` is not installed            -> stub module exposing `flatten` (one level, what flux_emphasis.py:380-383,416 uses)
   * float8_quantize.py:19-23 raises unless torch.version.cuda >= 12.4; on a ROCm wheel it is None
                                            -> set torch.version.cuda = "12.4" before importing
 """
@@ -27,6 +28,13 @@ def install():
         m = types.ModuleType("loguru")
         m.logger = _NullLogger()
         sys.modules["loguru"] = m
+    if "pydash" not in sys.modules:
+        try:
+            import pydash  # noqa: F401
+        except ImportError:
+            m = types.ModuleType("pydash")
+            m.flatten = lambda xs: [y for x in xs for y in (x if isinstance(x, (list, tuple)) else [x])]
+            sys.modules["pydash"] = m
     if not torch.version.cuda:
         torch.version.cuda = "12.4"
     if REFERENCE_ROOT not in sys.path:

@@ -551,3 +551,68 @@ def test_softmax_rows(ops, dev):
     ref = torch.softmax(S.float() * 0.125, dim=-1).bfloat16()
     got = ops.softmax_rows(S.to(dev), 0.125).cpu()
     assert_bf16_close(got, ref, max_ulp=1, min_exact=0.99, what="softmax rows")
+
+
+# ---- text-conditioning encoder pieces -----------------------------------------------------------------
+@pytest.mark.parametrize("D,rms", [(64, True), (4096, True), (768, False), (128, False)])
+def test_row_norm(ops, dev, D, rms):
+    """T5LayerNorm (fp32 variance, bf16 rounding before the weight) / LayerNorm with the rounding points of the HF modules in bf16."""
+    torch.manual_seed(41)
+    x = (torch.randn(37, D) * 3 + (0.0 if rms else 1.5)).bfloat16()
+    w = (1 + 0.2 * torch.randn(D)).bfloat16()
+    b = (0.1 * torch.randn(D)).bfloat16()
+    if rms:
+        h = (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6)).bfloat16()
+        ref = w * h
+    else:
+        ref = F.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5).bfloat16()
+    got = ops.row_norm(x.to(dev), w.to(dev), None if rms else b.to(dev), eps=1e-6 if rms else 1e-5, rms=rms).cpu()
+    assert_bf16_close(got, ref, max_ulp=1, min_exact=0.98, what=f"row_norm D={D} rms={rms}")
+
+
+def test_act_mul(ops, dev):
+    torch.manual_seed(42)
+    x = (torch.randn(50, 512) * 2).bfloat16()
+    a, b = x[:, :256].float(), x[:, 256:].float()
+    gelu = (0.5 * a * (1.0 + torch.tanh(0.7978845608028654 * (a + 0.044715 * a ** 3)))).bfloat16()
+    assert_bf16_close(ops.act_mul(x.to(dev), gated=True).cpu(), (gelu.float() * b).bfloat16(), max_ulp=1, min_exact=0.97, what="gated gelu_new")
+    q = (x.float() * torch.sigmoid(1.702 * x.float())).bfloat16()
+    assert_bf16_close(ops.act_mul(x.to(dev), gated=False).cpu(), q, max_ulp=1, min_exact=0.98, what="quick_gelu")
+
+
+@pytest.mark.parametrize("L,H,causal", [(40, 3, False), (512, 4, False), (77, 2, True), (32, 1, True)])
+def test_text_attention(ops, dev, L, H, causal):
+    """head_dim-64 attention of the text encoders vs fp32 math on the same bf16 inputs: T5 style (no scaling, additive
+    relative-position bias as a function of key - query, no mask) and CLIP style (1/sqrt(d), causal mask, v bias added after P V)."""
+    torch.manual_seed(43)
+    Lp = (L + 31) // 32 * 32
+    qk = torch.zeros(Lp, 2 * H * 64)
+    qk[:L] = torch.randn(L, 2 * H * 64) * (0.35 if not causal else 1.0)
+    qk = qk.bfloat16()
+    v = torch.zeros(Lp, H * 64)
+    v[:L] = torch.randn(L, H * 64)
+    v = v.bfloat16()
+    vb = (0.3 * torch.randn(H * 64)).bfloat16() if causal else None
+    rel = None if causal else torch.randn(H, 2 * Lp)
+    scale = 0.125 if causal else 1.0
+    q, k = qk[:, : H * 64], qk[:, H * 64:]
+    qh, kh, vh = (t[:L].float().view(L, H, 64).transpose(0, 1) for t in (q, k, v))
+    s = torch.matmul(qh, kh.transpose(-1, -2)) * scale
+    if rel is not None:
+        pos = torch.arange(L)
+        s = s + rel[:, (pos[None, :] - pos[:, None]) + Lp]
+    if causal:
+        s = s + torch.full((L, L), float("-inf")).triu(1)
+    p = torch.softmax(s, -1).bfloat16().float()
+    o = torch.matmul(p, vh)
+    if vb is not None:
+        o = o.bfloat16().float() + vb.float().view(H, 1, 64)
+    ref = o.transpose(0, 1).reshape(L, H * 64)
+    d = lambda t: t.to(dev)
+    qkd = d(qk)
+    got = ops.text_attention(qkd[:, : H * 64], qkd[:, H * 64:], d(v.t().contiguous()), L, H, scale=scale, causal=causal,
+                             rel_bias=d(rel) if rel is not None else None, v_bias=d(vb) if vb is not None else None).cpu()
+    assert torch.all(got[L:] == 0)
+    err = (got[:L].float() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs().clamp(min=0.05) + 4e-3  # one bf16 ulp of the output + the bf16 rounding of P (<= 2^-9 relative per term)
+    assert bool((err <= tol).all()), f"text attention L={L} H={H} causal={causal}: max err {err.max():.3e} (ref max {ref.abs().max():.2f})"
