@@ -7,9 +7,10 @@ Same public names / kwargs / defaults as the reference: FluxPipeline.load_pipeli
 load_pipeline_from_config / generate / load_lora / unload_lora / compile / set_seed / get_schedule /
 get_noise / prepare / unpack / vae_decode / into_bytes / load_init_image_if_needed / resize_center_crop / preprocess_latent.
 
-SURVEY.md §8f row 1 is built around it: the native VAE decoder (latents -> JPEG) and encoder (img2img: `init_image`, `strength`).
-Not built (§8f row 2): T5/CLIP text conditioning -- `generate()` takes the conditioning as pre-computed embeddings
-(`prompt={"txt": [B,Lt,4096], "vec": [B,768]}`); it returns latents when no autoencoder is attached.  CPU-offload flags are accepted
+SURVEY.md §8f rows 1-2 are built around it: the native VAE decoder (latents -> JPEG) and encoder (img2img: `init_image`, `strength`),
+and the text conditioning (flux_emphasis.py prompt weighting over the native T5 / CLIP encoders of modules/conditioner.py) when
+`config.text_enc_path` / `clip_path` point at local HF-layout directories.  Without them `generate()` takes the conditioning as
+pre-computed embeddings (`prompt={"txt": [B,Lt,4096], "vec": [B,768]}`); it returns latents when no autoencoder is attached.  CPU-offload flags are accepted
 and ignored (meaningless with 288 GB of HBM).  `compile()` keeps the reference's warm-up/calibration protocol
 (flux_pipeline.py:197-212) but never calls torch.compile: the fused kernels + hipGraph replace it.
 """
@@ -191,10 +192,16 @@ class FluxPipeline:
             if txt.shape[0] == 1 and bs > 1:
                 txt, vec = txt.expand(bs, -1, -1), vec.expand(bs, -1)
         elif self.t5 is not None and self.clip is not None:
-            raise NotImplementedError("T5/CLIP text conditioning is a SURVEY.md §8(f) 'next' row")
+            from flux_emphasis import get_weighted_text_embeddings_flux
+
+            if not isinstance(prompt, str):  # the reference sizes the batch by len(prompt) but embeds the list as one prompt; be explicit
+                raise TypeError("fluxmi: prompt must be a str (one prompt, `num_images` copies) or a dict of pre-computed embeddings")
+            vec, txt, txt_ids = get_weighted_text_embeddings_flux(self, prompt, num_images_per_prompt=bs, device=self.device_clip,
+                                                                  target_device=target_device, target_dtype=target_dtype, debug=self.debug)
+            return tokens, img_ids, vec, txt, txt_ids
         else:
-            raise NotImplementedError(
-                "fluxmi: no text encoders attached (SURVEY.md §8f row 2). Pass prompt={'txt': T5 states [B,Lt,4096], 'vec': CLIP pooled [B,768]}.")
+            raise RuntimeError("fluxmi: no text encoders attached (config.text_enc_path / clip_path not found). Pass "
+                               "prompt={'txt': T5 states [B,Lt,4096], 'vec': CLIP pooled [B,768]} or load the encoders.")
         txt_ids = torch.zeros(bs, txt.shape[1], 3, device=target_device, dtype=target_dtype)
         return tokens, img_ids, vec, txt, txt_ids
 
@@ -277,19 +284,22 @@ class FluxPipeline:
             config = load_config_from_path(path)
             if flow_model_path:
                 config.ckpt_path = flow_model_path
-            state_dict = kwargs.pop("state_dict", None)
-            ae_state_dict = kwargs.pop("ae_state_dict", None)
+            extra = {k: kwargs.pop(k, None) for k in ("state_dict", "ae_state_dict", "clip_kwargs", "t5_kwargs")}
             for k, v in kwargs.items():
                 if hasattr(config, k):
                     setattr(config, k, v)
-            return cls.load_pipeline_from_config(config, debug=debug, state_dict=state_dict, ae_state_dict=ae_state_dict)
+            return cls.load_pipeline_from_config(config, debug=debug, **extra)
 
     @classmethod
-    def load_pipeline_from_config(cls, config: ModelSpec, debug: bool = False, state_dict=None, ae_state_dict=None) -> "FluxPipeline":
+    def load_pipeline_from_config(cls, config: ModelSpec, debug: bool = False, state_dict=None, ae_state_dict=None, clip_kwargs=None,
+                                  t5_kwargs=None) -> "FluxPipeline":
+        """`state_dict` / `ae_state_dict` / `clip_kwargs` / `t5_kwargs` are offline hooks (weights, HF configs and tokenizers handed over in
+        memory instead of read from the config's paths)."""
         from float8_quantize import quantize_flow_transformer_and_dispatch_float8
 
         with torch.inference_mode():
-            models = load_models_from_config(config, state_dict=state_dict, ae_state_dict=ae_state_dict)
+            models = load_models_from_config(config, state_dict=state_dict, ae_state_dict=ae_state_dict, clip_kwargs=clip_kwargs,
+                                             t5_kwargs=t5_kwargs)
             config = models.config
             flux_device = into_device(config.flux_device)
             flux_dtype = into_dtype(config.flow_dtype)

@@ -212,9 +212,32 @@ def load_autoencoder(config: ModelSpec, state_dict=None):
     return ae.to(device=into_device(config.ae_device), dtype=torch.bfloat16)
 
 
-def load_models_from_config(config: ModelSpec, state_dict=None, ae_state_dict=None) -> LoadedModels:
-    """reference util.py:325-333; the text encoders are a SURVEY.md §8(f) 'next' row -> None here."""
-    return LoadedModels(flow=load_flow_model(config, state_dict), ae=load_autoencoder(config, ae_state_dict), clip=None, t5=None, config=config)
+def load_text_encoders(config: ModelSpec, clip_kwargs=None, t5_kwargs=None):
+    """reference util.py:262-280: (clip, t5) HFEmbedders -- CLIP at max_length 77, T5 at config.text_enc_max_length -- on
+    config.text_enc_device.  `config.clip_path` / `text_enc_path` must be local HF-layout directories (no network here); when either
+    is absent, or no `*_kwargs` offline hooks (hf_config / state_dict / tokenizer) are given, returns (None, None): the pipeline then
+    expects pre-computed embeddings."""
+    import os
+
+    from modules.conditioner import HFEmbedder
+
+    def have(path, kw):
+        return kw is not None or (isinstance(path, str) and os.path.isdir(path))
+
+    if not (have(config.clip_path, clip_kwargs) and have(config.text_enc_path, t5_kwargs)):
+        return None, None
+    dev = into_device(config.text_enc_device)
+    clip = HFEmbedder(config.clip_path, max_length=77, torch_dtype=into_dtype(config.text_enc_dtype), device=dev, is_clip=True,
+                      quantization_dtype=config.clip_quantization_dtype, **(clip_kwargs or {}))
+    t5 = HFEmbedder(config.text_enc_path, max_length=config.text_enc_max_length, torch_dtype=into_dtype(config.text_enc_dtype), device=dev,
+                    quantization_dtype=config.text_enc_quantization_dtype, **(t5_kwargs or {}))
+    return clip, t5
+
+
+def load_models_from_config(config: ModelSpec, state_dict=None, ae_state_dict=None, clip_kwargs=None, t5_kwargs=None) -> LoadedModels:
+    """reference util.py:325-333."""
+    clip, t5 = load_text_encoders(config, clip_kwargs, t5_kwargs)
+    return LoadedModels(flow=load_flow_model(config, state_dict), ae=load_autoencoder(config, ae_state_dict), clip=clip, t5=t5, config=config)
 
 
 def load_models_from_config_path(path: str) -> LoadedModels:

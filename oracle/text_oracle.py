@@ -38,7 +38,7 @@ def t5_relative_position_bucket(relative_position, num_buckets=32, max_distance=
 
 def t5_position_bias(table, L, num_buckets=32, max_distance=128):
     """table [num_buckets, H] (encoder.block.0...relative_attention_bias.weight) -> bias [H, L, L] (query, key)."""
-    pos = torch.arange(L)
+    pos = torch.arange(L, device=table.device)
     bucket = t5_relative_position_bucket(pos[None, :] - pos[:, None], num_buckets, max_distance)
     return table[bucket].permute(2, 0, 1)
 
@@ -89,7 +89,7 @@ def clip_text(sd, cfg, input_ids, dtype=torch.float32):
     x = g("embeddings.token_embedding.weight")[input_ids] + g("embeddings.position_embedding.weight")[:L][None]
     D = x.shape[-1]
     dh = D // H
-    causal = torch.full((L, L), float("-inf")).triu(1).to(dtype)
+    causal = torch.full((L, L), float("-inf"), device=input_ids.device).triu(1).to(dtype)
     for i in range(cfg["num_layers"]):
         p = f"encoder.layers.{i}."
         h = F.layer_norm(x, (D,), g(p + "layer_norm1.weight"), g(p + "layer_norm1.bias"), eps)
@@ -108,7 +108,7 @@ def clip_text(sd, cfg, input_ids, dtype=torch.float32):
         idx = input_ids.to(torch.int).argmax(-1)
     else:
         idx = (input_ids.to(torch.int) == cfg["eos_token_id"]).int().argmax(-1)
-    return x, x[torch.arange(B), idx]
+    return x, x[torch.arange(B, device=x.device), idx]
 
 
 # ---- prompt weighting (flux_emphasis.py:267-304) -----------------------------------------------------------------------------------
