@@ -97,6 +97,8 @@ class F8Linear(nn.Module):
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
+        if self.input_amax_trials.is_meta:
+            self.input_amax_trials = torch.zeros(self.num_scale_trials, dtype=torch.float32)
         self.input_amax_trials = fn(self.input_amax_trials)
         if self._amax_tmp is not None:
             self._amax_tmp = fn(self._amax_tmp)
@@ -212,6 +214,8 @@ class F8Linear(nn.Module):
             self.input_scale_reciprocal = sd["input_scale_reciprocal"].float().reshape(()).to(dev).clone()
             self.input_scale_initialized = True
             self.trial_index = self.num_scale_trials
+            if self.input_amax_trials.is_meta:  # module built under torch.device("meta") (util.load_flow_model): not part of the state dict
+                self.input_amax_trials = torch.zeros(self.num_scale_trials, dtype=torch.float32, device=dev)
         else:
             self.input_scale_initialized = False
             self.trial_index = 0

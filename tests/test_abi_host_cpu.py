@@ -137,6 +137,11 @@ def test_prequantized_state_dict_format():
     lin.load_state_dict(sd, assign=True)
     assert lin.weight_initialized and lin.input_scale_initialized and lin.trial_index == lin.num_scale_trials
     assert lin.scale.item() == 3.0 and lin.input_scale.item() == 5.0 and lin.weight.shape == (1,)
+    with torch.device("meta"):  # util.load_flow_model builds the model on meta and assigns the checkpoint tensors
+        lm = F8Linear(16, 8, bias=True, dtype=torch.bfloat16)
+    lm.load_state_dict(sd, assign=True)
+    lm.to("cpu")
+    assert not lm.input_amax_trials.is_meta and all(not t.is_meta for t in list(lm.parameters()) + list(lm.buffers()))
     lin2 = F8Linear(16, 8, bias=True, dtype=torch.bfloat16)
     del sd["input_scale"], sd["input_scale_reciprocal"]
     lin2.load_state_dict(sd, assign=True)
@@ -192,3 +197,58 @@ def test_resize_center_crop_arithmetic():
     assert torch.equal(crop, img[..., :, 10:110])
     up = FluxPipeline.resize_center_crop(img.to(torch.bfloat16), 160, 160)  # bf16 in -> fp32 bilinear -> bf16 out, 160 x 240 -> crop
     assert up.shape == (1, 3, 160, 160) and up.dtype == torch.bfloat16
+
+
+def test_http_api_contract():
+    """api.py keeps the reference's endpoints, request schema, defaults and status codes (api.py:26-122), exercised with a stub model."""
+    import io
+
+    from fastapi.testclient import TestClient
+
+    import api
+
+    calls = []
+
+    class Stub:
+        def generate(self, **kw):
+            calls.append(("generate", kw))
+            return io.BytesIO(b"\xff\xd8jpeg-bytes\xff\xd9")
+
+        def load_lora(self, path, scale, name):
+            calls.append(("load", path, scale, name))
+            if path == "missing.safetensors":
+                raise FileNotFoundError("no such LoRA")
+
+        def unload_lora(self, ident):
+            calls.append(("unload", ident))
+
+    api.app.state.model = Stub()
+    c = TestClient(api.app)
+    r = c.post("/generate", json={"prompt": "a (red:1.3) fox"})
+    assert r.status_code == 200 and r.headers["content-type"] == "image/jpeg" and r.content.startswith(b"\xff\xd8")
+    kw = calls[-1][1]
+    assert kw["prompt"] == "a (red:1.3) fox" and (kw["width"], kw["height"], kw["num_steps"], kw["guidance"]) == (720, 1024, 24, 3.5)
+    assert kw["strength"] == 1.0 and kw["init_image"] is None and 0 < kw["seed"] < api.MAX_RAND
+    assert c.post("/generate", json={"prompt": "x", "seed": 0}).status_code == 422  # seed must be > 0
+    assert c.post("/generate", json={}).status_code == 422
+    r = c.post("/generate", json={"prompt": "x", "width": 512, "height": 512, "num_steps": 4, "seed": 7, "strength": 0.6, "init_image": "in.png"})
+    assert r.status_code == 200 and calls[-1][1]["init_image"] == "in.png" and calls[-1][1]["seed"] == 7
+    r = c.post("/lora", json={"path": "a.safetensors", "scale": 0.8, "name": "style"})
+    assert r.status_code == 200 and r.json() == {"status": "success"} and calls[-1] == ("load", "a.safetensors", 0.8, "style")
+    assert c.post("/lora", json={"action": "unload", "name": "style", "path": "a.safetensors"}).status_code == 200 and calls[-1] == ("unload", "style")
+    assert c.post("/lora", json={"action": "unload", "path": "a.safetensors"}).status_code == 200 and calls[-1] == ("unload", "a.safetensors")
+    r = c.post("/lora", json={"path": "missing.safetensors"})
+    assert r.status_code == 500 and r.json() == {"status": "error", "message": "no such LoRA"}
+    assert c.post("/lora", json={"action": "reload"}).status_code == 422
+
+
+def test_cli_flags_match_reference():
+    """main.py: the reference's flags, short names, defaults and inverted offload switches (main.py:7-148)."""
+    import main
+
+    a = main.parse_args([])
+    assert (a.port, a.host, a.model_version, a.flux_device, a.num_to_quant, a.quant_text_enc) == (8088, "0.0.0.0", "flux-dev", "cuda:0", 20, "qfloat8")
+    assert a.offload_ae and a.offload_text_enc and not a.offload_flow and a.quantize_modulation and not a.quantize_flow_embedder_layers
+    a = main.parse_args(["-c", "cfg.json", "-p", "9000", "-OA", "-OT", "-OF", "-PF", "-nqfm", "-qfl", "-m", "flux-schnell", "-qT", "bf16", "-C"])
+    assert a.config_path == "cfg.json" and a.port == 9000 and not a.offload_ae and not a.offload_text_enc and a.offload_flow
+    assert a.prequantized_flow and not a.quantize_modulation and a.quantize_flow_embedder_layers and a.model_version == "flux-schnell" and a.compile

@@ -17,6 +17,7 @@ order is bit-identical; residual differences come from attention (flash vs math 
   * hipGraph denoise loop vs per-step forward + Euler on the GPU: bit-identical
 """
 import copy
+import os
 
 import pytest
 import torch
@@ -408,3 +409,44 @@ def test_pipeline_generate_jpeg_through_vae(dev):
     assert isinstance(buf, io.BytesIO)
     im = Image.open(buf)
     assert im.size == (64, 96) and im.mode == "RGB"
+
+
+def test_prequantized_checkpoint_round_trip(dev, tmp_path):
+    """a calibrated model's state_dict() saved as safetensors (`float8_data / scale / input_scale ...`, reference
+    float8_quantize.py:91-193, main.py:121-131) loads through `prequantized_flow=True` + `ckpt_path` without re-quantising or
+    re-calibrating and reproduces the same latents bit for bit; the file is about half the bf16 checkpoint."""
+    from safetensors.torch import save_file
+
+    from flux_pipeline import FluxPipeline
+    from fluxmi import synth
+
+    cfg = tiny_config()
+    cfg.text_enc_max_length = 32
+    sd = synth.make_state_dict(cfg.params, seed=0)
+    pipe = FluxPipeline.load_pipeline_from_config(cfg, state_dict=sd)
+    pipe.compile()
+    g = torch.Generator().manual_seed(1)
+    prompt = {"txt": 0.1 * torch.randn(1, 32, 128, generator=g), "vec": torch.randn(1, 64, generator=g)}
+    a = pipe.generate(prompt, width=64, height=96, num_steps=4, seed=3, silent=True)
+    ck = {k: v.detach().cpu().contiguous() for k, v in pipe.model.state_dict().items()}
+    assert any(k.endswith("float8_data") for k in ck) and any(k.endswith("input_scale") for k in ck)
+    path = str(tmp_path / "flow-prequantized.safetensors")
+    save_file(ck, path)
+    bf16_bytes = sum(v.numel() * 2 for v in sd.values())
+    assert os.path.getsize(path) < 0.62 * bf16_bytes
+
+    cfg2 = tiny_config()
+    cfg2.text_enc_max_length = 32
+    cfg2.prequantized_flow = True
+    cfg2.ckpt_path = path
+    pipe2 = FluxPipeline.load_pipeline_from_config(cfg2)
+    ok, _ = pipe2.model.calibration_state()
+    assert ok  # input scales came from the file: no warm-up needed
+    pipe2.compile()  # a no-op for prequantised checkpoints (reference flux_pipeline.py:197)
+    for n, m in pipe.model.named_modules():
+        if hasattr(m, "float8_data") and m.float8_data is not None:
+            m2 = pipe2.model.get_submodule(n)
+            assert torch.equal(m.float8_data.view(torch.uint8), m2.float8_data.view(torch.uint8)), n
+            assert m.input_scale.item() == m2.input_scale.item() and m.scale.item() == m2.scale.item(), n
+    b = pipe2.generate(prompt, width=64, height=96, num_steps=4, seed=3, silent=True)
+    assert torch.equal(a, b)
