@@ -112,6 +112,24 @@ def gemm_traffic_bytes():
         return None
 
 
+def gemm_mfma_busy(table):
+    """Matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD cycles) of the step's GEMM launches, weighted by
+    the launch times measured in THIS run; the per-shape counter values were collected offline with tools/clock_probe.sh and are
+    committed as profiles/r01_gemm_mfma_util.{txt,json}.  Reported beside `frac` because `frac` is priced against the 2.4 GHz spec peak
+    while the chip clocks these kernels at 1.6-2.0 GHz under its power limit."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_gemm_mfma_util.json")) as f:
+            per = json.load(f)["per_launch"]
+        num = den = 0.0
+        for row in table:
+            if row["launch"] in per:
+                w = row["us"] * row["per_step"]
+                num, den = num + w * per[row["launch"]], den + w
+        return round(num / den, 4) if den else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(torch, budget_s=25.0):
     """Reference CPU flow path (bf16 nn.Linear, no fp8) as restated by oracle/flux_oracle.py, on the host cores:
     one DoubleStreamBlock + one SingleStreamBlock at the 1024^2 sequence length, extrapolated x19 / x38."""
@@ -271,7 +289,7 @@ def main():
                              "achieved": round(achieved, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / FP8_PEAK_TFLOPS, 4), "traffic": gemm_traffic_bytes(),
                              "flops_per_launch": flops_per_launch, "avg_launch_us": round(sec_per_launch * 1e6, 2),
-                             "launches": gemm_table},
+                             "mfma_busy_frac_pmc": gemm_mfma_busy(gemm_table), "launches": gemm_table},
             }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
