@@ -205,7 +205,16 @@ class ClipTextNative(nn.Module):
 
     def __init__(self, config: dict):
         super().__init__()
-        c = self.cfg = dict(config.get("text_config", config))
+        # config.json of a CLIP checkpoint nests the text tower (`text_config`, older files also `text_config_dict`); keys left out mean
+        # transformers' CLIPTextConfig defaults
+        c = dict(vocab_size=49408, hidden_size=512, intermediate_size=2048, num_hidden_layers=12, num_attention_heads=8,
+                 max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5, eos_token_id=2)
+        if "text_config" in config or "text_config_dict" in config:
+            c.update(config.get("text_config_dict") or {})
+            c.update(config.get("text_config") or {})
+        else:
+            c.update(config)
+        self.cfg = c
         if c.get("hidden_act", "quick_gelu") != "quick_gelu" or c["hidden_size"] // c["num_attention_heads"] != 64:
             raise ValueError("fluxmi: the native CLIP text model covers quick_gelu MLPs with head_dim = 64 (CLIP ViT-L/14, ViT-B)")
         self.text_model = _ClipTextTransformer(c)
