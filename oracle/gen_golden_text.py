@@ -154,6 +154,19 @@ def main():
     meta = {"transformers": transformers.__version__, "prompts": PROMPTS, "parse": {}, "tokens": {}, "groups": {}}
     for s in PARSE_CASES + PROMPTS:
         meta["parse"][s] = ref_emph.parse_prompt_attention(s)
+    # seeded random strings over the grammar's alphabet: brackets, escapes, colons, numbers, BREAK, plain words
+    import random
+
+    rng = random.Random(1234)
+    atoms = ["(", ")", "[", "]", "\\", ":", ":1.5)", ":0.25)", ":-2)", ":+.5)", ":)", " ", "a", "cat", " BREAK ", "BREAK", "1", ".", ",", "\\(", "\\]",
+             "sky ", "on", ":x)", "((", "))", "\u00e9"]
+    meta["fuzz"] = []
+    for _ in range(400):
+        text = "".join(rng.choice(atoms) for _ in range(rng.randint(1, 14)))
+        try:
+            meta["fuzz"].append([text, ref_emph.parse_prompt_attention(text)])
+        except ValueError:  # float("1.5.") style payloads: the reference raises
+            meta["fuzz"].append([text, "ValueError"])
     for i, prompt in enumerate(PROMPTS):
         tk, tw = ref_emph.get_prompts_tokens_with_weights(clip_tok, prompt)
         t5k, t5w = ref_emph.get_prompts_tokens_with_weights(t5_tok, prompt)

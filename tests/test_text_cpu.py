@@ -40,6 +40,14 @@ def test_parse_prompt_attention_matches_reference(meta):
     assert len(meta["parse"]) >= 12
     for text, want in meta["parse"].items():
         assert fe.parse_prompt_attention(text) == want, text
+    # 400 seeded random strings over the grammar's alphabet, parsed by the unmodified reference when the fixture was written
+    assert len(meta["fuzz"]) == 400
+    for text, want in meta["fuzz"]:
+        if want == "ValueError":
+            with pytest.raises(ValueError):
+                fe.parse_prompt_attention(text)
+        else:
+            assert fe.parse_prompt_attention(text) == want, repr(text)
     # the reference's own doctest vectors (flux_emphasis.py:27-47)
     assert fe.parse_prompt_attention("normal text") == [["normal text", 1.0]]
     assert fe.parse_prompt_attention("an (important) word") == [["an ", 1.0], ["important", 1.1], [" word", 1.0]]
