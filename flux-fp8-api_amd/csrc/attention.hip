@@ -164,21 +164,33 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_kernel(const AttnArgs a)
   }
   // S^T = K . Q^T for one 64-key tile.  The two 32-key halves ALTERNATE on the matrix pipe: consecutive MFMAs never share an
   // accumulator, so none waits for the previous one's result.
+  // K fragments are fetched QK_PF chunks ahead into a rotating register set and the order is pinned (sched_barrier): left alone, the
+  // compiler sinks every ds_read next to its MFMA to save registers and each MFMA pair then waits a full LDS round trip.
+  constexpr int QK_PF = 2;
   auto qk = [&](int slot, v16f (&st)[2]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-    v8bf ka[8], kb[8];
+    const unsigned char* kbase = smem + slot * K_BYTES;
+    v8bf ka[QK_PF + 1], kb[QK_PF + 1];
 #pragma unroll
-    for (int cc = 0; cc < 8; ++cc) {
-      ka[cc] = *(const v8bf*)(smem + kx[cc] + slot * K_BYTES);
-      kb[cc] = *(const v8bf*)(smem + kx[cc] + slot * K_BYTES + 32 * 256);  // (32 + l31) & 15 == l31 & 15: same swizzle key
+    for (int cc = 0; cc < QK_PF; ++cc) {
+      ka[cc] = *(const v8bf*)(kbase + kx[cc]);
+      kb[cc] = *(const v8bf*)(kbase + kx[cc] + 32 * 256);  // (32 + l31) & 15 == l31 & 15: same swizzle key
     }
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[cc], qf[cc], st[0], 0, 0, 0);
-      st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[cc], qf[cc], st[1], 0, 0, 0);
+      if (cc + QK_PF < 8) {
+        ka[(cc + QK_PF) % (QK_PF + 1)] = *(const v8bf*)(kbase + kx[cc + QK_PF]);
+        kb[(cc + QK_PF) % (QK_PF + 1)] = *(const v8bf*)(kbase + kx[cc + QK_PF] + 32 * 256);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[cc % (QK_PF + 1)], qf[cc], st[0], 0, 0, 0);
+      st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[cc % (QK_PF + 1)], qf[cc], st[1], 0, 0, 0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // ragged last tile only: keys >= L get a score that exponentiates to 0
@@ -240,10 +252,9 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_kernel(const AttnArgs a)
     if (RD > 2 && j + RD - 1 < ntiles) wait_vm<(RD - 2) * 2 * LPW>(); else wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS reads of step j-1 done before anyone refills those slots
     if (!(a.abl & 2)) __builtin_amdgcn_s_barrier();
-    if (!(a.abl & 1)) {
-      if (j + RD < ntiles) stage_k(par, (j + RD) * KT);                            // slot of K_j, last read in step j-1
-      if (j + RD - 1 < ntiles) stage_v((par + RD - 1) % RD, (j + RD - 1) * KT);   // slot of V_{j-1}, last read in step j-1
-    }
+    // The refills of this step (K_{j+RD} into the slot of K_j, V_{j+RD-1} into the slot of V_{j-1}; both were last read in step j-1)
+    // are NOT issued here: an LDS-DMA piece costs 100-185 issue cycles next to a ds_read-dense segment and 25-60 in a VALU-only
+    // gap (MI355X_MICROARCH.md), so K goes behind the QK^T block and V behind the softmax.
     // -- A: running max; once it has settled the O rescale is skipped exactly (wave-uniform branch)
     const float m_new = fmaxf(m_run, mx);
     if (__any(m_new > m_run)) {
@@ -261,6 +272,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_kernel(const AttnArgs a)
     // -- B: S_{j+1} (matrix pipe)  ||  P_j = 2^(S_j*c - m*c), row sum, bf16 (VALU).  On the last step S_{j+1} is computed from
     //       a stale slot and never used (keeps the step branch-free).
     qk(nslot, nxt);
+    if (!(a.abl & 1) && j + RD < ntiles) stage_k(par, (j + RD) * KT);
     v8bf pf[4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -275,6 +287,9 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_kernel(const AttnArgs a)
           pf[t * 2 + u][e] = (bf16)p[0];
           pf[t * 2 + u][e + 1] = (bf16)p[1];
         }
+    // (measured: both refills right behind the QK^T block -- where the compiler hoists this one too -- beat V between the PV halves or
+    // after them by 1.5-2.5 %, and the old top-of-step placement by 4 %: there the matrix pipe was empty while the pieces issued)
+    if (!(a.abl & 1) && j + RD - 1 < ntiles) stage_v((par + RD - 1) % RD, (j + RD - 1) * KT);
     // -- C: O^T += V_j^T . P_j^T (matrix pipe, four independent accumulators)  ||  row max of S_{j+1} (VALU)
     if (ragged && j + 2 == ntiles) mask_tile(nxt, (j + 1) * KT);  // rare wave-uniform branch, kept ahead of the overlapped region
     mx = row_max(nxt);
