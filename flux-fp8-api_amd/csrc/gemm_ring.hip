@@ -373,7 +373,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
       __builtin_amdgcn_s_barrier();
       fence();
       const int rslot = slot == 0 ? NS - 1 : slot - 1;
-      if (VAR & 2) {
+      if (VAR & 8) {
+        read_frags(slot);
+      } else if (VAR & 2) {
         read_frags(slot);
         fence();
         if (kt + D < nk) stage(kt + D, rslot);
@@ -387,6 +389,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
       mma_all();
       if (VAR & 1) __builtin_amdgcn_s_setprio(0);
       fence();
+      if (VAR & 8) {  // refill behind this wave's own MFMA block (an LDS-DMA piece issues in 60 cycles there, 100-185 beside ds_reads)
+        if (kt + D < nk) stage(kt + D, rslot);
+        fence();
+      }
       slot = slot + 1 == NS ? 0 : slot + 1;
     }
   }
@@ -464,7 +470,7 @@ int launch_ring_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
     case 6: return launch_ring<128, 128, 2, 2, 4, false, FP8, ACT>(p, s);
     case 8: return launch_ring<256, 128, 2, 2, 3, true, FP8, ACT>(p, s);   // 72 KiB LDS, 4 waves: 2 blocks per CU
     case 13: return launch_pp<FP8, ACT, 2>(p, s);
-    case 12: return launch_pp<FP8, ACT, 6>(p, s);  // 13 with buffer-descriptor LDS-DMA
+    case 12: return launch_pp<FP8, ACT, 10>(p, s);  // 13 with the second wave group's refill behind its MFMA block
 #ifdef FLUXMI_EXPERIMENTS  // variants measured and rejected in round 1 (profiles/r01_gemm_ablation*.txt); not built by default
     case 7: return launch_ring<256, 256, 2, 4, 4, true, FP8, ACT>(p, s);
     case 9: return launch_ring<128, 256, 2, 2, 3, true, FP8, ACT>(p, s);
