@@ -102,6 +102,29 @@ def measure_gemm_roofline(torch, ops, dev, iters=10):
     return tot_f / n_launch, tot_t / n_launch, table
 
 
+def measure_attention(torch, ops, dev, iters=10, L=4608, H=24):
+    """The second kernel of the step (57 launches): joint attention at the step's shape, bf16 MFMA, fp8 output, HIP events on the
+    launch stream.  Reported beside the GEMM roofline; `peak` is the dense bf16 MFMA figure."""
+    q = torch.randn(1, H, L, 128, device=dev).bfloat16()
+    k = torch.randn(1, H, L, 128, device=dev).bfloat16()
+    vt = torch.randn(1, H, 128, L, device=dev).bfloat16()
+    one = torch.tensor(1.0, device=dev)
+    o8 = torch.empty(1, L, H * 128, dtype=torch.float8_e5m2, device=dev)
+    for _ in range(2):
+        ops.attention(q, k, vt, q_scale0=one, out=o8)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.attention(q, k, vt, q_scale0=one, out=o8)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / iters
+    f = 4.0 * L * L * 128 * H
+    return {"kernel": "attention_kernel<8 waves, 4-deep ring> (bf16 MFMA 32x32x16, fp8 output)", "per_step": 57, "us": round(t * 1e6, 1),
+            "achieved": round(f / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / 2500.0, 4),
+            "note": "432 workgroups on 256 CUs = 1.69 rounds: at most 84 % of the CU-time can be busy at this shape"}
+
+
 def gemm_traffic_bytes():
     """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
     MI355X_MICROARCH.md "HBM"); collected offline by tools/traffic.sh and committed as profiles/r01_gemm_traffic.json."""
@@ -289,7 +312,8 @@ def main():
                              "achieved": round(achieved, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / FP8_PEAK_TFLOPS, 4), "traffic": gemm_traffic_bytes(),
                              "flops_per_launch": flops_per_launch, "avg_launch_us": round(sec_per_launch * 1e6, 2),
-                             "mfma_busy_frac_pmc": gemm_mfma_busy(gemm_table), "launches": gemm_table},
+                             "mfma_busy_frac_pmc": gemm_mfma_busy(gemm_table), "launches": gemm_table,
+                             "attention": measure_attention(torch, ops, dev) if (args.height, args.width) == (1024, 1024) else None},
             }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
