@@ -252,3 +252,47 @@ def test_cli_flags_match_reference():
     a = main.parse_args(["-c", "cfg.json", "-p", "9000", "-OA", "-OT", "-OF", "-PF", "-nqfm", "-qfl", "-m", "flux-schnell", "-qT", "bf16", "-C"])
     assert a.config_path == "cfg.json" and a.port == 9000 and not a.offload_ae and not a.offload_text_enc and a.offload_flow
     assert a.prequantized_flow and not a.quantize_modulation and a.quantize_flow_embedder_layers and a.model_version == "flux-schnell" and a.compile
+
+
+def test_optional_models_absent_offline():
+    """Without local checkpoints the loaders return None instead of reaching for the network (reference util.py:262-296 downloads):
+    the pipeline then takes pre-computed embeddings / returns latents."""
+    import util
+
+    cfg = util.load_config(util.ModelVersion.flux_dev, flow_dtype="bfloat16")
+    assert util.load_text_encoders(cfg) == (None, None)          # clip_path is a hub id, text_enc_path is None: no local directories
+    assert util.load_autoencoder(cfg) is None                    # ae_path None
+    cfg.ae_path = "/nonexistent/ae.sft"
+    assert util.load_autoencoder(cfg) is None
+
+
+def test_native_text_modules_keep_hf_state_dict_keys():
+    """T5EncoderNative / ClipTextNative expose transformers' parameter names (so HF checkpoints load as they are), accept the tied
+    T5 embedding and both CLIP key layouts, and refuse to run without a GPU."""
+    import torch
+
+    from modules.conditioner import ClipTextNative, T5EncoderNative
+
+    t5 = T5EncoderNative(dict(vocab_size=32, d_model=64, d_kv=64, num_heads=2, d_ff=128, num_layers=2, feed_forward_proj="gated-gelu"))
+    keys = set(t5.state_dict())
+    assert {"shared.weight", "encoder.embed_tokens.weight", "encoder.block.0.layer.0.SelfAttention.q.weight",
+            "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", "encoder.block.1.layer.1.DenseReluDense.wi_1.weight",
+            "encoder.block.1.layer.1.layer_norm.weight", "encoder.final_layer_norm.weight"} <= keys
+    assert "encoder.block.1.layer.0.SelfAttention.relative_attention_bias.weight" not in keys  # owned by block 0 only
+    sd = {k: v.clone() for k, v in t5.state_dict().items() if k != "encoder.embed_tokens.weight"}  # tied in real checkpoints
+    assert not t5.load_state_dict(sd, strict=True).missing_keys
+    with pytest.raises(RuntimeError):
+        t5(torch.zeros(1, 8, dtype=torch.long))
+    with pytest.raises(ValueError):
+        T5EncoderNative(dict(vocab_size=32, d_model=64, d_kv=32, num_heads=2, d_ff=128, num_layers=1))
+
+    clip = ClipTextNative(dict(text_config=dict(vocab_size=40, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=1)))
+    ck = set(clip.state_dict())
+    assert {"text_model.embeddings.token_embedding.weight", "text_model.embeddings.position_embedding.weight",
+            "text_model.encoder.layers.0.self_attn.out_proj.bias", "text_model.encoder.layers.0.mlp.fc1.weight",
+            "text_model.final_layer_norm.bias"} <= ck
+    flat = {k[len("text_model."):]: v.clone() for k, v in clip.state_dict().items()}      # transformers 5.x layout
+    flat["embeddings.position_ids"] = torch.arange(77)[None]                                # legacy buffer, ignored
+    assert not clip.load_state_dict(flat, strict=True).missing_keys
+    with pytest.raises(ValueError):
+        ClipTextNative(dict(hidden_size=96, num_attention_heads=2, intermediate_size=64, num_hidden_layers=1, vocab_size=8))
