@@ -254,6 +254,8 @@ class FluxPipeline:
         latents = self.model.denoise(img, img_ids, txt, txt_ids, vec, timesteps, guidance=guidance, use_graph=use_graph)
         if world > 1:
             latents = fdist.gather_latents(latents, num_images, dst=0)
+            if latents is None:  # only the gather rank decodes / returns the images
+                return (None, seed) if return_seed else None
         if output_type == "latent" or self.ae is None:
             out = self.unpack(latents.float(), height, width) if latents is not None else None
             return (out, seed) if return_seed else out

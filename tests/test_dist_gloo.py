@@ -102,3 +102,61 @@ def test_shard_bounds_cover_and_balance():
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
     assert shard_bounds(8, 3, 8) == (3, 4)  # configs[3]: batch 8, one image per GPU
+
+
+def _pipeline_worker(rank, world, port, batch, q):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "flux-fp8-api_amd"))
+    from flux_pipeline import FluxPipeline
+    from fluxmi import dist as fdist
+
+    class StubFlow:  # per-sample function of (latent tokens, conditioning, schedule): no cross-sample interaction, like Flux.forward
+        calls = []
+
+        def denoise(self, img, img_ids, txt, txt_ids, vec, timesteps, guidance=3.5, use_graph=True):
+            StubFlow.calls.append(img.shape[0])
+            assert img_ids.shape[0] == txt.shape[0] == txt_ids.shape[0] == vec.shape[0] == img.shape[0]
+            return (img.float() * 2 + txt.float().mean(dim=(1, 2), keepdim=True) + vec.float().sum(-1)[:, None, None] + len(timesteps)).to(img.dtype)
+
+    def make_pipe():
+        pipe = FluxPipeline.__new__(FluxPipeline)
+        pipe.name, pipe.debug, pipe.dtype, pipe.ae_dtype = "flux-dev", False, torch.bfloat16, torch.bfloat16
+        pipe.device_flux = pipe.device_ae = pipe.device_clip = pipe.device_t5 = torch.device("cpu")
+        pipe.model, pipe.ae, pipe.clip, pipe.t5, pipe.rng = StubFlow(), None, None, None, torch.Generator(device="cpu")
+        return pipe
+
+    g = torch.Generator().manual_seed(1)
+    prompt = {"txt": torch.randn(batch, 6, 16, generator=g), "vec": torch.randn(batch, 8, generator=g)}
+    kw = dict(width=64, height=96, num_steps=5, seed=11, num_images=batch, output_type="latent", silent=True)
+    expect = make_pipe().generate(prompt, **kw)  # single process: the whole batch on one replica
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    fdist.init_from_env("gloo")
+    StubFlow.calls.clear()
+    if rank != 0:  # only rank 0 owns the real conditioning; the broadcast must overwrite whatever the others hold
+        prompt = {k: torch.zeros_like(v) for k, v in prompt.items()}
+    out = make_pipe().generate(prompt, **kw)
+    lo, hi = fdist.shard_bounds(batch, rank, world)
+    ok = StubFlow.calls == [hi - lo]
+    ok = ok and ((out is not None and torch.equal(out, expect)) if rank == 0 else out is None)
+    q.put((rank, bool(ok), (lo, hi)))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [2, 5])
+def test_two_rank_pipeline_generate_matches_single_process(batch):
+    """FluxPipeline.generate under a 2-rank process group (gloo): embeddings + noise broadcast from rank 0, every rank denoises its own
+    batch slice, rank 0 gathers -- and gets exactly what a single replica produces for the whole batch; other ranks return None."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
