@@ -287,9 +287,9 @@ __global__ void __launch_bounds__(256) add_bcast_kernel(const u16* __restrict__ 
   }
 }
 // dst[0..n) = table[(*step - step0) * n ..]: the modulation vectors of the current denoise step out of the per-request table
-__global__ void __launch_bounds__(256) select_step_kernel(const uint4* __restrict__ table, const int* __restrict__ step, int step0,
-                                                          uint4* __restrict__ dst, long long n16) {
-  const uint4* src = table + (long long)(*step - step0) * n16;
+__global__ void __launch_bounds__(256) select_step_kernel(const uint4* __restrict__ table, const int* __restrict__ step,
+                                                          const int* __restrict__ step0, uint4* __restrict__ dst, long long n16) {
+  const uint4* src = table + (long long)(*step - *step0) * n16;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
@@ -351,6 +351,15 @@ __global__ void set_timestep_kernel(u16* __restrict__ t_vec, const float* __rest
   if (b < B) t_vec[b] = f2bf(ts[*step]);
 }
 __global__ void advance_step_kernel(int* step) { *step += 1; }
+// rows of the step-ahead modulation table: t_rows[r] = bf16(ts[step0 + r / B]) (the value Flux.forward receives, flux_pipeline.py:636-640)
+__global__ void __launch_bounds__(256) timestep_rows_kernel(u16* __restrict__ t_rows, const float* __restrict__ ts, int step0, int B, int R) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < R) t_rows[r] = f2bf(ts[step0 + r / B]);
+}
+__global__ void fill_bf16_kernel(u16* __restrict__ dst, float v, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n) dst[i] = f2bf(v);
+}
 
 // w += delta (fp32), n multiple of 4                                       lora_loading.py:564-577
 __global__ void __launch_bounds__(256) axpy_f32_kernel(float* __restrict__ w, const float* __restrict__ d, float alpha, long long n) {
@@ -538,7 +547,7 @@ int fluxmi_k_add_bcast(const void* a, const void* b, void* z, long long rows, in
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }
-int fluxmi_k_select_step(const void* table, const int* step, int step0, void* dst, long long bytes, hipStream_t s) {
+int fluxmi_k_select_step(const void* table, const int* step, const int* step0, void* dst, long long bytes, hipStream_t s) {
   FLUXMI_REQUIRE(bytes % 16 == 0, "select_step: size must be a multiple of 16 bytes");
   if (bytes == 0) return 0;
   hipLaunchKernelGGL(select_step_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, s, (const uint4*)table, step, step0, (uint4*)dst, bytes / 16);
@@ -575,6 +584,18 @@ int fluxmi_k_set_timestep(void* t_vec, const float* ts, const int* step, int B, 
 }
 int fluxmi_k_advance_step(int* step, hipStream_t s) {
   hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, step);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+int fluxmi_k_timestep_rows(void* t_rows, const float* ts, int step0, int B, int R, hipStream_t s) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(timestep_rows_kernel, dim3((R + 255) / 256), dim3(256), 0, s, (u16*)t_rows, ts, step0, B, R);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+int fluxmi_k_fill_bf16(void* dst, float v, int n, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fill_bf16_kernel, dim3((n + 63) / 64), dim3(64), 0, s, (u16*)dst, v, n);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }

@@ -17,6 +17,7 @@
 //   Q,K    bf16 [B, heads, L, 128];  VT bf16 [B, heads, 128, Lp]  (attention operands)
 //   attn8  fp8  [B, L, H];  h8 fp8 [B, L, 4H];  cat8 fp8 [B, L, 5H]  (single block: attn | gelu(mlp))
 //   mod    bf16 [B, 12H*depth + 3H*single + 2H]   all modulation vectors of the step
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -44,7 +45,7 @@ struct fluxmi_engine {
   std::map<std::string, Buf> bufs;
   // persistent small device state
   char* consts = nullptr;
-  float *d_freqs, *d_omega, *d_ts, *d_dts, *d_amax;
+  float *d_freqs, *d_omega, *d_ts, *d_dts, *d_amax, *d_amax_own;
   int *d_axis, *d_step;
   FluxmiCalibLayer* d_calib;
   FluxmiGemvLayer* d_gemv = nullptr;
@@ -62,6 +63,19 @@ struct fluxmi_engine {
   hipGraphExec_t exec = nullptr;
   bool graph_ok = false;
   bool txt_emb_valid = false;
+  int* d_step0 = nullptr;          // first step of the modulation table (device scalar: the captured graph reads it)
+  int mods_rows_cap = 0;           // rows (steps x B) the table holds; sized in engine_prepare, never inside denoise
+  // pinned host staging for the per-request schedule (ts | dts), guarded by an event so that engine_denoise never waits on the stream
+  float* h_sched = nullptr;
+  hipEvent_t ev_sched = nullptr;
+  bool sched_pending = false;
+  // hipEvent timing of the frozen (graph-replayed) part of the last denoise call, read back by fluxmi_engine_last_timing
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+  int timed_steps = 0;
+  // multi-GPU calibration: caller-owned amax array + host hook called between the amax reduction of a layer and its scale update
+  float* amax_ext = nullptr;
+  fluxmi_amax_hook_t amax_hook = nullptr;
+  void* amax_user = nullptr;
 };
 
 namespace {
@@ -122,6 +136,8 @@ int calib_amax(E* e, int li, const void* x, int rows, int cols, long long ld, hi
 }
 int calib_commit(E* e, int li, int trial, hipStream_t s) {
   const fluxmi_linear_t& l = e->lin[li];
+  // float8_quantize.py:227 takes the max over the WHOLE batch: batch-sharded ranks exchange it here (all-reduce MAX of one float)
+  if (e->amax_hook) FLUXMI_REQUIRE(e->amax_hook(e->amax_user, li, 1, (void*)s) == 0, "amax exchange hook failed (layer %d)", li);
   const float mx = l.in_fmt == FLUXMI_E5M2 ? 57344.f : 448.f;
   return fluxmi_k_calib_update(e->d_amax + li, l.amax_trials, l.in_scale, l.in_scale_recip, trial, e->d.num_trials, mx, s);
 }
@@ -266,6 +282,7 @@ int compute_vec_and_mods(E* e, const u16* t_vec, const u16* g_vec, const u16* y,
   if (calib && !e->h_calib_mod.empty()) {
     FLUXMI_CHECK_HIP(hipMemsetAsync(e->d_amax, 0, sizeof(float), s));
     FLUXMI_TRY(fluxmi_k_amax(svec, e->d_amax, B, H, H, s));
+    if (e->amax_hook) FLUXMI_REQUIRE(e->amax_hook(e->amax_user, 0, 1, (void*)s) == 0, "amax exchange hook failed (modulations)");
     FLUXMI_TRY(fluxmi_k_calib_update_many(e->d_amax, e->d_calib_mod, (int)e->h_calib_mod.size(), trial, e->d.num_trials, 57344.f, s));
   }
   const size_t a8_stride = ((size_t)B * e->gemv_maxK + 255) & ~(size_t)255;
@@ -292,26 +309,23 @@ int embed_txt(E* e, const u16* txt, bool calib, int trial, u16* dst, long long d
 // computed with the SAME kernels as the per-step path (each row's dot products do not depend on how many rows share a launch,
 // so the table is bit-identical to what compute_vec_and_mods produces step by step), 8 rows per weight pass.
 // ---------------------------------------------------------------------------------------------------------
-int precompute_mods(E* e, const std::vector<float>& ts, int step0, int n_steps, const u16* g_vec, const u16* y, hipStream_t s) {
+// table geometry for `rows` rows: [table | t | temb | hidden | vec_t | vec | silu(vec) | per-group quantised activations]
+constexpr int MODS_STEPS = 64;  // steps per table window; a longer request rebuilds the table every MODS_STEPS steps
+size_t mods_table_bytes(E* e, size_t rows) {
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t H = e->d.hidden;
+  return al(rows * e->mod_cols * 2) + al(rows * 2) + al(rows * 512) + 4 * al(rows * H * 2) + FLUXMI_MAX_GROUPS * al(rows * (size_t)e->gemv_maxK);
+}
+// rows [step0, step_end) x B of the table; the allocation was made by engine_prepare (nothing is allocated or synchronised here)
+int precompute_mods(E* e, int step0, int step_end, const u16* g_vec, const u16* y, hipStream_t s) {
   const int H = e->d.hidden, B = e->B;
   const long long MC = e->mod_cols;
-  const int R = (n_steps - step0) * B;
+  const int R = (step_end - step0) * B;
   if (R <= 0) return 0;
+  FLUXMI_REQUIRE(R <= e->mods_rows_cap && e->mods_all, "precompute_mods: %d rows exceed the table of %d rows", R, e->mods_rows_cap);
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  // sized for at least 64 steps so that requests of different length reuse the allocation (and the captured graph, which reads
-  // the table through its address).  Layout: [table | t | temb | hidden | vec_t | vec | silu(vec)]
-  const size_t Rc = (size_t)std::max(R, 64 * B);
+  const size_t Rc = (size_t)e->mods_rows_cap;
   const size_t sz_mod = al(Rc * MC * 2), sz_t = al(Rc * 2), sz_temb = al(Rc * 512), sz_h = al(Rc * H * 2);
-  const size_t total = sz_mod + sz_t + sz_temb + 4 * sz_h + FLUXMI_MAX_GROUPS * al(Rc * (size_t)e->gemv_maxK);
-  if (total > e->mods_all_bytes) {
-    FLUXMI_CHECK_HIP(hipStreamSynchronize(s));
-    if (e->mods_all) hipFree(e->mods_all);
-    e->mods_all = nullptr; e->mods_all_bytes = 0;
-    if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
-    e->graph_ok = false;
-    if (hipMalloc((void**)&e->mods_all, total) != hipSuccess) { fluxmi_set_error("precompute_mods: hipMalloc(%zu) failed", total); return 2; }
-    e->mods_all_bytes = total;
-  }
   char* base = e->mods_all;
   u16* mod_all = (u16*)base;
   u16* tv = (u16*)(base + sz_mod);
@@ -320,10 +334,7 @@ int precompute_mods(E* e, const std::vector<float>& ts, int step0, int n_steps, 
   u16* vt = (u16*)((char*)hbuf + sz_h);
   u16* vec = (u16*)((char*)vt + sz_h);
   u16* sv = (u16*)((char*)vec + sz_h);
-  std::vector<u16> htv(R);
-  for (int r = 0; r < R; ++r) htv[r] = host_f2bf((double)ts[step0 + r / B]);
-  FLUXMI_CHECK_HIP(hipMemcpyAsync(tv, htv.data(), (size_t)R * 2, hipMemcpyHostToDevice, s));
-  FLUXMI_CHECK_HIP(hipStreamSynchronize(s));  // htv goes out of scope
+  FLUXMI_TRY(fluxmi_k_timestep_rows(tv, e->d_ts, step0, B, R, s));  // bf16(t) per row, from the schedule already on the device
   FLUXMI_TRY(fluxmi_k_timestep_embedding(tv, e->d_freqs, temb, R, 128, 1000.0f, s));
   auto rows_linear = [&](int li, const u16* x, long long ldx, u16* out, int pre_silu, int r0, int nr) -> int {
     const fluxmi_linear_t& l = e->lin[li];
@@ -357,6 +368,7 @@ int precompute_mods(E* e, const std::vector<float>& ts, int step0, int n_steps, 
   FLUXMI_TRY(fluxmi_k_act(vec, sv, R, H, H, H, 1, s));
   FLUXMI_TRY(mods_gemm(e, sv, R, mod_all, (uint8_t*)((char*)sv + sz_h), al(Rc * (size_t)e->gemv_maxK), s));
   e->mods_step0 = step0;
+  FLUXMI_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)e->d_step0, step0, 1, s));
   return 0;
 }
 
@@ -386,6 +398,233 @@ int build_qluts(E* e, hipStream_t s) {
   return 0;
 }
 
+// Workspace pointers of one forward pass (looked up once).
+struct Ctx {
+  int H, Hm, B, L, Lt, Li, heads;
+  long long XB, MC;
+  u16 *x, *mod, *qkv, *K, *VT, *pe, *abf, *catbf, *hbf, *attnbf, *lin1;
+  uint8_t *a8, *attn8, *h8, *cat8, *qlut;
+};
+Ctx make_ctx(E* e) {
+  Ctx c;
+  c.H = e->d.hidden; c.Hm = e->d.mlp_hidden; c.B = e->B; c.L = e->L; c.Lt = e->Lt; c.Li = e->Li; c.heads = e->d.heads;
+  c.XB = (long long)c.L * c.H; c.MC = e->mod_cols;
+  c.x = buf<u16>(e, "x"); c.mod = buf<u16>(e, "mod"); c.qkv = buf<u16>(e, "qkv"); c.K = buf<u16>(e, "K"); c.VT = buf<u16>(e, "VT");
+  c.pe = buf<u16>(e, "pe"); c.abf = buf<u16>(e, "abf"); c.catbf = buf<u16>(e, "catbf"); c.hbf = buf<u16>(e, "hbf");
+  c.attnbf = buf<u16>(e, "attnbf"); c.lin1 = buf<u16>(e, "lin1");
+  c.a8 = buf<uint8_t>(e, "a8"); c.attn8 = buf<uint8_t>(e, "attn8"); c.h8 = buf<uint8_t>(e, "h8"); c.cat8 = buf<uint8_t>(e, "cat8");
+  c.qlut = buf<uint8_t>(e, "qlut");
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DoubleStreamBlock.forward (flux_model.py:356-400) as eight stages; [s0, s1] selects a sub-range (fluxmi_engine_run_block: the
+// teacher-forced parity tests overwrite a stage's input buffer with the oracle's tensor and run that stage alone).
+//   0 LN + modulate (+quantise) -> a8 | 1 qkv GEMM -> qkv (+ V^T) | 2 K (and V^T) relayout | 3 attention -> attn8
+//   4 proj + gate1*y + x -> x | 5 LN + modulate (+quantise) -> a8 | 6 mlp.0 + GELU (+quantise) -> h8 | 7 mlp.2 + gate2*y + x -> x
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DOUBLE_STAGES = 8, SINGLE_STAGES = 5;
+int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1, hipStream_t s) {
+  const bool fused = mode == 1, calib = mode == 0;
+  const int H = c.H, Hm = c.Hm, B = c.B, L = c.L, Lt = c.Lt, Li = c.Li, heads = c.heads;
+  const long long XB = c.XB, MC = c.MC;
+  u16 *x = c.x, *qkv = c.qkv, *K = c.K, *VT = c.VT, *pe = c.pe, *abf = c.abf, *hbf = c.hbf, *attnbf = c.attnbf;
+  uint8_t *a8 = c.a8, *attn8 = c.attn8, *h8 = c.h8;
+  auto on = [&](int st) { return st >= s0 && st <= s1; };
+  const u16* mi = c.mod + (long long)i * 12 * H;  // img: shift1 scale1 gate1 shift2 scale2 gate2
+  const u16* mt = mi + 6 * H;                     // txt
+  const int li_q[2] = {DLi(e, i, D_TXT_QKV), DLi(e, i, D_IMG_QKV)};
+  const int li_p[2] = {DLi(e, i, D_TXT_PROJ), DLi(e, i, D_IMG_PROJ)};
+  const int li_m0[2] = {DLi(e, i, D_TXT_MLP0), DLi(e, i, D_IMG_MLP0)};
+  const int li_m2[2] = {DLi(e, i, D_TXT_MLP2), DLi(e, i, D_IMG_MLP2)};
+  const u16* mods[2] = {mt, mi};
+  const int roff[2] = {0, Lt}, rows[2] = {Lt, Li};
+  const void* const* ns = &e->norm[i * 4];  // img q, img k, txt q, txt k
+  // V^T leaves the qkv GEMM's epilogue directly in the attention kernel's layout when the 256x256 kernels apply
+  const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H, H, e->lin[li_q[0]].kind, 13) && Lt % 16 == 0;
+  const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;  // a 256-column tile must not straddle the q|k|v boundaries
+
+  for (int half = 0; half < 2; ++half) {
+    const int so = half * 3;  // offset of (shift, scale, gate) triple inside the 6H chunk
+    const int* li_in = half == 0 ? li_q : li_m0;
+    if (on(half == 0 ? 0 : 5)) {
+      if (fused) {
+        FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, mt + so * H, mt + (so + 1) * H, mi + so * H, mi + (so + 1) * H, MC,
+                                        e->lin[li_in[0]].in_scale, e->lin[li_in[1]].in_scale, B, L, Lt, H, 1, e->lin[li_in[0]].in_fmt, s));
+      } else {
+        FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, mt + so * H, mt + (so + 1) * H, mi + so * H, mi + (so + 1) * H, MC, nullptr,
+                                        nullptr, B, L, Lt, H, 0, 0, s));
+        for (int st = 0; st < 2; ++st)
+          FLUXMI_TRY(stage_input(e, li_in[st], calib, trial, abf + (long long)roff[st] * H, H, XB, a8 + (long long)roff[st] * H, H, XB, B,
+                                 rows[st], H, s));
+      }
+    }
+    if (half == 0) {
+      if (on(1)) {  // qkv GEMM (both streams, all batch elements in one grouped launch)
+        std::vector<FluxmiGemmGroup> gs;
+        for (int b = 0; b < B; ++b)
+          for (int st = 0; st < 2; ++st) {
+            const fluxmi_linear_t& l = e->lin[li_q[st]];
+            const long long r0 = (long long)b * L + roff[st];
+            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H, qkv + r0 * 3 * H, 3 * H, rows[st]);
+            if (fuse_v) {
+              g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = roff[st];
+              g.vt_rows = st == 0 ? Lt : e->Lp - Lt; g.kv_col0 = H; g.heads = heads;
+              if (fuse_k) {  // K: QKNorm (this stream's key scale) + RoPE in the epilogue as well -> no relayout kernel at all
+                g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[st == 0 ? 3 : 1];
+              }
+            }
+            gs.push_back(g);
+          }
+        FLUXMI_TRY(run_gemm(gs, 3 * H, H, e->lin[li_q[0]].kind, e->lin[li_q[0]].in_fmt, FLUXMI_EPI_BF16, s));
+      }
+      // K and V^T are relaid out once (every query block re-reads them); Q is normalised + rotated inside the attention kernel
+      if (on(2) && !fuse_k)
+        FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, Lt, s));
+      if (on(3)) {
+        if (fused) {
+          FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attn8, H, 0, 1, e->lin[li_p[0]].in_scale, e->lin[li_p[1]].in_scale, Lt, B, L, e->Lp,
+                                        heads, e->lin[li_p[0]].in_fmt, s, qkv, 3 * H, pe, ns[2], ns[0]));
+        } else {
+          FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attnbf, H, 0, 0, nullptr, nullptr, Lt, B, L, e->Lp, heads, 0, s, qkv, 3 * H, pe,
+                                        ns[2], ns[0]));
+          for (int st = 0; st < 2; ++st)
+            FLUXMI_TRY(stage_input(e, li_p[st], calib, trial, attnbf + (long long)roff[st] * H, H, XB, attn8 + (long long)roff[st] * H, H,
+                                   XB, B, rows[st], H, s));
+        }
+      }
+      if (on(4)) {  // proj GEMM + gate1 * y + x
+        std::vector<FluxmiGemmGroup> gs;
+        for (int b = 0; b < B; ++b)
+          for (int st = 0; st < 2; ++st) {
+            const fluxmi_linear_t& l = e->lin[li_p[st]];
+            const long long r0 = (long long)b * L + roff[st];
+            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(attn8 + r0 * H) : (const void*)(attnbf + r0 * H), H, x + r0 * H, H, rows[st]);
+            g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 2 * H;
+            gs.push_back(g);
+          }
+        FLUXMI_TRY(run_gemm(gs, H, H, e->lin[li_p[0]].kind, e->lin[li_p[0]].in_fmt, FLUXMI_EPI_GATE_RESID, s));
+      }
+    } else {
+      if (on(6)) {  // mlp.0 (+GELU, + quantise for mlp.2)
+        std::vector<FluxmiGemmGroup> gs;
+        for (int b = 0; b < B; ++b)
+          for (int st = 0; st < 2; ++st) {
+            const fluxmi_linear_t& l = e->lin[li_m0[st]];
+            const long long r0 = (long long)b * L + roff[st];
+            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H,
+                                         fused ? (void*)(h8 + r0 * Hm) : (void*)(hbf + r0 * Hm), Hm, rows[st]);
+            g.q_scale = e->lin[li_m2[st]].in_scale;
+            if (fused && qlut_enabled()) g.q_lut = c.qlut + (size_t)(i * 2 + st) * 65536;
+            gs.push_back(g);
+          }
+        FLUXMI_TRY(run_gemm(gs, Hm, H, e->lin[li_m0[0]].kind, e->lin[li_m2[0]].in_fmt, fused ? FLUXMI_EPI_GELU_QUANT : FLUXMI_EPI_BF16, s));
+        if (!fused) {
+          FLUXMI_TRY(fluxmi_k_act(hbf, hbf, B * L, Hm, Hm, Hm, 0, s));
+          for (int st = 0; st < 2; ++st)
+            FLUXMI_TRY(stage_input(e, li_m2[st], calib, trial, hbf + (long long)roff[st] * Hm, Hm, (long long)L * Hm,
+                                   h8 + (long long)roff[st] * Hm, Hm, (long long)L * Hm, B, rows[st], Hm, s));
+        }
+      }
+      if (on(7)) {  // mlp.2 + gate2 * y + x
+        std::vector<FluxmiGemmGroup> gs;
+        for (int b = 0; b < B; ++b)
+          for (int st = 0; st < 2; ++st) {
+            const fluxmi_linear_t& l = e->lin[li_m2[st]];
+            const long long r0 = (long long)b * L + roff[st];
+            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(h8 + r0 * Hm) : (const void*)(hbf + r0 * Hm), Hm, x + r0 * H, H, rows[st]);
+            g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 5 * H;
+            gs.push_back(g);
+          }
+        FLUXMI_TRY(run_gemm(gs, H, Hm, e->lin[li_m2[0]].kind, e->lin[li_m2[0]].in_fmt, FLUXMI_EPI_GATE_RESID, s));
+      }
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SingleStreamBlock.forward (flux_model.py:467-485) as five stages:
+//   0 LN + modulate (+quantise) -> a8 | 1 linear1 -> qkv (+ V^T) and gelu(mlp) -> cat8[:, H:] | 2 K (and V^T) relayout
+//   3 attention -> cat8[:, :H] | 4 linear2 + gate*y + x -> x
+// ---------------------------------------------------------------------------------------------------------
+int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1, hipStream_t s) {
+  const bool fused = mode == 1, calib = mode == 0;
+  const int H = c.H, Hm = c.Hm, B = c.B, L = c.L, heads = c.heads;
+  const long long XB = c.XB, MC = c.MC;
+  u16 *x = c.x, *qkv = c.qkv, *K = c.K, *VT = c.VT, *pe = c.pe, *abf = c.abf, *catbf = c.catbf, *lin1 = c.lin1;
+  uint8_t *a8 = c.a8, *cat8 = c.cat8;
+  auto on = [&](int st) { return st >= s0 && st <= s1; };
+  const int HC = H + Hm;
+  const u16* ms = c.mod + (long long)e->d.depth * 12 * H + (long long)i * 3 * H;  // shift scale gate
+  const int l1 = SLi(e, i, S_LIN1), l2 = SLi(e, i, S_LIN2);
+  const fluxmi_linear_t &L1 = e->lin[l1], &L2 = e->lin[l2];
+  const void* const* ns = &e->norm[e->d.depth * 4 + i * 2];
+  if (fused) {
+    const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H + Hm, H, 1, 13);
+    const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;
+    if (on(0))
+      FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, ms, ms + H, ms, ms + H, MC, L1.in_scale, L1.in_scale, B, L, L, H, 1, L1.in_fmt, s));
+    if (on(1)) {
+      std::vector<FluxmiGemmGroup> gs;
+      for (int b = 0; b < B; ++b) {  // one group per batch element: the fused V^T output is per sequence
+        const long long r0 = (long long)b * L;
+        FluxmiGemmGroup g = mk_group(L1, a8 + r0 * H, H, qkv + r0 * 3 * H, 3 * H, L);
+        g.C2 = cat8 + r0 * HC; g.ldc2 = HC; g.split_n = 3 * H; g.c2_col0 = H; g.q_scale = L2.in_scale;
+        if (qlut_enabled()) g.q_lut = c.qlut + (size_t)(e->d.depth * 2 + i) * 65536;
+        if (fuse_v) {
+          g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = 0; g.vt_rows = e->Lp; g.kv_col0 = H; g.heads = heads;
+          if (fuse_k) { g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[1]; }
+        }
+        gs.push_back(g);
+      }
+      FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, 1, L2.in_fmt, FLUXMI_EPI_SPLIT, s));
+    }
+    if (on(2) && !fuse_k)
+      FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, L, s));
+    if (on(3))
+      FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s, qkv,
+                                    3 * H, pe, ns[0], ns[0]));
+  } else {
+    if (on(0)) {
+      FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, ms, ms + H, ms, ms + H, MC, nullptr, nullptr, B, L, L, H, 0, 0, s));
+      FLUXMI_TRY(stage_input(e, l1, calib, trial, abf, H, 0, a8, H, 0, 1, B * L, H, s));
+    }
+    if (on(1)) {
+      std::vector<FluxmiGemmGroup> gs;
+      gs.push_back(mk_group(L1, L1.kind ? (const void*)a8 : (const void*)abf, H, lin1, 3 * H + Hm, B * L));
+      FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, L1.kind, L1.in_fmt, FLUXMI_EPI_BF16, s));
+    }
+    if (on(2)) FLUXMI_TRY(fluxmi_k_qkv_rope(lin1, 3 * H + Hm, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, L, s));
+    if (on(3)) {
+      FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, catbf, HC, 0, 0, nullptr, nullptr, L, B, L, e->Lp, heads, 0, s, lin1, 3 * H + Hm, pe,
+                                    ns[0], ns[0]));
+      FLUXMI_TRY(fluxmi_k_act(lin1 + 3 * H, catbf + H, B * L, Hm, 3 * H + Hm, HC, 0, s));
+      FLUXMI_TRY(stage_input(e, l2, calib, trial, catbf, HC, 0, cat8, HC, 0, 1, B * L, HC, s));
+    }
+  }
+  if (on(4)) {
+    std::vector<FluxmiGemmGroup> gs;
+    for (int b = 0; b < B; ++b) {
+      const long long r0 = (long long)b * L;
+      FluxmiGemmGroup g = mk_group(L2, L2.kind ? (const void*)(cat8 + r0 * HC) : (const void*)(catbf + r0 * HC), HC, x + r0 * H, H, L);
+      g.resid = x + r0 * H; g.ldr = H; g.gate = ms + (long long)b * MC + 2 * H;
+      gs.push_back(g);
+    }
+    FLUXMI_TRY(run_gemm(gs, H, HC, L2.kind, L2.in_fmt, FLUXMI_EPI_GATE_RESID, s));
+  }
+  return 0;
+}
+
+int require_all_f8(E* e) {
+  for (int i = 0; i < e->d.depth; ++i)
+    for (int sl : {D_IMG_QKV, D_IMG_PROJ, D_IMG_MLP0, D_IMG_MLP2, D_TXT_QKV, D_TXT_PROJ, D_TXT_MLP0, D_TXT_MLP2})
+      FLUXMI_REQUIRE(DL(e, i, sl).kind == 1, "fused mode needs every block linear to be F8Linear (double block %d)", i);
+  for (int i = 0; i < e->d.depth_single; ++i)
+    FLUXMI_REQUIRE(SL(e, i, S_LIN1).kind == 1 && SL(e, i, S_LIN2).kind == 1, "fused mode needs F8Linear in single block %d", i);
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* t_vec, const u16* g_vec, u16* pred, int mode,
                  int trial, bool txt_cached, hipStream_t s) {
@@ -400,13 +639,8 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
   uint8_t* in8 = buf<uint8_t>(e, "in8");
   const long long MC = e->mod_cols;
 
-  if (fused) {
-    for (int i = 0; i < e->d.depth; ++i)
-      for (int sl : {D_IMG_QKV, D_IMG_PROJ, D_IMG_MLP0, D_IMG_MLP2, D_TXT_QKV, D_TXT_PROJ, D_TXT_MLP0, D_TXT_MLP2})
-        FLUXMI_REQUIRE(DL(e, i, sl).kind == 1, "fused mode needs every block linear to be F8Linear (double block %d)", i);
-    for (int i = 0; i < e->d.depth_single; ++i)
-      FLUXMI_REQUIRE(SL(e, i, S_LIN1).kind == 1 && SL(e, i, S_LIN2).kind == 1, "fused mode needs F8Linear in single block %d", i);
-  }
+  if (fused) FLUXMI_TRY(require_all_f8(e));
+  const Ctx ctx = make_ctx(e);
 
   // ---- img_in / txt_in                                                             flux_model.py:686,699
   {
@@ -425,166 +659,13 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
     FLUXMI_TRY(embed_txt(e, txt, calib, trial, x, XB, s));
   }
   if (e->mods_table) {
-    FLUXMI_TRY(fluxmi_k_select_step(e->mods_all, e->d_step, e->mods_step0, mod, (long long)B * MC * 2, s));
+    FLUXMI_TRY(fluxmi_k_select_step(e->mods_all, e->d_step, e->d_step0, mod, (long long)B * MC * 2, s));
   } else {
     FLUXMI_TRY(compute_vec_and_mods(e, t_vec, g_vec, y, calib, trial, s));
   }
 
-  // ---- double blocks                                                              flux_model.py:356-400
-  for (int i = 0; i < e->d.depth; ++i) {
-    const u16* mi = mod + (long long)i * 12 * H;  // img: shift1 scale1 gate1 shift2 scale2 gate2
-    const u16* mt = mi + 6 * H;                   // txt
-    const int li_q[2] = {DLi(e, i, D_TXT_QKV), DLi(e, i, D_IMG_QKV)};
-    const int li_p[2] = {DLi(e, i, D_TXT_PROJ), DLi(e, i, D_IMG_PROJ)};
-    const int li_m0[2] = {DLi(e, i, D_TXT_MLP0), DLi(e, i, D_IMG_MLP0)};
-    const int li_m2[2] = {DLi(e, i, D_TXT_MLP2), DLi(e, i, D_IMG_MLP2)};
-    const u16* mods[2] = {mt, mi};
-    const int roff[2] = {0, Lt}, rows[2] = {Lt, Li};
-    const void* const* ns = &e->norm[i * 4];  // img q, img k, txt q, txt k
-
-    // -- attention half -------------------------------------------------------------------------
-    for (int half = 0; half < 2; ++half) {
-      const int so = half * 3;  // offset of (shift, scale, gate) triple inside the 6H chunk
-      const int* li_in = half == 0 ? li_q : li_m0;
-      if (fused) {
-        FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, mt + so * H, mt + (so + 1) * H, mi + so * H, mi + (so + 1) * H, MC,
-                                        e->lin[li_in[0]].in_scale, e->lin[li_in[1]].in_scale, B, L, Lt, H, 1, e->lin[li_in[0]].in_fmt, s));
-      } else {
-        FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, mt + so * H, mt + (so + 1) * H, mi + so * H, mi + (so + 1) * H, MC, nullptr,
-                                        nullptr, B, L, Lt, H, 0, 0, s));
-        for (int st = 0; st < 2; ++st)
-          FLUXMI_TRY(stage_input(e, li_in[st], calib, trial, abf + (long long)roff[st] * H, H, XB, a8 + (long long)roff[st] * H, H, XB, B,
-                                 rows[st], H, s));
-      }
-      if (half == 0) {
-        // qkv GEMM (both streams, all batch elements in one grouped launch)
-        std::vector<FluxmiGemmGroup> gs;
-        // V^T leaves the qkv GEMM's epilogue directly in the attention kernel's layout when the 256x256 kernels apply
-        const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H, H, e->lin[li_q[0]].kind, 13) && Lt % 16 == 0;
-        const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;  // a 256-column tile must not straddle the q|k|v boundaries
-        for (int b = 0; b < B; ++b)
-          for (int st = 0; st < 2; ++st) {
-            const fluxmi_linear_t& l = e->lin[li_q[st]];
-            const long long r0 = (long long)b * L + roff[st];
-            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H, qkv + r0 * 3 * H, 3 * H, rows[st]);
-            if (fuse_v) {
-              g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = roff[st];
-              g.vt_rows = st == 0 ? Lt : e->Lp - Lt; g.kv_col0 = H; g.heads = heads;
-              if (fuse_k) {  // K: QKNorm (this stream's key scale) + RoPE in the epilogue as well -> no relayout kernel at all
-                g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[st == 0 ? 3 : 1];
-              }
-            }
-            gs.push_back(g);
-          }
-        FLUXMI_TRY(run_gemm(gs, 3 * H, H, e->lin[li_q[0]].kind, e->lin[li_q[0]].in_fmt, FLUXMI_EPI_BF16, s));
-        // K and V^T are relaid out once (every query block re-reads them); Q is normalised + rotated inside the attention kernel
-        if (!fuse_k)
-          FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, Lt, s));
-        if (fused) {
-          FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attn8, H, 0, 1, e->lin[li_p[0]].in_scale, e->lin[li_p[1]].in_scale, Lt, B, L, e->Lp,
-                                        heads, e->lin[li_p[0]].in_fmt, s, qkv, 3 * H, pe, ns[2], ns[0]));
-        } else {
-          FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attnbf, H, 0, 0, nullptr, nullptr, Lt, B, L, e->Lp, heads, 0, s, qkv, 3 * H, pe,
-                                        ns[2], ns[0]));
-          for (int st = 0; st < 2; ++st)
-            FLUXMI_TRY(stage_input(e, li_p[st], calib, trial, attnbf + (long long)roff[st] * H, H, XB, attn8 + (long long)roff[st] * H, H,
-                                   XB, B, rows[st], H, s));
-        }
-        // proj GEMM + gate1 * y + x
-        gs.clear();
-        for (int b = 0; b < B; ++b)
-          for (int st = 0; st < 2; ++st) {
-            const fluxmi_linear_t& l = e->lin[li_p[st]];
-            const long long r0 = (long long)b * L + roff[st];
-            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(attn8 + r0 * H) : (const void*)(attnbf + r0 * H), H, x + r0 * H, H, rows[st]);
-            g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 2 * H;
-            gs.push_back(g);
-          }
-        FLUXMI_TRY(run_gemm(gs, H, H, e->lin[li_p[0]].kind, e->lin[li_p[0]].in_fmt, FLUXMI_EPI_GATE_RESID, s));
-      } else {
-        // MLP: mlp.0 (+GELU, + quantise for mlp.2) then mlp.2 + gate2 * y + x
-        std::vector<FluxmiGemmGroup> gs;
-        for (int b = 0; b < B; ++b)
-          for (int st = 0; st < 2; ++st) {
-            const fluxmi_linear_t& l = e->lin[li_m0[st]];
-            const long long r0 = (long long)b * L + roff[st];
-            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H,
-                                         fused ? (void*)(h8 + r0 * Hm) : (void*)(hbf + r0 * Hm), Hm, rows[st]);
-            g.q_scale = e->lin[li_m2[st]].in_scale;
-            if (fused && qlut_enabled()) g.q_lut = buf<uint8_t>(e, "qlut") + (size_t)(i * 2 + st) * 65536;
-            gs.push_back(g);
-          }
-        FLUXMI_TRY(run_gemm(gs, Hm, H, e->lin[li_m0[0]].kind, e->lin[li_m2[0]].in_fmt, fused ? FLUXMI_EPI_GELU_QUANT : FLUXMI_EPI_BF16, s));
-        if (!fused) {
-          FLUXMI_TRY(fluxmi_k_act(hbf, hbf, B * L, Hm, Hm, Hm, 0, s));
-          for (int st = 0; st < 2; ++st)
-            FLUXMI_TRY(stage_input(e, li_m2[st], calib, trial, hbf + (long long)roff[st] * Hm, Hm, (long long)L * Hm,
-                                   h8 + (long long)roff[st] * Hm, Hm, (long long)L * Hm, B, rows[st], Hm, s));
-        }
-        gs.clear();
-        for (int b = 0; b < B; ++b)
-          for (int st = 0; st < 2; ++st) {
-            const fluxmi_linear_t& l = e->lin[li_m2[st]];
-            const long long r0 = (long long)b * L + roff[st];
-            FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(h8 + r0 * Hm) : (const void*)(hbf + r0 * Hm), Hm, x + r0 * H, H, rows[st]);
-            g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 5 * H;
-            gs.push_back(g);
-          }
-        FLUXMI_TRY(run_gemm(gs, H, Hm, e->lin[li_m2[0]].kind, e->lin[li_m2[0]].in_fmt, FLUXMI_EPI_GATE_RESID, s));
-      }
-    }
-  }
-
-  // ---- single blocks                                                              flux_model.py:467-485
-  const int HC = H + Hm;
-  for (int i = 0; i < e->d.depth_single; ++i) {
-    const u16* ms = mod + (long long)e->d.depth * 12 * H + (long long)i * 3 * H;  // shift scale gate
-    const int l1 = SLi(e, i, S_LIN1), l2 = SLi(e, i, S_LIN2);
-    const fluxmi_linear_t &L1 = e->lin[l1], &L2 = e->lin[l2];
-    const void* const* ns = &e->norm[e->d.depth * 4 + i * 2];
-    if (fused) {
-      FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, ms, ms + H, ms, ms + H, MC, L1.in_scale, L1.in_scale, B, L, L, H, 1, L1.in_fmt, s));
-      std::vector<FluxmiGemmGroup> gs;
-      const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H + Hm, H, 1, 13);
-      const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;
-      for (int b = 0; b < B; ++b) {  // one group per batch element: the fused V^T output is per sequence
-        const long long r0 = (long long)b * L;
-        FluxmiGemmGroup g = mk_group(L1, a8 + r0 * H, H, qkv + r0 * 3 * H, 3 * H, L);
-        g.C2 = cat8 + r0 * HC; g.ldc2 = HC; g.split_n = 3 * H; g.c2_col0 = H; g.q_scale = L2.in_scale;
-        if (qlut_enabled()) g.q_lut = buf<uint8_t>(e, "qlut") + (size_t)(e->d.depth * 2 + i) * 65536;
-        if (fuse_v) {
-          g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = 0; g.vt_rows = e->Lp; g.kv_col0 = H; g.heads = heads;
-          if (fuse_k) { g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[1]; }
-        }
-        gs.push_back(g);
-      }
-      FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, 1, L2.in_fmt, FLUXMI_EPI_SPLIT, s));
-      if (!fuse_k)
-        FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, L, s));
-      FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s, qkv,
-                                    3 * H, pe, ns[0], ns[0]));
-    } else {
-      u16* lin1 = buf<u16>(e, "lin1");
-      FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, ms, ms + H, ms, ms + H, MC, nullptr, nullptr, B, L, L, H, 0, 0, s));
-      FLUXMI_TRY(stage_input(e, l1, calib, trial, abf, H, 0, a8, H, 0, 1, B * L, H, s));
-      std::vector<FluxmiGemmGroup> gs;
-      gs.push_back(mk_group(L1, L1.kind ? (const void*)a8 : (const void*)abf, H, lin1, 3 * H + Hm, B * L));
-      FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, L1.kind, L1.in_fmt, FLUXMI_EPI_BF16, s));
-      FLUXMI_TRY(fluxmi_k_qkv_rope(lin1, 3 * H + Hm, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, L, s));
-      FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, catbf, HC, 0, 0, nullptr, nullptr, L, B, L, e->Lp, heads, 0, s, lin1, 3 * H + Hm, pe,
-                                    ns[0], ns[0]));
-      FLUXMI_TRY(fluxmi_k_act(lin1 + 3 * H, catbf + H, B * L, Hm, 3 * H + Hm, HC, 0, s));
-      FLUXMI_TRY(stage_input(e, l2, calib, trial, catbf, HC, 0, cat8, HC, 0, 1, B * L, HC, s));
-    }
-    std::vector<FluxmiGemmGroup> gs;
-    for (int b = 0; b < B; ++b) {
-      const long long r0 = (long long)b * L;
-      FluxmiGemmGroup g = mk_group(L2, L2.kind ? (const void*)(cat8 + r0 * HC) : (const void*)(catbf + r0 * HC), HC, x + r0 * H, H, L);
-      g.resid = x + r0 * H; g.ldr = H; g.gate = ms + (long long)b * MC + 2 * H;
-      gs.push_back(g);
-    }
-    FLUXMI_TRY(run_gemm(gs, H, HC, L2.kind, L2.in_fmt, FLUXMI_EPI_GATE_RESID, s));
-  }
+  for (int i = 0; i < e->d.depth; ++i) FLUXMI_TRY(double_block(e, ctx, i, mode, trial, 0, DOUBLE_STAGES - 1, s));
+  for (int i = 0; i < e->d.depth_single; ++i) FLUXMI_TRY(single_block(e, ctx, i, mode, trial, 0, SINGLE_STAGES - 1, s));
 
   // ---- final layer                                                                flux_model.py:499-503, 714-715
   {
@@ -642,14 +723,23 @@ int fluxmi_engine_create(const fluxmi_model_desc_t* desc, const fluxmi_linear_t*
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t o_freqs = carve(128 * 4), o_omega = carve(64 * 4), o_axis = carve(64 * 4), o_ts = carve((MAX_STEPS + 1) * 4),
-               o_dts = carve((MAX_STEPS + 1) * 4), o_step = carve(4), o_amax = carve((size_t)n_linears * 4),
+               o_dts = carve((MAX_STEPS + 1) * 4), o_step = carve(4), o_step0 = carve(4), o_amax = carve((size_t)n_linears * 4),
                o_gemv = carve(sizeof(FluxmiGemvLayer) * n_mod), o_cm = carve(sizeof(FluxmiCalibLayer) * n_mod);
   if (hipMalloc((void**)&e->consts, off) != hipSuccess) { delete e; fluxmi_set_error("engine_create: hipMalloc(%zu) failed", off); return 2; }
   e->d_freqs = (float*)(e->consts + o_freqs); e->d_omega = (float*)(e->consts + o_omega); e->d_axis = (int*)(e->consts + o_axis);
   e->d_ts = (float*)(e->consts + o_ts); e->d_dts = (float*)(e->consts + o_dts); e->d_step = (int*)(e->consts + o_step);
-  e->d_amax = (float*)(e->consts + o_amax); e->d_gemv = (FluxmiGemvLayer*)(e->consts + o_gemv);
+  e->d_amax = e->d_amax_own = (float*)(e->consts + o_amax); e->d_gemv = (FluxmiGemvLayer*)(e->consts + o_gemv);
   e->d_calib_mod = (FluxmiCalibLayer*)(e->consts + o_cm);
+  e->d_step0 = (int*)(e->consts + o_step0);
   hipMemset(e->consts, 0, off);
+  // pinned staging for the schedule + the events (guard of the staging buffer, timing of the frozen steps)
+  if (hipHostMalloc((void**)&e->h_sched, 2 * (MAX_STEPS + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&e->ev_sched, hipEventDisableTiming) != hipSuccess || hipEventCreate(&e->ev_t0) != hipSuccess ||
+      hipEventCreate(&e->ev_t1) != hipSuccess) {
+    fluxmi_engine_destroy(e);
+    fluxmi_set_error("engine_create: pinned staging / event allocation failed");
+    return 2;
+  }
   *out = e;
   return 0;
 }
@@ -659,6 +749,10 @@ int fluxmi_engine_destroy(fluxmi_engine_t* e) {
   free_ws(e);
   if (e->mods_all) hipFree(e->mods_all);
   if (e->consts) hipFree(e->consts);
+  if (e->h_sched) hipHostFree(e->h_sched);
+  if (e->ev_sched) hipEventDestroy(e->ev_sched);
+  if (e->ev_t0) hipEventDestroy(e->ev_t0);
+  if (e->ev_t1) hipEventDestroy(e->ev_t1);
   delete e;
   return 0;
 }
@@ -726,6 +820,16 @@ int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void*
       off += (it.bytes + 255) & ~(size_t)255;
     }
     FLUXMI_TRY(build_gemv_table(e, s));
+    // step-ahead modulation table: MODS_STEPS steps x B rows (59 MB per 28 steps at Flux-dev); engine_denoise never allocates
+    const int rows_cap = MODS_STEPS * B;
+    const size_t need = mods_table_bytes(e, (size_t)rows_cap);
+    if (need > e->mods_all_bytes || rows_cap != e->mods_rows_cap) {
+      if (e->mods_all) hipFree(e->mods_all);
+      e->mods_all = nullptr; e->mods_all_bytes = 0;
+      if (hipMalloc((void**)&e->mods_all, need) != hipSuccess) { fluxmi_set_error("engine_prepare: hipMalloc(%zu) failed (modulation table)", need); return 2; }
+      e->mods_all_bytes = need;
+    }
+    e->mods_rows_cap = rows_cap;
   }
   // ids = cat(txt_ids, img_ids) per batch element; pe table                              flux_model.py:701-702
   u16* ids = buf<u16>(e, "ids");
@@ -750,12 +854,37 @@ int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, 
 }
 
 
+// roctx ranges (rocprofv3 --marker-trace) around the phases of a denoise call, resolved at run time so that the library has no
+// hard dependency on the profiler: FLUXMI_ROCTX=1 turns them on.
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* on = getenv("FLUXMI_ROCTX");
+    if (!on || !atoi(on)) return;
+    void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+struct Range {
+  Range(const char* name) { if (roctx().push) roctx().push(name); }
+  ~Range() { if (roctx().pop) roctx().pop(); }
+};
+}  // namespace
+
 int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const void* y, float guidance,
                           const double* timesteps_host, int n_steps, int* trial_index_inout, int use_graph, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   FLUXMI_REQUIRE(e && e->ws, "engine_denoise: call fluxmi_engine_prepare first");
   FLUXMI_REQUIRE(img && txt && y && timesteps_host && trial_index_inout, "engine_denoise: NULL argument");
   FLUXMI_REQUIRE(n_steps >= 0 && n_steps <= MAX_STEPS, "engine_denoise: n_steps=%d out of range", n_steps);
+  Range whole("fluxmi_engine_denoise");
   const int B = e->B, Li = e->Li, Lt = e->Lt, C = e->d.in_channels;
   // any bf16 block linear -> the fused path is unavailable, run unfused-frozen (mode 2)
   bool all_f8 = true;
@@ -767,48 +896,50 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
   bool any_f8 = false;
   for (auto& l : e->lin) any_f8 |= (l.kind != 0);
 
-  std::vector<float> ts(n_steps + 1), dts(n_steps + 1, 0.f);
-  for (int i = 0; i <= n_steps; ++i) ts[i] = (float)timesteps_host[i];
-  for (int i = 0; i < n_steps; ++i) dts[i] = (float)(timesteps_host[i + 1] - timesteps_host[i]);
-  FLUXMI_CHECK_HIP(hipMemcpyAsync(e->d_ts, ts.data(), (n_steps + 1) * 4, hipMemcpyHostToDevice, s));
-  FLUXMI_CHECK_HIP(hipMemcpyAsync(e->d_dts, dts.data(), (n_steps + 1) * 4, hipMemcpyHostToDevice, s));
-  u16 gv[64];
-  for (int b = 0; b < B; ++b) gv[b] = host_f2bf((double)guidance);
+  // schedule -> device through the engine's pinned staging buffer.  The buffer may still be the source of the previous request's
+  // (long finished) copy: wait on that copy's event, never on the stream.
+  if (e->sched_pending) FLUXMI_CHECK_HIP(hipEventSynchronize(e->ev_sched));
+  float *h_ts = e->h_sched, *h_dts = e->h_sched + (MAX_STEPS + 1);
+  for (int i = 0; i <= n_steps; ++i) h_ts[i] = (float)timesteps_host[i];
+  for (int i = 0; i < n_steps; ++i) h_dts[i] = (float)(timesteps_host[i + 1] - timesteps_host[i]);
+  h_dts[n_steps] = 0.f;
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(e->d_ts, h_ts, (n_steps + 1) * 4, hipMemcpyHostToDevice, s));
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(e->d_dts, h_dts, (n_steps + 1) * 4, hipMemcpyHostToDevice, s));
+  FLUXMI_CHECK_HIP(hipEventRecord(e->ev_sched, s));
+  e->sched_pending = true;
   u16 *gvec = buf<u16>(e, "gvec"), *tvec = buf<u16>(e, "tvec");
-  FLUXMI_CHECK_HIP(hipMemcpyAsync(gvec, gv, B * 2, hipMemcpyHostToDevice, s));
+  FLUXMI_TRY(fluxmi_k_fill_bf16(gvec, guidance, B, s));  // guidance arrives in the flow dtype (flux_pipeline.py:619-623)
   FLUXMI_CHECK_HIP(hipMemsetAsync(e->d_step, 0, 4, s));
   u16 *img_s = buf<u16>(e, "img_s"), *txt_s = buf<u16>(e, "txt_s"), *y_s = buf<u16>(e, "y_s"), *pred_s = buf<u16>(e, "pred_s");
   const long long n_img = (long long)B * Li * C;
   FLUXMI_CHECK_HIP(hipMemcpyAsync(img_s, img, n_img * 2, hipMemcpyDeviceToDevice, s));
   FLUXMI_CHECK_HIP(hipMemcpyAsync(txt_s, txt, (size_t)B * Lt * e->d.ctx_in * 2, hipMemcpyDeviceToDevice, s));
   FLUXMI_CHECK_HIP(hipMemcpyAsync(y_s, y, (size_t)B * e->d.vec_in * 2, hipMemcpyDeviceToDevice, s));
-  FLUXMI_CHECK_HIP(hipStreamSynchronize(s));  // host staging buffers (ts, dts, gv) go out of scope below
 
   int trial = *trial_index_inout;
   int step = 0;
   const u16* g_arg = e->d.guidance_embed ? gvec : nullptr;
   // -- calibrating steps: the reference's first num_trials+1 calls of every F8Linear ----------------------
-  while (step < n_steps && any_f8 && trial <= e->d.num_trials) {
-    FLUXMI_TRY(fluxmi_k_set_timestep(tvec, e->d_ts, e->d_step, B, s));
-    e->qlut_valid = false;
-    FLUXMI_TRY(forward_impl(e, img_s, txt_s, y_s, tvec, g_arg, pred_s, 0, trial, false, s));
-    FLUXMI_TRY(fluxmi_k_euler(img_s, pred_s, e->d_dts, e->d_step, n_img, s));
-    FLUXMI_TRY(fluxmi_k_advance_step(e->d_step, s));
-    ++trial; ++step;
+  {
+    Range r("calibrating steps (unfused)");
+    while (step < n_steps && any_f8 && trial <= e->d.num_trials) {
+      FLUXMI_TRY(fluxmi_k_set_timestep(tvec, e->d_ts, e->d_step, B, s));
+      e->qlut_valid = false;
+      FLUXMI_TRY(forward_impl(e, img_s, txt_s, y_s, tvec, g_arg, pred_s, 0, trial, false, s));
+      FLUXMI_TRY(fluxmi_k_euler(img_s, pred_s, e->d_dts, e->d_step, n_img, s));
+      FLUXMI_TRY(fluxmi_k_advance_step(e->d_step, s));
+      ++trial; ++step;
+    }
   }
   // -- frozen steps -------------------------------------------------------------------------------------------
+  e->timed_steps = 0;
   if (step < n_steps) {
     const int mode = all_f8 ? 1 : 2;
     if (mode == 1) {
       FLUXMI_TRY(embed_txt(e, txt_s, false, 0, buf<u16>(e, "txt_emb"), (long long)Lt * e->d.hidden, s));
       e->txt_emb_valid = true;
+      FLUXMI_TRY(build_qluts(e, s));
     }
-    // modulation table for steps [step, n_steps); a captured graph stays valid as long as the table does not move and
-    // starts at the same step index
-    if (mode == 1) FLUXMI_TRY(build_qluts(e, s));
-    const int old_step0 = e->mods_step0;
-    FLUXMI_TRY(precompute_mods(e, ts, step, n_steps, g_arg, y_s, s));
-    if (old_step0 != e->mods_step0) e->graph_ok = false;
     auto one_step = [&](hipStream_t st) -> int {
       e->mods_table = true;
       int rc = forward_impl(e, img_s, txt_s, y_s, tvec, g_arg, pred_s, mode, 0, mode == 1, st);
@@ -817,40 +948,109 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
       FLUXMI_TRY(fluxmi_k_euler(img_s, pred_s, e->d_dts, e->d_step, n_img, st));
       return fluxmi_k_advance_step(e->d_step, st);
     };
-    if (use_graph && !e->graph_ok) {
-      // the first frozen step runs eagerly so that every lazy one-time init (function attributes) happens outside capture
-      FLUXMI_TRY(one_step(s));
-      ++step;
-    }
-    if (use_graph && step < n_steps) {
-      if (!e->graph_ok) {
-        hipStream_t cs;
-        FLUXMI_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        FLUXMI_CHECK_HIP(hipStreamSynchronize(s));
-        hipGraph_t graph = nullptr;
-        FLUXMI_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        int rc = one_step(cs);
-        hipError_t ce = hipStreamEndCapture(cs, &graph);
-        if (rc || ce != hipSuccess) {
-          if (graph) hipGraphDestroy(graph);
-          hipStreamDestroy(cs);
-          if (!rc) fluxmi_set_error("engine_denoise: hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-          return rc ? rc : 2;
-        }
-        if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
-        hipError_t ie = hipGraphInstantiate(&e->exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-        hipStreamDestroy(cs);
-        if (ie != hipSuccess) { fluxmi_set_error("engine_denoise: hipGraphInstantiate failed: %s", hipGetErrorString(ie)); return 2; }
-        e->graph_ok = true;
+    FLUXMI_CHECK_HIP(hipEventRecord(e->ev_t0, s));
+    const int first_frozen = step;
+    // the modulation vectors of up to MODS_STEPS steps are produced ahead (one pass over the 3.2 GB of modulation weights per window);
+    // the table address and the device-side window origin never change, so ONE captured graph serves every step of every request
+    while (step < n_steps) {
+      const int win_end = std::min(n_steps, step + MODS_STEPS);
+      {
+        Range r("step-ahead modulation table");
+        FLUXMI_TRY(precompute_mods(e, step, win_end, g_arg, y_s, s));
       }
-      for (; step < n_steps; ++step) FLUXMI_CHECK_HIP(hipGraphLaunch(e->exec, s));
-    } else {
-      for (; step < n_steps; ++step) FLUXMI_TRY(one_step(s));
+      if (use_graph && !e->graph_ok) {
+        // the first frozen step runs eagerly so that every lazy one-time init (function attributes) happens outside capture
+        FLUXMI_TRY(one_step(s));
+        ++step;
+        if (step < win_end) {
+          hipStream_t cs;
+          FLUXMI_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+          FLUXMI_CHECK_HIP(hipStreamSynchronize(s));  // one-time, at graph capture only
+          hipGraph_t graph = nullptr;
+          FLUXMI_CHECK_HIP(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+          int rc = one_step(cs);
+          hipError_t ce = hipStreamEndCapture(cs, &graph);
+          if (rc || ce != hipSuccess) {
+            if (graph) hipGraphDestroy(graph);
+            hipStreamDestroy(cs);
+            if (!rc) fluxmi_set_error("engine_denoise: hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            return rc ? rc : 2;
+          }
+          if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+          hipError_t ie = hipGraphInstantiate(&e->exec, graph, nullptr, nullptr, 0);
+          hipGraphDestroy(graph);
+          hipStreamDestroy(cs);
+          if (ie != hipSuccess) { fluxmi_set_error("engine_denoise: hipGraphInstantiate failed: %s", hipGetErrorString(ie)); return 2; }
+          e->graph_ok = true;
+        }
+      }
+      Range r("frozen steps (hipGraph replay)");
+      if (use_graph && e->graph_ok) {
+        for (; step < win_end; ++step) FLUXMI_CHECK_HIP(hipGraphLaunch(e->exec, s));
+      } else {
+        for (; step < win_end; ++step) FLUXMI_TRY(one_step(s));
+      }
     }
+    FLUXMI_CHECK_HIP(hipEventRecord(e->ev_t1, s));
+    e->timed_steps = n_steps - first_frozen;
   }
   FLUXMI_CHECK_HIP(hipMemcpyAsync(img, img_s, n_img * 2, hipMemcpyDeviceToDevice, s));
   *trial_index_inout = trial;
+  return 0;
+}
+
+int fluxmi_engine_last_timing(fluxmi_engine_t* e, float* ms, int* steps) {
+  FLUXMI_REQUIRE(e && ms && steps, "engine_last_timing: NULL argument");
+  *ms = 0.f; *steps = e->timed_steps;
+  if (e->timed_steps > 0) {
+    FLUXMI_CHECK_HIP(hipEventSynchronize(e->ev_t1));
+    FLUXMI_CHECK_HIP(hipEventElapsedTime(ms, e->ev_t0, e->ev_t1));
+  }
+  return 0;
+}
+
+int fluxmi_engine_set_amax_exchange(fluxmi_engine_t* e, float* amax_dev, int n, fluxmi_amax_hook_t hook, void* user) {
+  FLUXMI_REQUIRE(e, "engine_set_amax_exchange: NULL engine");
+  if (!hook) {
+    e->amax_hook = nullptr; e->amax_user = nullptr; e->amax_ext = nullptr;
+    e->d_amax = e->d_amax_own;
+    return 0;
+  }
+  FLUXMI_REQUIRE(amax_dev && n >= (int)e->lin.size(), "engine_set_amax_exchange: need a device array of >= %d floats", (int)e->lin.size());
+  e->amax_hook = hook; e->amax_user = user; e->amax_ext = amax_dev; e->d_amax = amax_dev;
+  return 0;
+}
+
+// One block (kind 0 = DoubleStreamBlock `index`, 1 = SingleStreamBlock `index`), stages [stage_from, stage_to], on the engine's own
+// buffers: x (and the stage's input buffer) hold whatever the caller put there with fluxmi_engine_copy_buffer, the modulation vectors
+// are read from `mod`.  Test hook for teacher-forced per-layer parity; mode as in fluxmi_engine_forward (1 fused, 2 unfused-frozen).
+int fluxmi_engine_run_block(fluxmi_engine_t* e, int kind, int index, int mode, int stage_from, int stage_to, void* stream) {
+  FLUXMI_REQUIRE(e && e->ws, "engine_run_block: call fluxmi_engine_prepare first");
+  FLUXMI_REQUIRE(mode == 1 || mode == 2, "engine_run_block: mode must be 1 (fused) or 2 (unfused, frozen scales)");
+  const int nst = kind == 0 ? DOUBLE_STAGES : SINGLE_STAGES, nb = kind == 0 ? e->d.depth : e->d.depth_single;
+  FLUXMI_REQUIRE((kind == 0 || kind == 1) && index >= 0 && index < nb, "engine_run_block: no block %d of kind %d", index, kind);
+  FLUXMI_REQUIRE(stage_from >= 0 && stage_to < nst && stage_from <= stage_to, "engine_run_block: stages [%d, %d] out of range (0..%d)",
+                 stage_from, stage_to, nst - 1);
+  if (mode == 1) {
+    FLUXMI_TRY(require_all_f8(e));
+    FLUXMI_TRY(build_qluts(e, (hipStream_t)stream));
+  }
+  const Ctx ctx = make_ctx(e);
+  return kind == 0 ? double_block(e, ctx, index, mode, 0, stage_from, stage_to, (hipStream_t)stream)
+                   : single_block(e, ctx, index, mode, 0, stage_from, stage_to, (hipStream_t)stream);
+}
+
+// copy `bytes` between a named workspace buffer (at byte `offset`) and a caller DEVICE buffer; to_engine != 0 writes the workspace
+int fluxmi_engine_copy_buffer(fluxmi_engine_t* e, const char* name, long long offset, void* dev_ptr, long long bytes, int to_engine,
+                              void* stream) {
+  FLUXMI_REQUIRE(e && name && dev_ptr, "engine_copy_buffer: NULL argument");
+  auto it = e->bufs.find(name);
+  FLUXMI_REQUIRE(it != e->bufs.end(), "engine_copy_buffer: no buffer named '%s'", name);
+  FLUXMI_REQUIRE(offset >= 0 && bytes >= 0 && (size_t)(offset + bytes) <= it->second.n, "engine_copy_buffer: [%lld, +%lld) outside '%s' (%zu bytes)",
+                 offset, bytes, name, it->second.n);
+  char* p = (char*)it->second.p + offset;
+  FLUXMI_CHECK_HIP(hipMemcpyAsync(to_engine ? (void*)p : dev_ptr, to_engine ? (const void*)dev_ptr : (const void*)p, (size_t)bytes,
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 

@@ -86,7 +86,9 @@ int fluxmi_k_gate_residual(const void* x, const void* y, const void* gate, void*
 int fluxmi_k_add(const void* a, const void* b, void* z, long long n, hipStream_t s);
 int fluxmi_k_build_qlut(const float* scale, int fmt, int act, void* lut, hipStream_t s);
 int fluxmi_k_add_bcast(const void* a, const void* b, void* z, long long rows, int nb, int cols, hipStream_t s);
-int fluxmi_k_select_step(const void* table, const int* step, int step0, void* dst, long long bytes, hipStream_t s);
+int fluxmi_k_select_step(const void* table, const int* step, const int* step0_dev, void* dst, long long bytes, hipStream_t s);
+int fluxmi_k_timestep_rows(void* t_rows, const float* ts, int step0, int B, int R, hipStream_t s);
+int fluxmi_k_fill_bf16(void* dst, float v, int n, hipStream_t s);
 int fluxmi_k_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, hipStream_t s);
 int fluxmi_k_rope_table(const void* ids, const float* omega, const int* axis, void* pe, long long rows, int n_axes, int pairs, hipStream_t s);
 int fluxmi_k_euler(void* img, const void* pred, const float* dts, const int* step, long long n, hipStream_t s);

@@ -90,7 +90,12 @@ _SIGS = {
     "fluxmi_engine_denoise": ([vp, vp, vp, vp, f32, C.POINTER(C.c_double), i32, C.POINTER(i32), i32, vp], i32),
     "fluxmi_engine_workspace_bytes": ([vp, C.POINTER(i64)], i32),
     "fluxmi_engine_get_buffer": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i64)], i32),
+    "fluxmi_engine_last_timing": ([vp, C.POINTER(f32), C.POINTER(i32)], i32),
+    "fluxmi_engine_set_amax_exchange": ([vp, vp, i32, vp, vp], i32),
+    "fluxmi_engine_run_block": ([vp, i32, i32, i32, i32, i32, vp], i32),
+    "fluxmi_engine_copy_buffer": ([vp, C.c_char_p, i64, vp, i64, i32, vp], i32),
 }
+AMAX_HOOK = C.CFUNCTYPE(i32, vp, i32, i32, vp)
 EXPORTS = sorted(list(_SIGS) + ["fluxmi_last_error"])
 
 lib.fluxmi_last_error.restype = C.c_char_p

@@ -10,8 +10,16 @@
  * Conventions
  *   - plain C types only: raw DEVICE pointers, sizes, a hipStream_t passed as void* (0 = null stream)
  *   - every function returns 0 on success; non-zero -> call fluxmi_last_error() (thread-local string)
- *   - nothing throws across the ABI; no allocation, host sync or hipMalloc inside any *_forward /
- *     op call (all are hipGraph-capturable); engine_create/prepare allocate the private workspace
+ *   - nothing throws across the ABI; no allocation and no host synchronisation inside any op call, fluxmi_engine_forward or
+ *     fluxmi_engine_run_block (all are hipGraph-capturable).  Allocation happens in fluxmi_engine_create (constants, pinned
+ *     staging, events) and fluxmi_engine_prepare (workspace + the step-ahead modulation table) only.  fluxmi_engine_denoise
+ *     allocates nothing and never waits on the stream; its only host waits are (a) on the event of the PREVIOUS request's schedule
+ *     upload before the pinned staging buffer is rewritten (complete long before, in practice never blocks) and (b) one
+ *     hipStreamSynchronize the first time a shape is seen, immediately before the hipGraph capture
+ *   - multi-GPU: the library holds no communicator.  The path shards by batch with no data-path collective, so the
+ *     three small exchanges (embeddings + noise broadcast, per-layer amax MAX during calibration, latent gather) are made by the
+ *     host with torch.distributed over RCCL (flux-fp8-api_amd/fluxmi/dist.py); the engine exposes the one hook they need that
+ *     lies INSIDE a forward pass: fluxmi_engine_set_amax_exchange
  *   - caller owns every buffer passed in; row strides ("ld") are in ELEMENTS of that buffer
  *   - tensors are bf16 (uint16 storage) unless stated; fp8 tensors are OCP e4m3fn / e5m2 bytes
  *   - an engine handle is not re-entrant: the host wrapper serialises calls per engine
@@ -235,9 +243,32 @@ int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, 
  * Steps with trial_index <= num_trials run unfused; the remainder replays ONE captured hipGraph per step. */
 int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const void* y, float guidance,
                           const double* timesteps_host, int n_steps, int* trial_index_inout, int use_graph, void* stream);
+/* hipEvent timing of the frozen (table + graph-replayed) part of the last fluxmi_engine_denoise call: the events are recorded on the
+ * caller's stream around the replays (the reference's only meter is tqdm's it/s, flux_pipeline.py:628-630).  Blocks until the
+ * second event has completed.  steps = number of steps between the events (0: nothing was timed, ms = 0).
+ * FLUXMI_ROCTX=1 additionally emits roctx ranges (calibrating steps / modulation table / graph replays) for rocprofv3 --marker-trace. */
+int fluxmi_engine_last_timing(fluxmi_engine_t* e, float* ms, int* steps);
+/* Batch-sharded calibration: F8Linear.quantize_input takes amax over the WHOLE batch (float8_quantize.py:227).
+ * With a hook installed the engine keeps the per-layer running amax in the caller's device array amax_dev[n >= n_linears] and
+ * calls hook(user, first, count, stream) on the host after the amax of layers [first, first+count) is enqueued on `stream` and
+ * before their scale update is: the host enqueues an all-reduce(MAX) of amax_dev[first..first+count) on that stream (RCCL via
+ * torch.distributed) and returns 0.  Calibrating steps only; never called from the captured graph.  hook = NULL uninstalls. */
+typedef int (*fluxmi_amax_hook_t)(void* user, int first, int count, void* stream);
+int fluxmi_engine_set_amax_exchange(fluxmi_engine_t* e, float* amax_dev, int n, fluxmi_amax_hook_t hook, void* user);
 /* introspection for tests / bench */
 int fluxmi_engine_workspace_bytes(fluxmi_engine_t* e, long long* bytes);
 int fluxmi_engine_get_buffer(fluxmi_engine_t* e, const char* name, void** ptr, long long* bytes);
+/* Teacher-forced parity hooks (tests only).  run_block: stages [stage_from, stage_to] of DoubleStreamBlock (kind 0; stages
+ * 0 LN+modulate->a8, 1 qkv GEMM->qkv(+V^T), 2 K relayout, 3 attention->attn8, 4 proj+gate+resid->x, 5 LN+modulate->a8,
+ * 6 mlp.0+GELU->h8, 7 mlp.2+gate+resid->x; flux_model.py:356-400) or SingleStreamBlock (kind 1; 0 LN+modulate->a8,
+ * 1 linear1->qkv(+V^T)|cat8[:,H:], 2 K relayout, 3 attention->cat8[:,:H], 4 linear2+gate+resid->x; flux_model.py:467-485) `index`
+ * on the engine's own workspace: the residual stream is buffer "x" ([B, Lt+Li, H], txt rows first), the modulation vectors are read
+ * from buffer "mod" (per batch row: double block i at [i*12H, +12H) = img shift1|scale1|gate1|shift2|scale2|gate2 then txt, single
+ * block i at depth*12H + i*3H = shift|scale|gate).  mode 1 = fused kernels, 2 = unfused with frozen scales.
+ * copy_buffer: device-to-device copy between a named workspace buffer and a caller buffer (to_engine != 0 writes the workspace). */
+int fluxmi_engine_run_block(fluxmi_engine_t* e, int kind, int index, int mode, int stage_from, int stage_to, void* stream);
+int fluxmi_engine_copy_buffer(fluxmi_engine_t* e, const char* name, long long offset, void* dev_ptr, long long bytes, int to_engine,
+                              void* stream);
 
 #ifdef __cplusplus
 }
