@@ -1,0 +1,345 @@
+// fluxmi -- flash-attention forward, round-2 pipeline (bf16, head_dim 128, non-causal), gfx950.
+//
+// Same math, operands, LDS image and launch geometry as attention.hip (8 waves x 32 query rows, KV tiles of 64, swapped QK^T,
+// P fed to the PV MFMA straight from the accumulator, K / V^T tiles by LDS-DMA into 4-deep rings); what changes is the schedule
+// inside the wave.  The round-1 ISA (profiles/r02_attention_isa_notes.txt) showed where its time went:
+//   * hipcc sank the whole softmax of tile j (33 v_exp, 21 fma, 16 cvt) plus the 16 v_max3 of tile j+1 into the 16 PV MFMAs
+//     (5.4 VALU per MFMA gap, more than the <= 5 the matrix pipe hides) while the 16 QK^T MFMAs ran with an idle VALU, and the
+//     16 row-sum adds formed ONE dependent chain of v_pk_add behind the barrier with the matrix pipe empty;
+//   * with exact running-max tracking the O rescale (33 v_pk_mul on the PV accumulators, i.e. a wait for the matrix pipe) fired
+//     in ~65 % of the tiles on random scores: P(any of a wave's 32 rows sees a new max in tile j) = 1 - (1 - 1/(j+1))^32.
+// This kernel therefore
+//   1. skews the pipeline by one tile: step j runs S_{j+1} = K_{j+1} Q^T, P_j = softmax numerators of S_j, and O += V_{j-1} P_{j-1}.
+//      P_{j-1} is complete before the step starts, so the softmax VALU work of P_j can be spread EVENLY over all 32 MFMA gaps of
+//      the step (one score per gap: fma, exp2, row-sum add, half a cvt_pk; the row max of S_{j+1} rides in the PV gaps), each
+//      gap pinned with sched_barrier: ~4 VALU + 1 ds_read per MFMA in both halves;
+//   2. defers the running max (guide T13): O, l and the pending P_{j-1} are rescaled only when a row's max grew by more than
+//      2^8 since the last rescale, so P is bounded by 256 (exact in bf16's exponent range, fp32 sums to 1.2e6 at L = 4608) and
+//      the rescale leaves the steady state;
+//   3. keeps four independent row-sum accumulators (no dependent chain) and scalar f32 VALU ops (packed f32 VALU beside MFMAs is
+//      an anti-lever on CDNA4, MI355X_MICROARCH.md).
+// Correctness of the deferred rescale with a pending tile: when the branch fires with f = 2^((m_old - m_new) c), everything still at
+// the old max is scaled exactly once -- O (tiles <= j-2), l (tiles <= j-1) and the bf16 fragments of P_{j-1} (re-rounded) -- and
+// P_j is exponentiated after the decision.  tests/test_ops_gpu.py forces the branch (spiked key rows) and sweeps THR.
+#include "attention_common.h"
+
+namespace {
+
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+__device__ __forceinline__ void fence() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int NW2 = 8, RD2 = 4, LPW2 = 16 / NW2;
+constexpr int VRING2 = RD2 * K_BYTES;
+constexpr float DEFER_LOG2 = 8.0f;  // rescale only when a row max grew by more than 2^8 (in the exp2 domain)
+// VAR bit 1 (A/B + the THR sweep of the tests): exact max tracking, i.e. rescale whenever any row max grows
+
+// VAR bit 0: LDS-DMA refills in the PV half instead of the QK^T half (A/B knob)
+template <int FMT, int VAR>
+__global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs a) {
+  constexpr int QB = NW2 * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nqb = (a.L + QB - 1) / QB;
+  const int lid = xcd_remap(blockIdx.x, nqb * a.H * a.B);  // whole heads per XCD (see attention.hip)
+  const int bhid = lid / nqb;
+  const int h = bhid % a.H, b = bhid / a.H;
+  const int q0 = (lid - bhid * nqb) * QB + wave * 32;
+  const int qrow = q0 + l31;
+  const int qld = min(qrow, a.L - 1);
+  const long long bh = (long long)b * a.H + h;
+
+  v8bf qf[8];
+  load_q_frags(a, b, h, qld, hi, qf);
+
+  const auto krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.K + bh * a.L * 128), 0, a.L * 256, 0x00020000);
+  const auto vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.VT + bh * 128 * a.Lp), 0, 128 * a.Lp * 2, 0x00020000);
+  unsigned k_off[LPW2], v_off[LPW2];
+#pragma unroll
+  for (int i = 0; i < LPW2; ++i) {
+    const int p = tid + NW2 * 64 * i;
+    k_off[i] = (unsigned)((p >> 4) * 256 + ((p & 15) ^ ((p >> 4) & 15)) * 16);
+    const int d = p >> 3, vs = (p & 7) ^ ((d >> 1) & 7);
+    v_off[i] = (unsigned)(d * a.Lp * 2 + vs * 16);
+  }
+  auto dma_k = [&](int slot, int kv0, int i) { dma16(krsrc, smem + slot * K_BYTES + wave * 1024 + NW2 * 1024 * i, k_off[i], kv0 * 256); };
+  auto dma_v = [&](int slot, int kv0, int i) { dma16(vrsrc, smem + VRING2 + slot * V_BYTES + wave * 1024 + NW2 * 1024 * i, v_off[i], kv0 * 2); };
+
+  v16f o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -1e30f;
+  float l4[4] = {0.f, 0.f, 0.f, 0.f};
+  const float c = a.scale_log2;
+
+  unsigned kx[8], vx[4];
+  {
+    const int sw = l31 & 15, vsw = (l31 >> 1) & 7;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) kx[cc] = (unsigned)(l31 * 256 + (((cc * 2 + hi) ^ sw) << 4));
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) vx[ch] = (unsigned)(VRING2 + l31 * 128 + (((ch * 2 + hi) ^ vsw) << 4));
+  }
+  auto k_frag = [&](int slot, int cc, int t) -> v8bf { return *(const v8bf*)(smem + slot * K_BYTES + kx[cc] + t * (32 * 256)); };
+  auto v_frag = [&](int slot, int ch4, int db) -> v8bf { return *(const v8bf*)(smem + vx[ch4] + slot * V_BYTES + db * 4096); };
+
+  auto mask_tile = [&](v16f (&st)[2], int kv0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        st[t][r] = key < a.L ? st[t][r] : -1e30f;
+      }
+  };
+  auto finish_max = [&](float mx) -> float {  // the other 32 keys of the row sit in lane ^ 32
+    const unsigned u = __float_as_uint(mx);
+    const auto sw2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
+  };
+
+  const int ntiles = (a.L + KT - 1) / KT;
+  const bool ragged = (a.L % KT) != 0;
+
+  // ---- prologue: K0 K1 V0 K2 V1 K3 in flight (step j issues K_{j+4} then V_{j+2}); S_0 and its row max ---------------------------
+  // Every issue is unconditional: a tile past the end of the sequence reads zeros (descriptor bounds check) or harmless bytes of
+  // the next V^T row into a ring slot nobody reads any more, so the vmcnt arithmetic is the same in every step and the step body
+  // has no branch (a wave-uniform branch per refill split the step into basic blocks and let MachineSink drag the pinned VALU
+  // work out of its MFMA gaps).
+  {
+    auto iss_k = [&](int t) { dma_k(t, t * KT, 0); dma_k(t, t * KT, 1); };
+    auto iss_v = [&](int t) { dma_v(t, t * KT, 0); dma_v(t, t * KT, 1); };
+    iss_k(0); iss_k(1); iss_v(0); iss_k(2); iss_v(1); iss_k(3);
+  }
+  wait_vm<5 * LPW2>();
+  __builtin_amdgcn_s_barrier();
+  v16f sa[2], sb[2];
+  v4i pfa[4], pfb[4];  // bf16 P fragments as packed words (two tiles: the one the PV MFMAs consume and the one being produced)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pfa[i][e] = 0; pfb[i][e] = 0; }
+  {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[t][r] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+      sa[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_frag(0, cc, 0), qf[cc], sa[0], 0, 0, 0);
+      sa[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_frag(0, cc, 1), qf[cc], sa[1], 0, 0, 0);
+    }
+  }
+  if (ragged && ntiles == 1) mask_tile(sa, 0);
+  float mx;
+  {
+    float m0 = sa[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, sa[t][r]);
+    mx = finish_max(m0);
+  }
+
+  // ---- one step, compile-time ring slot PAR = j % 4; FIRST: no pending tile (j == 0) ------------------------------------------------
+  // cur = S_j (raw scores, turned into P_j in place), nxt = S_{j+1}, pp = bf16 fragments of P_{j-1} (consumed), pc = of P_j (produced)
+  auto step = [&](auto PARC, auto FIRSTC, v16f (&cur)[2], v16f (&nxt)[2], v4i (&pp)[4], v4i (&pc)[4], int j) {
+    constexpr int PAR = decltype(PARC)::value;
+    constexpr bool FIRST = decltype(FIRSTC)::value;
+    constexpr int KS = (PAR + 1) & 3;  // slot of K_{j+1}
+    constexpr int VS = (PAR + 3) & 3;  // slot of V_{j-1}
+    constexpr int VR = (PAR + 2) & 3;  // slot V_{j+2} refills (held V_{j-2})
+    // K_{j+1} and V_{j-1} have landed (own pieces; the barrier extends that to every wave); the two younger tile pairs stay in flight
+    wait_vm<4 * LPW2>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!(a.abl & 2)) __builtin_amdgcn_s_barrier();
+    // -- A: running max with deferred rescale (wave-uniform branch, out of the steady state)
+    {
+      const float m_new = fmaxf(m_run, mx);
+      if (__any((m_new - m_run) * c > ((VAR & 2) ? 0.0f : DEFER_LOG2))) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l4[i] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        if constexpr (!FIRST) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned w = (unsigned)pp[i][e];
+              pp[i][e] = (int)pack_bf2(__uint_as_float(w << 16) * alpha, __uint_as_float(w & 0xffff0000u) * alpha);
+            }
+        }
+        m_run = m_new;
+      }
+    }
+    const float nmc = -m_run * c;
+    // score e (0..31) of S_j -> P_j in place; every second one packs a bf16 pair of the P fragment
+    // Pure VALU nodes carry no chain: left alone, the DAG scheduler floats every fma / exp of the step above the first MFMA and
+    // MachineSink drags results down to their users.  Passing the input and the outputs of a gap's work through (empty) asm
+    // volatile statements ties them between the two sched_barriers of that gap; hipcc still schedules and pads inside the gap.
+    auto soft = [&](auto EC) {
+      constexpr int e = decltype(EC)::value, t = e >> 4, r = e & 15;
+      float sc = cur[t][r];
+      asm volatile("" : "+v"(sc));
+      float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c, nmc));
+      float ls = l4[e & 3] + p;
+      if constexpr (e & 1) {
+        constexpr int f = t * 2 + (r >> 3), q = (r & 7) >> 1;
+        // one v_cvt_pk_bf16_f32 for the pair (through pack_bf2 hipcc converts each half separately and ORs them: 4 instructions).
+        // The s_nop is the trans-op -> VALU wait state hipcc would pad itself (p comes straight from v_exp_f32).
+        int w;
+        asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[t][r - 1]), "v"(p));
+        asm volatile("" : "+v"(p), "+v"(ls));
+        pc[f][q] = w;
+      } else {
+        asm volatile("" : "+v"(p), "+v"(ls));
+      }
+      cur[t][r] = p;
+      l4[e & 3] = ls;
+    };
+    // -- B: S_{j+1} = K_{j+1} Q^T, two alternating accumulators; K fragments two chunks ahead; one score of P_j per gap
+    {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nxt[t][r] = 0.f;
+      v8bf kf[3][2];
+      kf[0][0] = k_frag(KS, 0, 0); kf[0][1] = k_frag(KS, 0, 1);
+      kf[1][0] = k_frag(KS, 1, 0); kf[1][1] = k_frag(KS, 1, 1);
+      fence();
+      static_for<16>([&](auto SC) {
+        constexpr int s = decltype(SC)::value, cc = s >> 1, t = s & 1;
+        nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[cc % 3][t], qf[cc], nxt[t], 0, 0, 0);
+        fence();
+        if constexpr (cc + 2 < 8) kf[(cc + 2) % 3][t] = k_frag(KS, cc + 2, t);
+        soft(std::integral_constant<int, s>{});
+        if constexpr (!(VAR & 1)) {
+          if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
+          if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
+          if constexpr (s == 11) dma_v(VR, (j + 2) * KT, 0);
+          if constexpr (s == 15) dma_v(VR, (j + 2) * KT, 1);
+        }
+        fence();
+      });
+    }
+    if (ragged && j + 2 == ntiles) mask_tile(nxt, (j + 1) * KT);  // rare wave-uniform branch between the two halves
+    // -- C: O^T += V_{j-1}^T P_{j-1}^T, four independent accumulators; V fragments two ahead; the other 16 scores of P_j and the
+    //       row max of S_{j+1} (two scores per gap, v_max3)
+    float m0 = nxt[0][0];
+    auto rmax = [&](auto SC) {  // two scores of S_{j+1} per gap (v_max3), pinned like the softmax work
+      constexpr int s = decltype(SC)::value;
+      asm volatile("" : "+v"(m0));
+      m0 = fmaxf(fmaxf(m0, nxt[s >> 3][(2 * s) & 15]), nxt[s >> 3][((2 * s) & 15) + 1]);
+      asm volatile("" : "+v"(m0));
+    };
+    if constexpr (!FIRST) {
+      v8bf vf[3];
+      vf[0] = v_frag(VS, 0, 0);
+      vf[1] = v_frag(VS, 0, 1);
+      fence();
+      static_for<16>([&](auto SC) {
+        constexpr int s = decltype(SC)::value, ch4 = s >> 2, db = s & 3;
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s % 3], __builtin_bit_cast(v8bf, pp[ch4]), o[db], 0, 0, 0);
+        fence();
+        if constexpr (s + 2 < 16) vf[(s + 2) % 3] = v_frag(VS, (s + 2) >> 2, (s + 2) & 3);
+        soft(std::integral_constant<int, 16 + s>{});
+        rmax(SC);
+        if constexpr (VAR & 1) {
+          if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
+          if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
+          if constexpr (s == 11) dma_v(VR, (j + 2) * KT, 0);
+          if constexpr (s == 15) dma_v(VR, (j + 2) * KT, 1);
+        }
+        fence();
+      });
+    } else {
+      static_for<16>([&](auto SC) {
+        constexpr int s = decltype(SC)::value;
+        soft(std::integral_constant<int, 16 + s>{});
+        rmax(SC);
+      });
+      if constexpr (VAR & 1) {
+        dma_k(PAR, (j + 4) * KT, 0); dma_k(PAR, (j + 4) * KT, 1);
+        dma_v(VR, (j + 2) * KT, 0); dma_v(VR, (j + 2) * KT, 1);
+      }
+    }
+    mx = finish_max(m0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  using TT = std::true_type; using FF = std::false_type;
+  // even j: cur = sa, nxt = sb, consumes pfa, produces pfb; odd j: the mirror image
+  step(I0{}, TT{}, sa, sb, pfa, pfb, 0);
+  int j = 1;
+  for (; j + 4 <= ntiles; j += 4) {
+    step(I1{}, FF{}, sb, sa, pfb, pfa, j);
+    step(I2{}, FF{}, sa, sb, pfa, pfb, j + 1);
+    step(I3{}, FF{}, sb, sa, pfb, pfa, j + 2);
+    step(I0{}, FF{}, sa, sb, pfa, pfb, j + 3);
+  }
+  if (j < ntiles) { step(I1{}, FF{}, sb, sa, pfb, pfa, j); ++j; }
+  if (j < ntiles) { step(I2{}, FF{}, sa, sb, pfa, pfb, j); ++j; }
+  if (j < ntiles) { step(I3{}, FF{}, sb, sa, pfb, pfa, j); ++j; }
+
+  // ---- drain: O^T += V_{n-1}^T P_{n-1}^T (the tile the last step produced) ---------------------------------------------------------
+  wait_vm<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    const int vs = (ntiles - 1) & 3;
+    const bool odd_last = ((ntiles - 1) & 1) != 0;  // P of an odd tile was produced into pfa, of an even tile into pfb
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const v8bf vfr = *(const v8bf*)(smem + vx[s >> 2] + vs * V_BYTES + (s & 3) * 4096);
+      const v4i pf = odd_last ? pfa[s >> 2] : pfb[s >> 2];
+      o[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, __builtin_bit_cast(v8bf, pf), o[s & 3], 0, 0, 0);
+    }
+  }
+  const float l_part = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  const float inv = 1.0f / l_tot;
+  store_o<FMT>(a, o, inv, b, h, qrow, hi);
+}
+
+}  // namespace
+
+template <int VAR> static int launch2(const AttnArgs& a, int fmt, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E5M2, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E4M3, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
+    attr = true;
+  }
+  const dim3 grid(((a.L + 255) / 256) * a.H * a.B);
+  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, VAR>), grid, dim3(512), 4 * A_STAGE, s, a);
+  else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, VAR>), grid, dim3(512), 4 * A_STAGE, s, a);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+// FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 0 = refills in the PV half, bit 1 = exact (undeferred) running max
+int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s) {
+  const char* e = getenv("FLUXMI_ATTN_VAR");
+  switch (e ? atoi(e) & 3 : 0) {
+    case 1: return launch2<1>(a, fmt, s);
+    case 2: return launch2<2>(a, fmt, s);
+    case 3: return launch2<3>(a, fmt, s);
+    default: return launch2<0>(a, fmt, s);
+  }
+}

@@ -1,0 +1,123 @@
+// fluxmi -- pieces shared by the two attention kernels (attention.hip: round-1 kernel, attention2.hip: the round-2 pipeline).
+#pragma once
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.h"
+#include "fluxmi_internal.h"
+
+// launch arguments of both attention kernels
+struct AttnArgs {
+  const u16* Q; const u16* K; const u16* VT;
+  // raw-Q mode (Q == nullptr): query rows come straight from the qkv GEMM output; QKNorm + RoPE are applied while the Q fragments
+  // are loaded (flux_model.py:158-176,60-65), so the normalised/rotated Q tensor is never written to or re-read from HBM
+  const u16* qraw; long long ldq; const u16* pe; const u16* qn[2];
+  void* out; long long ld_out; int col_off; int out_fp8;
+  const float* q_scale[2]; int split;
+  int B, L, Lp, H;
+  float scale_log2;
+  int abl;  // timing-only ablations (FLUXMI_ATTN_ABL): 1 = no LDS-DMA in the tile loop, 2 = no barrier
+};
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// one 1 KiB LDS-DMA piece: 16 B per lane from buffer `rsrc` at (per-lane voff + wave-uniform soff) to LDS at lds + lane*16.
+// Kept out of the kernel template: a device-only builtin inside template-dependent code makes hipcc's HOST pass drop the kernel stub.
+typedef __attribute__((address_space(3))) void* lds_ptr;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)lds, 16, voff, soff, 0, 0);
+}
+
+
+constexpr int KT = 64;                 // keys per tile
+constexpr int K_BYTES = KT * 256;      // 16 KiB
+constexpr int V_BYTES = 128 * KT * 2;  // 16 KiB
+constexpr int A_STAGE = K_BYTES + V_BYTES;
+
+
+// Q fragments (MFMA B operand): 8 x (8 bf16); lane (l31, hi) holds d = c*16 + hi*8 + [0,8) of query row `qld` of (b, h).
+// raw-Q mode (a.Q == nullptr): the row comes straight from the qkv GEMM output and QKNorm + RoPE are applied here
+// (flux_model.py:158-176,60-65), so the normalised / rotated Q tensor never exists in HBM.
+__device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, int qld, int hi, v8bf (&qf)[8]) {
+  const long long bh = (long long)b * a.H + h;
+  if (a.Q) {
+    const u16* qp = a.Q + (bh * a.L + qld) * 128 + hi * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qf[c] = *(const v8bf*)(qp + c * 16);
+  } else {
+    const long long tok = (long long)b * a.L + qld;
+    const u16* qp = a.qraw + tok * a.ldq + (long long)h * 128 + hi * 8;
+    const u16* pp = a.pe + (tok * 64 + hi * 4) * 2;  // (cos, sin) of pairs d/2
+    const u16* wn = a.qn[qld < a.split ? 0 : 1] + hi * 8;
+    float x[8][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      unpack8(*(const uint4*)(qp + c * 16), x[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += x[c][j] * x[c][j];
+    }
+    {  // the other 64 values of the row sit in lane ^ 32
+      const unsigned u = __float_as_uint(ss);
+      const auto sw2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      ss = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
+    }
+    const float rinv = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float w[8], cs[8], y[8];
+      unpack8(*(const uint4*)(wn + c * 16), w);
+      unpack8(*(const uint4*)(pp + c * 16), cs);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[c][j] = rbf((x[c][j] * rinv) * w[j]);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float cc = cs[2 * p], sn = cs[2 * p + 1];
+        y[2 * p] = rbf(rbf(cc * x[c][2 * p]) + rbf((-sn) * x[c][2 * p + 1]));
+        y[2 * p + 1] = rbf(rbf(sn * x[c][2 * p]) + rbf(cc * x[c][2 * p + 1]));
+      }
+      const uint4 pk = pack8(y);
+      qf[c] = __builtin_bit_cast(v8bf, pk);
+    }
+  }
+}
+
+// normalise the O^T accumulators by the row sum and store one query row per lane (bf16, or fp8 with the consumer's input scale)
+template <int FMT>
+__device__ __forceinline__ void store_o(const AttnArgs& a, const v16f (&o)[4], float inv, int b, int h, int qrow, int hi) {
+  if (qrow >= a.L) return;
+  const long long orow = ((long long)b * a.L + qrow) * a.ld_out + a.col_off + h * 128;
+  if (a.out_fp8) {
+    const float qs = *a.q_scale[qrow < a.split ? 0 : 1];
+    unsigned char* op = (unsigned char*)a.out + orow;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + g * 8 + hi * 4;
+        *(unsigned*)(op + d) = cvt4_fp8<FMT>(q_prepare<FMT>(rbf(o[db][g * 4 + 0] * inv), qs), q_prepare<FMT>(rbf(o[db][g * 4 + 1] * inv), qs),
+                                             q_prepare<FMT>(rbf(o[db][g * 4 + 2] * inv), qs), q_prepare<FMT>(rbf(o[db][g * 4 + 3] * inv), qs));
+      }
+  } else {
+    u16* op = (u16*)a.out + orow;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + g * 8 + hi * 4;
+        uint2 v;
+        v.x = pack_bf2(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv);
+        v.y = pack_bf2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv);
+        *(uint2*)(op + d) = v;
+      }
+  }
+}
+
+}  // namespace
+
+// round-2 kernel (attention2.hip)
+int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s);

@@ -1,0 +1,148 @@
+"""Full-geometry parity cases (Flux-dev widths: hidden 3072 = 24 heads x 128, mlp 12288)  --  TEST INFRASTRUCTURE.
+
+Shared by oracle/gen_golden_full.py (build container: runs the UNMODIFIED reference beside the oracle, asserts equality, writes
+tests/golden/g10_full_*.safetensors) and tests/test_full_geometry_gpu.py (GPU box: re-runs the oracle on the host cores, checks
+it against the committed reference samples, then checks the HIP engine against the oracle layer by layer, teacher-forced).
+
+Cases (BASELINE.json configs[1], configs[2] and the full depth):
+  c2_2p2_L4608   2 double + 2 single blocks, 1024x1024 (Li 4096) + Lt 512, quantize_modulation, embedders in bf16
+  c3_2p2_L2816   2 + 2 blocks, 768x768 (Li 2304) + Lt 512, quantize_modulation + quantize_flow_embedder_layers
+  c2_19p38_L320  the whole 19 + 38-block model, 256x256 (Li 256) + Lt 64 (fp8 error accumulation through 57 residual blocks)
+Protocol per case: call 1 calibrates (every F8Linear takes its first amax trial, float8_quantize.py:220-238), the input scales are
+then frozen (`input_scale_initialized = True`, what the reference does after its 13th call, :239-246) and call 2 runs frozen with
+every intermediate recorded.  A full tensor at L = 4608 is tens of MB, so fixtures hold SAMPLES (first 256 + 768 evenly strided
+elements) plus an order-independent checksum of every recorded tensor.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict
+
+import torch
+
+import flux_oracle as fo
+
+CASES = {
+    "c2_2p2_L4608": dict(depth=2, single=2, height=1024, width=1024, txt_len=512, quant=dict(modulation=True, embedders=False),
+                         w_seed=11, in_seed=21, trace="all"),
+    "c3_2p2_L2816": dict(depth=2, single=2, height=768, width=768, txt_len=512, quant=dict(modulation=True, embedders=True),
+                         w_seed=12, in_seed=22, trace="all"),
+    "c2_19p38_L320": dict(depth=19, single=38, height=256, width=256, txt_len=64, quant=dict(modulation=True, embedders=False),
+                          w_seed=13, in_seed=23, trace="blocks"),
+}
+T_CALIB, T_FROZEN, GUIDANCE = 1.0, 0.75, 3.5
+N_HEAD, N_STRIDED = 256, 768
+
+
+def params_for(case: dict) -> fo.FluxParams:
+    return fo.FluxParams(depth=case["depth"], depth_single_blocks=case["single"])
+
+
+def make_case(name: str, synth):
+    """-> (case dict, FluxParams, state dict (CPU bf16), inputs dict).  `synth` = the fluxmi.synth module."""
+    case = CASES[name]
+    p = params_for(case)
+    sd = synth.make_state_dict(p, seed=case["w_seed"])
+    inp = synth.make_inputs(p, case["height"], case["width"], case["txt_len"], batch=1, seed=case["in_seed"], real_tokens=32)
+    return case, p, sd, inp
+
+
+def call_args(inp, t: float):
+    tv = torch.full((inp["img"].shape[0],), t, dtype=torch.bfloat16)
+    gv = torch.full((inp["img"].shape[0],), GUIDANCE, dtype=torch.bfloat16)
+    return (inp["img"], inp["img_ids"], inp["txt"], inp["txt_ids"], tv, inp["y"], gv)
+
+
+class FilteredTrace(dict):
+    """A trace dict that drops what the case does not record (the 19+38 case keeps block outputs only: a full trace is ~30 GB)."""
+
+    def __init__(self, mode):
+        super().__init__()
+        self.mode = mode
+
+    def __setitem__(self, k, v):
+        if self.mode == "all" or k in ("vec", "pe", "img_in.out", "txt_in.out") or k.endswith((".img_out", ".txt_out")) or (
+                k.startswith("single_blocks") and k.endswith(".out") and k.count(".") == 2):
+            super().__setitem__(k, v)
+
+
+def run_oracle(name: str, p, sd, inp, log=print):
+    """calibrating call, freeze, traced frozen call.  -> (oracle, pred_calib, pred_frozen, trace)"""
+    case = CASES[name]
+    t0 = time.time()
+    orc = fo.FluxOracle(sd, p, quantize=case["quant"])
+    log(f"[{name}] oracle built ({orc.n_f8()} F8Linear) in {time.time() - t0:.1f} s")
+    t0 = time.time()
+    with torch.inference_mode():
+        pred0 = orc.forward(*call_args(inp, T_CALIB))
+        log(f"[{name}] oracle calibrating call {time.time() - t0:.1f} s")
+        orc.freeze_input_scales()
+        tr = FilteredTrace(case["trace"])
+        t0 = time.time()
+        pred1 = orc.forward(*call_args(inp, T_FROZEN), trace=tr)
+        log(f"[{name}] oracle frozen call {time.time() - t0:.1f} s, {len(tr)} tensors recorded")
+    return orc, pred0, pred1, tr
+
+
+def sample_index(n: int) -> torch.Tensor:
+    if n <= N_HEAD + N_STRIDED:
+        return torch.arange(n)
+    head = torch.arange(N_HEAD)
+    strided = N_HEAD + (torch.arange(N_STRIDED, dtype=torch.int64) * (n - 1 - N_HEAD)) // (N_STRIDED - 1)
+    return torch.cat([head, strided])
+
+
+def as_words(t: torch.Tensor) -> torch.Tensor:
+    """raw storage words of a bf16 / fp8 / fp32 tensor as integers (for samples and checksums)."""
+    t = t.contiguous()
+    if t.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
+        return t.view(torch.uint8)
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16)
+    if t.dtype == torch.float32:
+        return t.view(torch.int32)
+    return t
+
+
+def digest(trace: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """name -> samples (storage words) and name + '#sum' -> [sum of words (int64), sum of |value| (fp64 bits)]."""
+    out = {}
+    for k, v in trace.items():
+        if not torch.is_tensor(v):
+            continue
+        w = as_words(v).reshape(-1)
+        out[k] = w[sample_index(w.numel())].clone()
+        out[k + "#sum"] = torch.stack([w.to(torch.int64).sum(), v.double().abs().sum().view(torch.int64)])
+    return out
+
+
+def _decode(w: torch.Tensor) -> torch.Tensor:
+    if w.dtype == torch.int16:
+        return w.view(torch.bfloat16).double()
+    if w.dtype == torch.uint8:
+        return w.view(torch.float8_e5m2).double()  # every quantised activation on this path is e5m2 (float8_quantize.py:43)
+    if w.dtype == torch.int32:
+        return w.view(torch.float32).double()
+    return w.double()
+
+
+def compare_digest(got: Dict[str, torch.Tensor], want: Dict[str, torch.Tensor]):
+    """-> (n_tensors, n bit-identical (samples AND whole-tensor checksums), worst relative L2 distance of a tensor's samples, its name).
+    Bit-identity is what the build container shows; another host CPU may select other GEMM / SDPA blockings inside torch, so the
+    callers gate on the distance and report the identity count."""
+    n = eq = 0
+    worst, worst_name = 0.0, ""
+    for k, w in want.items():
+        if k.endswith("#sum"):
+            continue
+        n += 1
+        g = got[k]
+        if torch.equal(got[k + "#sum"], want[k + "#sum"]) and torch.equal(g, w):
+            eq += 1
+            continue
+        gd, wd = _decode(g), _decode(w)
+        fin = torch.isfinite(gd) & torch.isfinite(wd)
+        d = float((gd[fin] - wd[fin]).norm() / wd[fin].norm().clamp_min(1e-30))
+        if d > worst:
+            worst, worst_name = d, k
+    return n, eq, worst, worst_name

@@ -133,6 +133,50 @@ def test_f8_gemm(ops, dev, cfg, shape, fmt):
     assert_close_mag(out, ref2, mag=noise, ulps=1.05, min_exact=0.98, what="vs torch._scaled_mm")
 
 
+PROD_SHAPES = {  # (groups of M rows, N, K): the launches of one Flux-dev 1024x1024 step
+    "double.qkv": ((512, 4096), 9216, 3072), "double.proj": ((512, 4096), 3072, 3072), "double.mlp0": ((512, 4096), 12288, 3072),
+    "double.mlp2": ((512, 4096), 3072, 12288), "single.linear1": ((4608,), 21504, 3072), "single.linear2": ((4608,), 3072, 15360),
+    "768.qkv": ((512, 2304), 9216, 3072), "768.linear2": ((2816,), 3072, 15360),
+}
+
+
+@pytest.mark.parametrize("which", list(PROD_SHAPES))
+def test_f8_gemm_production_shapes_auto_dispatch(ops, dev, which):
+    """The shapes and the DISPATCH the engine really uses (tile_cfg = -1: cost model, grouped txt + img launch, 256x256 ping-pong for
+    K = 3072, one-wave-per-SIMD for K >= 8192, the hybrid 256x256 + 128x128 peel of a thin last round) on identical fp8 operands:
+    <= 1 bf16 ulp of an fp64 evaluation on sampled rows (tile borders included), every column.   float8_quantize.py:284-292"""
+    from fluxmi import _lib
+
+    Ms, N, K = PROD_SHAPES[which]
+    g = torch.Generator().manual_seed(N + K + sum(Ms))
+    groups, keep, checks = [], [], []
+    for gi, M in enumerate(Ms):
+        a = (torch.randn(M, K, generator=g) * 2.0).bfloat16()
+        a[:, 3] += 1.5
+        w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+        w[1] *= 3.0
+        sa = fo.amax_to_scale(a.abs().max().float(), 57344.0)
+        a8 = fo.to_fp8_saturated(a, sa, 57344.0).to(torch.float8_e5m2)
+        w8, sb, sbr = fo.quantize_weight(w)
+        bias = torch.randn(N, generator=g).bfloat16()
+        sar = sa.reciprocal()
+        dv = [t.to(dev) for t in (a8, w8, bias, sar, sbr)]
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        keep += dv + [out]
+        groups.append(ops.make_group(ops._p(dv[0]), ops._p(dv[1]), ops._p(dv[2]), ops._p(dv[3]), ops._p(dv[4]), ops._p(out), M, K, N))
+        rows = sorted(set([0, 1, 127, 128, 255, 256, M // 2, M - 257, M - 256, M - 129, M - 128, M - 2, M - 1] + list(range(7, M, max(1, M // 23)))))
+        rows = torch.tensor([r for r in rows if 0 <= r < M])
+        checks.append((out, a8, w8, sar, sbr, bias, rows))
+    ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_BF16, -1)
+    torch.cuda.synchronize()
+    for gi, (out, a8, w8, sar, sbr, bias, rows) in enumerate(checks):
+        a = a8[rows]
+        ref = round_fp64_to_bf16(fo.scaled_mm_fp64(a, w8, sar, sbr, bias))
+        noise = accum_noise(a, w8, sar * sbr)
+        ex = assert_close_mag(out.cpu()[rows], ref, mag=noise, ulps=1.05, min_exact=0.98, what=f"{which} group {gi} M={out.shape[0]} N={N} K={K} vs fp64")
+        print(f"{which} group {gi}: {len(rows)} rows x {N} columns within 1 bf16 ulp of fp64, bit-exact {ex:.5f}")
+
+
 def accum_noise(a, w, s):
     """Magnitude (already in 'bf16-ulp units', i.e. multiplied by 2^7) of fp32 accumulation-order noise:
     16*sqrt(K)*2^-24 * sum_k|a||w| * s  (worst case is K*2^-24; the MX MFMA also aligns the 64 products of a block to
@@ -376,6 +420,57 @@ def test_attention(ops, dev, B, H, L, Lt):
     refq = torch.cat((fo.to_fp8_saturated(out[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float() / s0,
                       fo.to_fp8_saturated(out[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float() / s1), 1)
     assert torch.equal(deq, refq), f"fp8 attention output differs from quantise(bf16 output): {(deq != refq).float().mean().item()}"
+
+
+def _vt_layout(v, L):
+    """V^T in the attention kernels' layout: transposed, key order inside every 16-key group with bit2 <-> bit3 swapped, zero padded"""
+    B, H = v.shape[:2]
+    Lp = (L + 63) // 64 * 64
+    pos = torch.arange(Lp)
+    j = pos % 16
+    key = (pos // 16) * 16 + ((j & 3) | (((j >> 2) & 1) << 3) | (((j >> 3) & 1) << 2))
+    vpad = torch.zeros(B, H, Lp, 128, dtype=torch.bfloat16)
+    vpad[:, :, :L] = v
+    return vpad[:, :, key].transpose(-1, -2).contiguous()
+
+
+@pytest.mark.parametrize("L", [448, 1100, 4608])
+def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
+    """The round-2 kernel rescales O / l / the pending P tile only when a row max grew by more than 2^8 (guide T13).  The branch is
+    rare on random data, so it is FORCED: key rows are spiked against chosen query rows so that the row max jumps by far more than
+    the threshold at chosen tiles (first tile, an odd tile, an even tile, the last tile), some rows several times; every row of the
+    full tensor is checked against fp64, and the three builds -- deferred, exact running max (FLUXMI_ATTN_VAR=2) and the
+    independently written round-1 kernel (FLUXMI_ATTN_V=1) -- must agree to rounding."""
+    torch.manual_seed(81)
+    B, H = 1, 2
+    q = torch.randn(B, H, L, 128).bfloat16()
+    k = torch.randn(B, H, L, 128).bfloat16()
+    v = torch.randn(B, H, L, 128).bfloat16()
+    nt = (L + 63) // 64
+    # scores are q.k/sqrt(128)*log2(e) ~ N(0, 1.44) in the exp2 domain; a key equal to +7 x a query row scores ~ 7*128/11.3*1.44 = 114
+    for t_i, (row, tile, gain) in enumerate([(3, 0, 5.0), (3, 3, 7.0), (3, nt - 1, 9.0), (40, 2, 6.0), (41, nt - 2, 6.0), (L - 1, 1, 8.0),
+                                             (L // 2, nt // 2, 6.0), (L // 2, nt // 2 + 1, 8.0)]):
+        key = min(tile * 64 + 5 + t_i, L - 1)
+        k[:, :, key] = (q[:, :, row].float() * gain).bfloat16()
+    ref = fo.attention_fp64(q, k, v).transpose(1, 2).reshape(B, L, H * 128)
+    VT = _vt_layout(v, L)
+    d = lambda t: t.to(dev)
+    outs = {}
+    for name, env in (("deferred", {}), ("exact", {"FLUXMI_ATTN_VAR": "2"}), ("dma_in_pv", {"FLUXMI_ATTN_VAR": "1"}), ("round1", {"FLUXMI_ATTN_V": "1"})):
+        for kk in ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V"):
+            monkeypatch.delenv(kk, raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        outs[name] = ops.attention(d(q), d(k), d(VT)).cpu()
+        err = (outs[name].double() - ref).abs().max().item()
+        assert torch.isfinite(outs[name]).all() and err <= 2e-2 * v.abs().max().item(), f"{name}: max abs err {err:.3e} vs fp64"
+    for name in ("exact", "dma_in_pv", "round1"):
+        dd = (outs["deferred"].float() - outs[name].float()).abs().max().item()
+        assert dd <= 2e-2 * v.abs().max().item(), f"deferred vs {name}: {dd:.3e}"
+    same = (outs["deferred"] == outs["exact"]).float().mean().item()
+    print(f"L={L}: max |err| vs fp64 deferred {(outs['deferred'].double() - ref).abs().max().item():.2e} / exact "
+          f"{(outs['exact'].double() - ref).abs().max().item():.2e} / round-1 {(outs['round1'].double() - ref).abs().max().item():.2e}; "
+          f"deferred == exact on {same:.4f} of the outputs")
 
 
 @pytest.mark.parametrize("L,Lt", [(320, 64), (200, 40)])

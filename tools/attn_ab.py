@@ -1,0 +1,47 @@
+"""Interleaved A/B of the attention kernels in ONE process (guide rule 24): round-1 kernel (FLUXMI_ATTN_V=1) vs the round-2 pipeline and
+its variants (FLUXMI_ATTN_VAR bit 0 = refills in the PV half, bit 1 = exact running max), Flux-dev shapes, random data.
+    python tools/attn_ab.py [--rounds 5] [--iters 20] [--L 4608 2816]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flux-fp8-api_amd"))
+import torch
+from fluxmi import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--L", type=int, nargs="+", default=[4608, 2816, 8192]); ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--rounds", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}), ("r2", {}), ("r2 dma-in-pv", {"FLUXMI_ATTN_VAR": "1"}), ("r2 exact-max", {"FLUXMI_ATTN_VAR": "2"})]
+
+
+def setenv(env):
+    for k in ("FLUXMI_ATTN_V", "FLUXMI_ATTN_VAR"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+
+
+for L in a.L:
+    B, H = 1, 24
+    Lp = (L + 63) // 64 * 64
+    q = torch.randn(B, H, L, 128, device=dev).bfloat16(); k = torch.randn(B, H, L, 128, device=dev).bfloat16()
+    vt = torch.randn(B, H, 128, Lp, device=dev).bfloat16()
+    one = torch.tensor(1.0, device=dev)
+    o8 = torch.empty(B, L, H * 128, dtype=torch.float8_e5m2, device=dev)
+    res = {n: [] for n, _ in VARIANTS}
+    for n, env in VARIANTS:
+        setenv(env)
+        for _ in range(3): ops.attention(q, k, vt, q_scale0=one, out=o8)
+    torch.cuda.synchronize()
+    for r in range(a.rounds):
+        for n, env in VARIANTS:
+            setenv(env)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters): ops.attention(q, k, vt, q_scale0=one, out=o8)
+            e1.record(); torch.cuda.synchronize()
+            res[n].append(e0.elapsed_time(e1) / a.iters * 1e-3)
+    fl = 4 * L * L * 128 * H * B
+    for n, _ in VARIANTS:
+        ts = sorted(res[n]); t = ts[len(ts) // 2]
+        print(f"L={L:5d} {n:14s}: median {fl / t / 1e12:7.1f} TF/s ({t * 1e6:6.1f} us)  best {fl / ts[0] / 1e12:7.1f}  frac of 2.5 PF {fl / t / 2.5e15:.3f}", flush=True)
