@@ -1,23 +1,34 @@
 #!/usr/bin/env python
-"""Headline benchmark: denoise it/s, Flux-dev 1024x1024, fp8 F8Linear + bf16 flow (BASELINE.json configs[1]).
+"""Headline benchmark: denoise it/s of the Flux hot path on MI355X (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--config {1,2,3,5}]     (N>1: launched by torch.distributed.run, one rank per GPU)
 
-One "step" = one pass of the hot path = one Flux.forward + Euler update of the denoise loop
-(reference flux_pipeline.py:641-651) on one 1024x1024 latent (Li=4096 image tokens + Lt=512 text tokens), inputs
-resident in HBM, replayed from the captured hipGraph.  Synthetic seeded request + random-init weights of the
-Flux-dev architecture (no checkpoint exists offline).  Setup (untimed, like the reference's compile() warm-up,
+One "step" = one pass of the hot path = one Flux.forward + Euler update of the denoise loop (reference flux_pipeline.py:641-651)
+on one latent per GPU, inputs resident in HBM, replayed from the captured hipGraph.  Synthetic seeded request + random-init weights
+of the Flux architecture (no checkpoint exists offline).  Setup (untimed, like the reference's compile() warm-up,
 flux_pipeline.py:197-212): 13 calibrating steps that freeze the F8Linear input scales.
-N GPUs = N batch-sharded replicas (1 image per GPU, weak scaling); the only collective is the one-off RCCL
-broadcast of the T5/CLIP embeddings + noise before the loop.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel -- the fp8 MX-MFMA GEMM -- from HIP-event
-timings taken live in this process on the launch stream; `cpu_baseline` times the oracle's bf16 flow path (a port of
-the reference's CPU path) on the host cores for a bounded sample.
+--config selects the BASELINE.json configuration (default 2 = the one the metric is quoted on):
+  1  Flux-schnell 256x256, 1-step requests, bf16 flow (nn.Linear, no fp8): weight-stream bound -> roofline in GB/s of HBM
+  2  Flux-dev 1024x1024, 28 steps, fp8 F8Linear (quantize_modulation) + bf16 flow                       [default]
+  3  Flux-dev 768x768, quantize_modulation + quantize_flow_embedder_layers
+  5  config 2 + a synthetic rank-16 LoRA on every attention / MLP linear, fused into the fp8 weights (scale 1.0) before timing
+  (config 4 = config 2 launched with --gpus 8: batch-sharded replicas, one image per GPU)
+N GPUs = N batch-sharded replicas (weak scaling); collectives: one RCCL broadcast of the T5/CLIP embeddings + noise before the
+loop and, during calibration only, the per-layer amax MAX-reduction.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel of the configuration (the fp8 MX-MFMA GEMM; for config 1
+the bf16 GEMM's weight stream) from HIP-event timings taken live in this process on the launch stream; `cpu_baseline` times the
+reference's CPU flow path on the host cores for a bounded sample: the UNMODIFIED reference when /root/reference is present
+(build container), otherwise the oracle port that is pinned bit-for-bit to it (oracle/gen_golden*.py).
+  python bench.py --cpu-baseline-only [--config C]      runs only that leg (no GPU needed)
+  python bench.py --pmc                                  additionally collects the rocprofv3 PMC counters (HBM traffic, MFMA busy) live
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,13 +36,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "flux-fp8-api_amd"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-H100_COMPILED_ITS = 11.5  # reference README.md:25 -- the only published number for this metric (other hardware)
-FP8_PEAK_TFLOPS = 5000.0  # MI355X dense fp8 MFMA (MX-scaled K=128/64 opcodes), /opt/skills/guides/MI355X_MICROARCH.md
+H100_COMPILED = {2: 11.5, 5: 11.5, 3: 20.8}  # reference README.md:25,34 -- the only published numbers for this metric (other hardware)
+FP8_PEAK_TFLOPS = 5000.0   # MI355X dense fp8 MFMA (MX-scaled K=128/64 opcodes), /opt/skills/guides/MI355X_MICROARCH.md
+BF16_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0
+
+CONFIGS = {
+    1: dict(name="Flux-schnell 256x256, 1-step requests, bf16 flow (no fp8)", schnell=True, height=256, width=256, txt_len=256, quant=None,
+            steps_per_request=1, lora=False),
+    2: dict(name="Flux-dev 1024x1024, fp8 F8Linear + bf16 flow", schnell=False, height=1024, width=1024, txt_len=512,
+            quant=dict(modulation=True, embedders=False), steps_per_request=None, lora=False),
+    3: dict(name="Flux-dev 768x768, quantize_modulation + quantize_flow_embedder_layers", schnell=False, height=768, width=768, txt_len=512,
+            quant=dict(modulation=True, embedders=True), steps_per_request=None, lora=False),
+    5: dict(name="Flux-dev 1024x1024 + rank-16 LoRA fused into the fp8 weights (scale 1.0)", schnell=False, height=1024, width=1024, txt_len=512,
+            quant=dict(modulation=True, embedders=False), steps_per_request=None, lora=True),
+}
 
 
-def flux_dev_gemm_shapes(Li=4096, Lt=512, H=3072):
-    """(name, Ms, N, K, launches/step, fused epilogue) of the six grouped F8Linear GEMM launches of one step:
-    exactly what engine.hip issues in fused mode -- txt+img streams of a double block share one grouped launch."""
+def gemm_shapes(Li, Lt, H=3072):
+    """(name, Ms, N, K, launches/step, fused epilogue) of the six grouped Linear launches of one step: exactly what
+    engine.hip issues in fused mode -- txt+img streams of a double block share one grouped launch."""
     L, Hm = Li + Lt, 4 * H
     return [
         ("double.qkv(txt+img)", (Lt, Li), 3 * H, H, 19, "bf16"), ("double.proj(txt+img)", (Lt, Li), H, H, 19, "gate_resid"),
@@ -40,50 +64,72 @@ def flux_dev_gemm_shapes(Li=4096, Lt=512, H=3072):
     ]
 
 
-def linear_flops_per_step(Li=4096, Lt=512, H=3072):
-    return sum(2.0 * sum(Ms) * N * K * cnt for _, Ms, N, K, cnt, _e in flux_dev_gemm_shapes(Li, Lt, H))
+def linear_flops_per_step(Li, Lt, H=3072):
+    return sum(2.0 * sum(Ms) * N * K * cnt for _, Ms, N, K, cnt, _e in gemm_shapes(Li, Lt, H))
 
 
-def measure_gemm_roofline(torch, ops, dev, iters=10):
-    """Average duration of one F8Linear GEMM launch of the step: the six launch shapes WITH their fused epilogues (GELU+quantise,
-    gate*y+x in place, qkv|mlp split), weighted by their count per step; HIP events on the launch stream, random operands.
-    Returns (flops per launch, seconds per launch, per-shape table)."""
+def kernel_source_key():
+    """content hash of the GEMM / attention kernel sources: counter files collected for other sources are reported as stale (null)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "flux-fp8-api_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.startswith(("gemm", "attention", "common", "api")) and f.endswith((".hip", ".h", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
+    """Average duration of one Linear GEMM launch of the step: the six launch shapes WITH their fused epilogues (fp8 path: GELU+quantise,
+    gate*y+x in place, qkv|mlp split; bf16 path of config 1: plain bf16 outputs, what the unfused engine issues), weighted by their
+    count per step; HIP events on the launch stream, random operands.  Returns (flops, algorithmic bytes, seconds) per launch + table."""
     from fluxmi import _lib
 
     one = torch.tensor(1.0, device=dev)
     H = 3072
-    # the engine hands frozen-scale GELU -> F8Linear epilogues a 64 KiB bf16 -> fp8 table (fluxmi_gemm_group_t.q_lut), so do we
-    lut = ops.build_quant_lut(one, _lib.E5M2, act=1) if os.environ.get("FLUXMI_QLUT", "1") != "0" else None
+    lut = ops.build_quant_lut(one, _lib.E5M2, act=1) if (fp8 and os.environ.get("FLUXMI_QLUT", "1") != "0") else None
     lut_ptr = lut.data_ptr() if lut is not None else None
-    tot_t, tot_f, n_launch, table = 0.0, 0.0, 0, []
-    for name, Ms, N, K, cnt, epi in flux_dev_gemm_shapes():
+    tot_t = tot_f = tot_b = 0.0
+    n_launch, table = 0, []
+    for name, Ms, N, K, cnt, epi in gemm_shapes(Li, Lt):
         groups, keep = [], []
+        nbytes = 0
         for M in Ms:
-            a = (torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2)
-            w = (torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn)
+            if fp8:
+                a = (torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2)
+                w = (torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn)
+            else:
+                a = torch.randn(M, K, device=dev).bfloat16()
+                w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+                epi = "bf16"
             bias = torch.randn(N, device=dev).bfloat16()
             keep += [a, w, bias]
             kw = {}
+            eb = 1 if fp8 else 2
+            nbytes += (M * K + N * K) * eb  # operands in; outputs added below
             if epi == "bf16":
                 o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
                 code = _lib.EPI_BF16
+                nbytes += M * N * 2
             elif epi == "gelu_quant":
                 o = torch.empty(M, N, dtype=torch.float8_e5m2, device=dev)
                 code, kw = _lib.EPI_GELU_QUANT, dict(q_scale=one.data_ptr(), q_lut=lut_ptr)
+                nbytes += M * N
             elif epi == "gate_resid":
                 o = torch.randn(M, N, device=dev).bfloat16()  # residual stream, updated in place
                 gate = torch.randn(N, device=dev).bfloat16()
                 keep.append(gate)
                 code, kw = _lib.EPI_GATE_RESID, dict(gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N)
+                nbytes += 2 * M * N * 2
             else:  # split: q|k|v bf16 to C, gelu(mlp) fp8 into the [attn | mlp] buffer at column H
                 o = torch.empty(M, 3 * H, dtype=torch.bfloat16, device=dev)
                 o2 = torch.empty(M, 5 * H, dtype=torch.float8_e5m2, device=dev)
                 keep.append(o2)
                 code, kw = _lib.EPI_SPLIT, dict(C2=o2.data_ptr(), ldc2=5 * H, split_n=3 * H, c2_col0=H, q_scale=one.data_ptr(), q_lut=lut_ptr)
+                nbytes += M * 3 * H * 2 + M * 4 * H
             keep.append(o)
-            groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr(), one.data_ptr(), o.data_ptr(), M, K,
-                                         o.stride(0), **kw))
-        fn = lambda: ops.gemm_grouped(groups, N, K, True, _lib.E5M2, code, -1)
+            groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr() if fp8 else None, one.data_ptr() if fp8 else None,
+                                         o.data_ptr(), M, K, o.stride(0), **kw))
+        fn = lambda: ops.gemm_grouped(groups, N, K, fp8, _lib.E5M2, code, -1)
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -94,20 +140,23 @@ def measure_gemm_roofline(torch, ops, dev, iters=10):
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e-3 / iters
         f = 2.0 * sum(Ms) * N * K
-        table.append({"launch": name, "epilogue": epi, "per_step": cnt, "us": round(t * 1e6, 1), "tflops": round(f / t / 1e12, 1)})
+        table.append({"launch": name, "epilogue": epi, "per_step": cnt, "us": round(t * 1e6, 1), "tflops": round(f / t / 1e12, 1),
+                      "alg_gbs": round(nbytes / t / 1e9, 1)})
         tot_t += t * cnt
         tot_f += f * cnt
+        tot_b += nbytes * cnt
         n_launch += cnt
         del groups, keep
-    return tot_f / n_launch, tot_t / n_launch, table
+    return tot_f / n_launch, tot_b / n_launch, tot_t / n_launch, table
 
 
-def measure_attention(torch, ops, dev, iters=10, L=4608, H=24):
+def measure_attention(torch, ops, dev, L, iters=10, H=24):
     """The second kernel of the step (57 launches): joint attention at the step's shape, bf16 MFMA, fp8 output, HIP events on the
     launch stream.  Reported beside the GEMM roofline; `peak` is the dense bf16 MFMA figure."""
+    Lp = (L + 63) // 64 * 64
     q = torch.randn(1, H, L, 128, device=dev).bfloat16()
     k = torch.randn(1, H, L, 128, device=dev).bfloat16()
-    vt = torch.randn(1, H, 128, L, device=dev).bfloat16()
+    vt = torch.randn(1, H, 128, Lp, device=dev).bfloat16()
     one = torch.tensor(1.0, device=dev)
     o8 = torch.empty(1, L, H * 128, dtype=torch.float8_e5m2, device=dev)
     for _ in range(2):
@@ -120,91 +169,110 @@ def measure_attention(torch, ops, dev, iters=10, L=4608, H=24):
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / iters
     f = 4.0 * L * L * 128 * H
-    return {"kernel": "attention_kernel<8 waves, 4-deep ring> (bf16 MFMA 32x32x16, fp8 output)", "per_step": 57, "us": round(t * 1e6, 1),
-            "achieved": round(f / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / 2500.0, 4),
-            "note": "432 workgroups on 256 CUs = 1.69 rounds: at most 84 % of the CU-time can be busy at this shape"}
+    wgs = ((L + 255) // 256) * H
+    kern = "attention_kernel (round 1)" if os.environ.get("FLUXMI_ATTN_V") == "1" else "attention2_kernel (skewed pipeline, deferred rescale)"
+    return {"kernel": kern + ", bf16 MFMA 32x32x16, fp8 output", "per_step": 57, "us": round(t * 1e6, 1),
+            "achieved": round(f / t / 1e12, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / BF16_PEAK_TFLOPS, 4),
+            "note": f"{wgs} workgroups on 256 CUs = {wgs / 256:.2f} rounds"}
 
 
-def gemm_traffic_bytes():
-    """HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-    MI355X_MICROARCH.md "HBM"); collected offline by tools/traffic.sh and committed as profiles/r01_gemm_traffic.json."""
+def pmc_file(kind, cfg_id):
+    return os.path.join(ROOT, "profiles", f"r02_{kind}_config{cfg_id}.json")
+
+
+def read_pmc(kind, cfg_id):
+    """Counter values collected by `bench.py --pmc` (rocprofv3 PMC passes over tools/gemm_probe.py); null when the kernel sources
+    changed since (the file is keyed by a content hash of csrc/gemm*, attention*, common.h, api.cpp)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")) as f:
-            return json.load(f)["bytes_per_launch"]
+        with open(pmc_file(kind, cfg_id)) as f:
+            d = json.load(f)
+        return d if d.get("source_key") == kernel_source_key() else None
     except Exception:
         return None
 
 
-def gemm_mfma_busy(table):
-    """Matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD cycles) of the step's GEMM launches, weighted by
-    the launch times measured in THIS run; the per-shape counter values were collected offline with tools/clock_probe.sh and are
-    committed as profiles/r01_gemm_mfma_util.{txt,json}.  Reported beside `frac` because `frac` is priced against the 2.4 GHz spec peak
-    while the chip clocks these kernels at 1.6-2.0 GHz under its power limit."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_gemm_mfma_util.json")) as f:
-            per = json.load(f)["per_launch"]
-        num = den = 0.0
-        for row in table:
-            if row["launch"] in per:
-                w = row["us"] * row["per_step"]
-                num, den = num + w * per[row["launch"]], den + w
-        return round(num / den, 4) if den else None
-    except Exception:
-        return None
+def collect_pmc(cfg_id, Li, Lt, table):
+    """Live rocprofv3 PMC passes (separate --pmc runs, never combined with traces: MI355X_MICROARCH.md 'HBM' / 'rocprofv3 PMC slots'):
+    FETCH_SIZE (x2: gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE -> HBM bytes per launch; SQ_VALU_MFMA_BUSY_CYCLES over
+    GRBM_GUI_ACTIVE/8 x 1024 SIMDs -> matrix-pipe busy fraction.  Writes profiles/r02_{traffic,mfma}_config<id>.json."""
+    out_dir = os.path.join(ROOT, "gpurun_out", f"pmc_config{cfg_id}")
+    os.makedirs(out_dir, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    per_traffic, per_busy = {}, {}
+    for name, Ms, N, K, cnt, epi in gemm_shapes(Li, Lt):
+        M = sum(Ms)
+        tag = name.split("(")[0].replace(".", "_")
+        vals = {}
+        for pi, counters in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"])):
+            d = os.path.join(out_dir, f"{tag}_p{pi}")
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "gemm_probe.py"), "--shape", f"{M},{N},{K}", "--cfg", "-1", "--iters", "4",
+                   "--epi", {"bf16": "bf16", "gate_resid": "gate", "gelu_quant": "gelu", "split": "bf16"}[epi]]
+            try:
+                subprocess.run(cmd, env=env, cwd="/tmp", check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+                import csv
+                import glob
+
+                for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    with open(path) as f:
+                        for row in csv.DictReader(f):
+                            if "gemm" in row.get("Kernel_Name", ""):
+                                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            except Exception as ex:  # noqa
+                vals["error"] = str(ex)
+        mean = lambda k: (sum(vals[k]) / len(vals[k])) if vals.get(k) else None
+        fs, ws, ga, mb = mean("FETCH_SIZE"), mean("WRITE_SIZE"), mean("GRBM_GUI_ACTIVE"), mean("SQ_VALU_MFMA_BUSY_CYCLES")
+        if fs is not None and ws is not None:
+            per_traffic[name] = (2.0 * fs + ws) * 1024.0  # KiB counters
+        if ga and mb:
+            per_busy[name] = mb / (ga / 8.0 * 1024.0)
+    key = kernel_source_key()
+    w = {r["launch"]: r["per_step"] for r in table}
+    if per_traffic:
+        tot = sum(per_traffic[n] * w[n] for n in per_traffic) / sum(w[n] for n in per_traffic)
+        json.dump({"source_key": key, "bytes_per_launch": tot, "per_launch": per_traffic,
+                   "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/gemm_probe.py --cfg -1; (2*FETCH_SIZE + WRITE_SIZE) KiB"},
+                  open(pmc_file("traffic", cfg_id), "w"), indent=1)
+    if per_busy:
+        json.dump({"source_key": key, "per_launch": per_busy,
+                   "how": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), tools/gemm_probe.py --cfg -1"},
+                  open(pmc_file("mfma", cfg_id), "w"), indent=1)
 
 
-def cpu_baseline(torch, budget_s=25.0):
-    """Reference CPU flow path (bf16 nn.Linear, no fp8) as restated by oracle/flux_oracle.py, on the host cores:
-    one DoubleStreamBlock + one SingleStreamBlock at the 1024^2 sequence length, extrapolated x19 / x38."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import flux_oracle as fo
-    from fluxmi import synth
+# ---------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg_id):
+    """The reference's CPU flow path on the host cores, bounded sample: runs oracle/cpu_baseline.py in its own interpreter (the
+    unmodified reference's `modules` / `util` packages shadow this repo's same-named host modules, so the two cannot share a process)."""
+    C = CONFIGS[cfg_id]
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--height", str(C["height"]), "--width", str(C["width"]),
+           "--txt-len", str(C["txt_len"])] + (["--schnell", "--full-step"] if C["schnell"] else [])
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1]
+    return json.loads(out)
 
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # pick the thread count that is actually fastest on this host (containers often expose more CPUs than their quota)
-    probe_a = torch.randn(1024, 3072).bfloat16()
-    probe_w = torch.randn(3072, 3072).bfloat16()
-    best_t, cores = 1e30, 1
-    for n in sorted({1, 4, 8, 16, 32, 64, 128, avail}):
-        if n > avail:
-            continue
-        torch.set_num_threads(n)
-        torch.nn.functional.linear(probe_a, probe_w)
-        t0 = time.time()
-        for _ in range(3):
-            torch.nn.functional.linear(probe_a, probe_w)
-        dt = time.time() - t0
-        if dt < best_t:
-            best_t, cores = dt, n
-    torch.set_num_threads(cores)
-    p = fo.FluxParams(depth=1, depth_single_blocks=1)
-    sd = synth.make_state_dict(p, seed=0)
-    orc = fo.FluxOracle(sd, p, quantize=None)
-    Li, Lt, H = 4096, 512, p.hidden_size
-    g = torch.Generator().manual_seed(0)
-    img = torch.randn(1, Li, H, generator=g).bfloat16()
-    txt = torch.randn(1, Lt, H, generator=g).bfloat16()
-    vec = torch.randn(1, H, generator=g).bfloat16()
-    img_ids, txt_ids = fo.make_ids(1, 64, 64, Lt, torch.bfloat16)
-    pe = fo.rope_table(torch.cat((txt_ids, img_ids), 1), p.axes_dim, p.theta, torch.bfloat16)
-    with torch.inference_mode():
-        t0 = time.time()
-        orc.double_block(0, img, txt, vec, pe)  # warm-up
-        orc.single_block(0, torch.cat((txt, img), 1), vec, pe)
-        warm = time.time() - t0
-        reps = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
-        t0 = time.time()
-        for _ in range(reps):
-            orc.double_block(0, img, txt, vec, pe)
-        td = (time.time() - t0) / reps
-        t0 = time.time()
-        for _ in range(reps):
-            orc.single_block(0, torch.cat((txt, img), 1), vec, pe)
-        ts = (time.time() - t0) / reps
-    step_s = 19 * td + 38 * ts
-    return {"value": 1.0 / step_s, "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"bf16 flow path (no fp8) of the oracle: 1 DoubleStreamBlock ({td:.3f} s) + 1 SingleStreamBlock ({ts:.3f} s) at "
-                      f"L=4608, {reps} reps each, extrapolated to 19+38 blocks = {step_s:.1f} s/step"}
+
+def synthetic_lora(p, rank=16, seed=5):
+    """rank-16 LoRA on every attention / MLP linear of the model (BFL-dotted keys, what Flux.load_lora takes as a dict;
+    lora_loading.py:608-612): fused qkv layers get the 'uneven rank' form A [3r, K], B [3N', r]."""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    H, Hm = p.hidden_size, int(p.hidden_size * p.mlp_ratio)
+    lora = {}
+
+    def add(name, N, K, uneven=False):
+        lora[name + ".lora_A.weight"] = torch.randn((3 if uneven else 1) * rank, K, generator=g) * 0.02
+        lora[name + ".lora_B.weight"] = torch.randn(N, rank, generator=g) * 0.02
+
+    for i in range(p.depth):
+        for s in ("img", "txt"):
+            add(f"double_blocks.{i}.{s}_attn.qkv", 3 * H, H, True)
+            add(f"double_blocks.{i}.{s}_attn.proj", H, H)
+            add(f"double_blocks.{i}.{s}_mlp.0", Hm, H)
+            add(f"double_blocks.{i}.{s}_mlp.2", H, Hm)
+    for i in range(p.depth_single_blocks):
+        add(f"single_blocks.{i}.linear1", 3 * H + Hm, H)
+        add(f"single_blocks.{i}.linear2", H, H + Hm)
+    return lora
 
 
 def main():
@@ -212,14 +280,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=28)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--pmc", action="store_true", help="collect the rocprofv3 PMC counters live (adds ~2 min)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--depth", type=int, default=None, help="debug only: fewer blocks (the result is then flagged invalid)")
     args = ap.parse_args()
+    C = CONFIGS[args.config]
 
     import torch
+
+    if args.cpu_baseline_only:
+        print(json.dumps({"config": args.config, "workload": C["name"], "cpu_baseline": cpu_baseline(args.config)}), flush=True)
+        return
+
     import torch.distributed as td
 
     from fluxmi import dist as fdist
@@ -232,22 +307,30 @@ def main():
 
     import util
     from float8_quantize import quantize_flow_transformer_and_dispatch_float8
-    from fluxmi import ops, synth
+    from fluxmi import _lib, ops, synth
 
-    cfg = util.load_config(util.ModelVersion.flux_dev, flow_dtype="bfloat16", quantize_modulation=True, quantize_flow_embedder_layers=False)
+    cfg = util.load_config(util.ModelVersion.flux_schnell if C["schnell"] else util.ModelVersion.flux_dev, flow_dtype="bfloat16",
+                           quantize_modulation=bool(C["quant"] and C["quant"]["modulation"]),
+                           quantize_flow_embedder_layers=bool(C["quant"] and C["quant"]["embedders"]))
     if args.depth is not None:
         cfg.params.depth, cfg.params.depth_single_blocks = args.depth, 2 * args.depth
     p = cfg.params
+    spr = C["steps_per_request"] or args.steps          # steps per denoise request (config 1: 1-step requests)
+    n_req = args.steps // spr
     t_setup = time.time()
     with torch.inference_mode():
         sd = synth.make_state_dict(p, seed=0, device=dev)
         model = util.load_flow_model(cfg, sd)
         del sd
-        quantize_flow_transformer_and_dispatch_float8(model, dev, flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
-                                                      quantize_modulation=True, quantize_flow_embedder_layers=False)
+        if C["quant"] is not None:
+            quantize_flow_transformer_and_dispatch_float8(model, dev, flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
+                                                          quantize_modulation=C["quant"]["modulation"],
+                                                          quantize_flow_embedder_layers=C["quant"]["embedders"])
+        else:
+            model.to(dev)
         torch.cuda.empty_cache()
-        # request: rank 0 plays the text-encoder rank; ONE RCCL broadcast of embeddings + noise (SURVEY.md §8e)
-        inp = synth.make_inputs(p, args.height, args.width, 512, batch=world, seed=0)
+        # request: rank 0 plays the text-encoder rank; ONE RCCL broadcast of embeddings + noise (SURVEY.md 8e)
+        inp = synth.make_inputs(p, C["height"], C["width"], C["txt_len"], batch=world, seed=0)
         txt, vec, img = (inp[k].to(dev) for k in ("txt", "y", "img"))
         if world > 1:
             if rank != 0:
@@ -256,30 +339,50 @@ def main():
         lo, hi = fdist.shard_bounds(world, rank, world)
         txt, vec, img = txt[lo:hi].contiguous(), vec[lo:hi].contiguous(), img[lo:hi].contiguous()
         img_ids, txt_ids = inp["img_ids"][lo:hi].to(dev), inp["txt_ids"][lo:hi].to(dev)
-        Li = img.shape[1]
-        sched = lambda n: util_schedule(n, Li)
-        # calibration (untimed): 13 unfused steps freeze every F8Linear input scale
-        lat = model.denoise(img, img_ids, txt, txt_ids, vec, sched(13), guidance=3.5, use_graph=False)
-        assert model.calibration_state()[0]
-        if world > 1:  # the reference calibrates on the whole batch: share the running amax values, then re-freeze (float8_quantize.py:227)
-            fdist.sync_calibration(model.f8_modules())
-            model.rebind_weights()
+        Li, Lt = img.shape[1], txt.shape[1]
+        sched = lambda n: util_schedule(n, Li, shift=not C["schnell"])
+        nranks = td.get_world_size() if world > 1 else 1
+        backend = td.get_backend() if world > 1 else None
+        if C["quant"] is not None:
+            # calibration (untimed): 13 unfused steps freeze every F8Linear input scale.  Batch-sharded replicas MAX-reduce each
+            # layer's amax inside every calibrating step (float8_quantize.py:227 takes it over the whole batch)
+            if world > 1:
+                model.enable_amax_exchange()
+            model.denoise(img, img_ids, txt, txt_ids, vec, sched(13), guidance=3.5, use_graph=False)
+            if world > 1:
+                model.enable_amax_exchange(False)
+            assert model.calibration_state()[0]
+        lora_s = None
+        if C["lora"]:
+            t0 = time.time()
+            model.load_lora(synthetic_lora(p), 1.0, name="bench-rank16")
+            torch.cuda.synchronize()
+            lora_s = time.time() - t0
         if args.warmup > 0:
-            model.denoise(img, img_ids, txt, txt_ids, vec, sched(max(args.warmup, 2)), guidance=3.5, use_graph=not args.no_graph)
+            model.denoise(img, img_ids, txt, txt_ids, vec, sched(max(min(args.warmup, spr), 2) if spr > 1 else 1), guidance=3.5,
+                          use_graph=not args.no_graph)
+            if spr == 1:
+                for _ in range(max(args.warmup - 1, 1)):
+                    model.denoise(img, img_ids, txt, txt_ids, vec, sched(1), guidance=3.5, use_graph=not args.no_graph)
         torch.cuda.synchronize()
         setup_s = time.time() - t_setup
 
-        ts = sched(args.steps)
+        ts = sched(spr)
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = model.denoise(img, img_ids, txt, txt_ids, vec, ts, guidance=3.5, use_graph=not args.no_graph)
+        ev_ms = 0.0
+        for _ in range(n_req):
+            out = model.denoise(img, img_ids, txt, txt_ids, vec, ts, guidance=3.5, use_graph=not args.no_graph)
         torch.cuda.synchronize()
         if world > 1:
             td.barrier()
         elapsed = time.perf_counter() - t0
         finite = bool(torch.isfinite(out).all())
+        # engine-side meter: hipEvents recorded on the stream around the table build + graph replays of the LAST request
+        ms_ev, n_ev = _lib.C.c_float(0), _lib.C.c_int(0)
+        _lib.call("fluxmi_engine_last_timing", model._engine, _lib.C.byref(ms_ev), _lib.C.byref(n_ev))
         if world > 1:
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -287,38 +390,59 @@ def main():
 
         result = None
         if rank == 0:
-            ms_per_step = elapsed / args.steps * 1e3
-            its = world * args.steps / elapsed
-            lin_flops = linear_flops_per_step(Li)
-            flops_per_launch, sec_per_launch, gemm_table = (measure_gemm_roofline(torch, ops, dev) if (args.height, args.width) == (1024, 1024)
-                                                            else (0.0, 1.0, []))
-            achieved = flops_per_launch / sec_per_launch / 1e12
+            steps_done = n_req * spr
+            ms_per_step = elapsed / steps_done * 1e3
+            its = world * steps_done / elapsed
+            lin_flops = linear_flops_per_step(Li, Lt)
+            fp8 = C["quant"] is not None
+            fl, by, sec, gemm_table = measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=fp8)
+            if args.pmc and world == 1 and fp8:
+                collect_pmc(args.config, Li, Lt, gemm_table)
+            traffic, busy = read_pmc("traffic", args.config), read_pmc("mfma", args.config)
+            busy_w = None
+            if busy:
+                num = den = 0.0
+                for row in gemm_table:
+                    if row["launch"] in busy["per_launch"]:
+                        w = row["us"] * row["per_step"]
+                        num, den = num + w * busy["per_launch"][row["launch"]], den + w
+                busy_w = round(num / den, 4) if den else None
+            if fp8:
+                roof = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_w1_kernel <fp8 MX-MFMA 32x32x64, 256x256 tiles> (the 152 grouped "
+                                                    "F8Linear GEMM launches of a step, fused epilogues included)",
+                        "achieved": round(fl / sec / 1e12, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / FP8_PEAK_TFLOPS, 4)}
+            else:
+                roof = {"bound": "hbm", "kernel": "bf16 MFMA GEMM at M = 512 (weight-stream bound: 23.8 GB of bf16 weights per step)",
+                        "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4)}
+            roof.update({"traffic": traffic["bytes_per_launch"] if traffic else None,
+                         "traffic_note": None if traffic else "no PMC file for the current kernel sources (run bench.py --pmc)",
+                         "flops_per_launch": fl, "algorithmic_bytes_per_launch": by, "avg_launch_us": round(sec * 1e6, 2),
+                         "mfma_busy_frac_pmc": busy_w, "launches": gemm_table,
+                         "attention": measure_attention(torch, ops, dev, Li + Lt)})
             result = {
-                "metric": "denoise it/s at 1024x1024, Flux-dev, fp8 F8Linear + bf16 flow",
-                "value": round(its, 4), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "metric": "denoise it/s, " + C["name"],
+                "value": round(its, 4), "unit": "it/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "fp8_e4m3 weights x fp8_e5m2 activations (fp32 accumulate), bf16 flow",
-                "data": "synthetic seeded request + random-init Flux-dev weights (no checkpoint available offline)",
-                "config": {"workload": f"Flux-dev {args.height}x{args.width}, batch 1 per GPU, Li={Li}+Lt=512 tokens, 19 double + 38 single blocks, "
-                                       "quantize_modulation=true, quantize_flow_embedder_layers=false, hipGraph denoise loop",
-                           "images_per_gpu": 1, "parallelism": f"batch-sharded replicas x{world}", "finite_output": finite,
-                           "depth_override": args.depth},
-                "reference_h100_compiled_its": H100_COMPILED_ITS,
-                "vs_h100_compiled": round(its / world / H100_COMPILED_ITS, 3),
-                "fp8_mfma_fraction_whole_step": round(lin_flops / (ms_per_step * 1e-3) / (FP8_PEAK_TFLOPS * 1e12), 4),
+                "vs_baseline": None,
+                "dtype": ("fp8_e4m3 weights x fp8_e5m2 activations (fp32 accumulate), bf16 flow" if fp8 else "bf16 (nn.Linear weights and flow)"),
+                "data": "synthetic seeded request + random-init Flux weights (no checkpoint available offline)",
+                "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {C['name']}; batch 1 per GPU, Li={Li}+Lt={Lt} tokens, "
+                                       f"{p.depth} double + {p.depth_single_blocks} single blocks, {spr} step(s) per request x {n_req} request(s), "
+                                       "hipGraph denoise loop",
+                           "baseline_config": args.config, "images_per_gpu": 1, "parallelism": f"batch-sharded replicas x{world}",
+                           "nranks": nranks, "backend": backend, "finite_output": finite, "depth_override": args.depth,
+                           "lora_fuse_s": None if lora_s is None else round(lora_s, 2)},
+                "reference_h100_compiled_its": H100_COMPILED.get(args.config),
+                "vs_h100_compiled": round(its / world / H100_COMPILED[args.config], 3) if args.config in H100_COMPILED else None,
+                "fp8_mfma_fraction_whole_step": round(lin_flops / (ms_per_step * 1e-3) / (FP8_PEAK_TFLOPS * 1e12), 4) if fp8 else None,
+                "ms_per_step_hipevent": round(ms_ev.value / n_ev.value, 3) if n_ev.value else None,
                 "setup_s": round(setup_s, 1),
-                "roofline": {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_w1_kernel <fp8 MX-MFMA 32x32x64, 256x256 tiles> (the 152 grouped "
-                                                            "F8Linear GEMM launches of a step, fused epilogues included)",
-                             "achieved": round(achieved, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(achieved / FP8_PEAK_TFLOPS, 4), "traffic": gemm_traffic_bytes(),
-                             "flops_per_launch": flops_per_launch, "avg_launch_us": round(sec_per_launch * 1e6, 2),
-                             "mfma_busy_frac_pmc": gemm_mfma_busy(gemm_table), "launches": gemm_table,
-                             "attention": measure_attention(torch, ops, dev) if (args.height, args.width) == (1024, 1024) else None},
+                "roofline": roof,
             }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(torch)
+                result["cpu_baseline"] = cpu_baseline(args.config)
             except Exception as ex:  # the baseline must never take the measurement down
                 result["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {ex}"}
         else:
@@ -329,16 +453,18 @@ def main():
         td.destroy_process_group()
 
 
-def util_schedule(num_steps, image_seq_len):
+def util_schedule(num_steps, image_seq_len, shift=True):
     """get_schedule + time_shift (reference flux_pipeline.py:314-344), host floats."""
     import math
 
     import torch
 
     ts = torch.linspace(1, 0, num_steps + 1)
-    m = (1.15 - 0.5) / (4096 - 256)
-    mu = m * image_seq_len + (0.5 - m * 256)
-    return (math.exp(mu) / (math.exp(mu) + (1 / ts - 1) ** 1.0)).tolist()
+    if shift:
+        m = (1.15 - 0.5) / (4096 - 256)
+        mu = m * image_seq_len + (0.5 - m * 256)
+        ts = math.exp(mu) / (math.exp(mu) + (1 / ts - 1) ** 1.0)
+    return ts.tolist()
 
 
 if __name__ == "__main__":

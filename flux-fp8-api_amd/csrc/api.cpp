@@ -20,7 +20,7 @@ void fluxmi_set_error(const char* fmt, ...) {
 }
 
 // Tile choice: minimise (#waves of tiles over the 256 CUs) x (per-tile cost).  Relative per-tile
-// efficiencies were measured on MI355X (profiles/r01_gemm_sweep.txt); FLUXMI_GEMM_CFG overrides.
+// efficiencies were measured on MI355X (profiles/r01_kernel_sweep.txt); FLUXMI_GEMM_CFG overrides.
 int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8) {
   static int forced = -2;
   if (forced == -2) {

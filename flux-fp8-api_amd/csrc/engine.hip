@@ -62,6 +62,7 @@ struct fluxmi_engine {
   bool qlut_valid = false;  // the quantising-epilogue tables reflect the current input scales
   hipGraphExec_t exec = nullptr;
   bool graph_ok = false;
+  bool warmed = false;             // one frozen step of this shape has run eagerly (lazy one-time inits done): later calls may capture at once
   bool txt_emb_valid = false;
   int* d_step0 = nullptr;          // first step of the modulation table (device scalar: the captured graph reads it)
   int mods_rows_cap = 0;           // rows (steps x B) the table holds; sized in engine_prepare, never inside denoise
@@ -683,6 +684,7 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
 void free_ws(E* e) {
   if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
   e->graph_ok = false;
+  e->warmed = false;
   e->qlut_valid = false;
   if (e->ws) { hipFree(e->ws); e->ws = nullptr; }
   e->bufs.clear();
@@ -761,6 +763,7 @@ int fluxmi_engine_rebind(fluxmi_engine_t* e, const fluxmi_linear_t* linears, int
   FLUXMI_REQUIRE(e && linears && n_linears == (int)e->lin.size(), "engine_rebind: bad arguments");
   e->lin.assign(linears, linears + n_linears);
   e->graph_ok = false;
+  e->warmed = false;
   e->txt_emb_valid = false;
   e->qlut_valid = false;
   if (e->ws) return build_gemv_table(e, 0);
@@ -959,9 +962,12 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
         FLUXMI_TRY(precompute_mods(e, step, win_end, g_arg, y_s, s));
       }
       if (use_graph && !e->graph_ok) {
-        // the first frozen step runs eagerly so that every lazy one-time init (function attributes) happens outside capture
-        FLUXMI_TRY(one_step(s));
-        ++step;
+        // the first frozen step of a shape runs eagerly so that every lazy one-time init (function attributes) happens outside capture
+        if (!e->warmed) {
+          FLUXMI_TRY(one_step(s));
+          ++step;
+          e->warmed = true;
+        }
         if (step < win_end) {
           hipStream_t cs;
           FLUXMI_CHECK_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));

@@ -17,11 +17,8 @@ Differences by design (MI355X-first):
 """
 from __future__ import annotations
 
-import math
-
 import torch
 import torch.nn as nn
-from torch.nn import init
 
 from fluxmi import ops  # raises ImportError loudly when libfluxmi.so has not been built
 
@@ -49,6 +46,9 @@ class F8Linear(nn.Module):
         input_float8_dtype=torch.float8_e5m2,
     ) -> None:
         super().__init__()
+        if float8_dtype != torch.float8_e4m3fn:
+            # the reference's default (float8_quantize.py:39); libfluxmi's MX-MFMA kernels fix the weight operand to e4m3fn
+            raise ValueError(f"fluxmi F8Linear: weights must be torch.float8_e4m3fn, got {float8_dtype}")
         self.in_features = in_features
         self.out_features = out_features
         self.float8_dtype = float8_dtype
@@ -163,20 +163,19 @@ class F8Linear(nn.Module):
         return out if self.weight.dtype == torch.bfloat16 else out.to(self.weight.dtype)
 
     def reset_parameters(self) -> None:
-        if self.weight_initialized:
-            self.weight = nn.Parameter(
-                torch.empty((self.out_features, self.in_features), dtype=self.weight.dtype, device=self.weight.device),
-                requires_grad=False,
-            )
-            self.weight_initialized = False
-            self.input_scale_initialized = False
-            self.trial_index = 0
-            self.input_amax_trials.zero_()
-        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        """Re-draw the weight and quantise it again (same role as the reference's float8_quantize.py:248-271).  Not on the hot
+        path: nn.Linear's default init is taken from a throw-away nn.Linear on the weight's device, then the calibration state
+        starts over because the old input scales belong to the old weight."""
+        w = self.weight
+        dev, dt = (w.device, w.dtype)
+        fresh = nn.Linear(self.in_features, self.out_features, bias=self.bias is not None, device=dev, dtype=torch.float32)
+        self.weight = nn.Parameter(fresh.weight.detach().to(dt), requires_grad=False)
         if self.bias is not None:
-            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
-            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
-            init.uniform_(self.bias, -bound, bound)
+            self.bias = nn.Parameter(fresh.bias.detach().to(self.bias.dtype), requires_grad=False)
+        self.weight_initialized = False
+        self.input_scale_initialized = False
+        self.trial_index = 0
+        self.input_amax_trials.zero_()
         self.quantize_weight()
 
     # ---- prequantised checkpoints (state-dict format of reference float8_quantize.py:91-193) -----

@@ -220,9 +220,21 @@ class FluxPipeline:
         p = self.model.params
         lt = self.config.text_enc_max_length
         if prompt is None:
-            g = torch.Generator().manual_seed(10)
-            prompt = {"txt": 0.1 * torch.randn(1, lt, p.context_in_dim, generator=g), "vec": torch.randn(1, p.vec_in_dim, generator=g)}
-        kw = dict(prompt=prompt, height=768, width=768, num_steps=12, guidance=3.5, seed=10, silent=True, output_type="latent")
+            if self.t5 is not None and self.clip is not None:
+                # the reference's own warm-up prompt (flux_pipeline.py:199): the frozen input scales then reflect real text activations
+                prompt = "A beautiful test image used to solidify the fp8 nn.Linear input scales prior to compilation 😉"
+            else:
+                # no encoders attached (offline runs): synthetic embeddings of T5 / CLIP-like statistics.  The scales are then tuned on
+                # noise-like conditioning -- callers with real embeddings should pass them as `prompt`
+                g = torch.Generator().manual_seed(10)
+                prompt = {"txt": 0.1 * torch.randn(1, lt, p.context_in_dim, generator=g), "vec": torch.randn(1, p.vec_in_dim, generator=g)}
+        # batch-sharded replicas: every layer's running amax is MAX-reduced across the ranks inside each calibrating step, so all
+        # replicas freeze the SAME input scales (float8_quantize.py:227 takes amax over the whole batch)
+        world = fdist.world_size()
+        if world > 1:
+            self.model.enable_amax_exchange()
+        kw = dict(prompt=prompt, height=768, width=768, num_steps=12, guidance=3.5, seed=10, silent=True, output_type="latent",
+                  num_images=max(1, world))
         if self.name == ModelVersion.flux_schnell.value or self.name == "flux-schnell":
             kw["num_steps"] = 4
             for _ in range(3):
@@ -230,6 +242,8 @@ class FluxPipeline:
         else:
             self.generate(**kw)
             self.generate(**{**kw, "num_steps": 1})  # 13th call: freezes the input scales
+        if world > 1:
+            self.model.enable_amax_exchange(False)
 
     # ---- the request (reference flux_pipeline.py:526-663) ---------------------------------------------------------------
     @torch.inference_mode()
@@ -251,7 +265,16 @@ class FluxPipeline:
             txt, vec, img = fdist.broadcast_request(txt, vec, img, src=0)
             lo, hi = fdist.shard_bounds(img.shape[0], rank, world)
             img, img_ids, vec, txt, txt_ids = (t[lo:hi].contiguous() for t in (img, img_ids, vec, txt, txt_ids))
-        latents = self.model.denoise(img, img_ids, txt, txt_ids, vec, timesteps, guidance=guidance, use_graph=use_graph)
+        if img.shape[0] == 0:
+            # more ranks than images: this rank has nothing to denoise but still takes part in the gather below (an exception or an
+            # early return here would leave the other ranks blocked in the collective).  A calibrating model must not run like this:
+            # its per-layer amax exchange is a collective too.
+            cal = getattr(self.model, "calibration_state", None)
+            if cal is not None and cal()[0] is False and getattr(self.model, "_amax_xchg", None) is not None:
+                raise RuntimeError("fluxmi: calibrating with fewer images than ranks (use num_images >= world_size for the warm-up)")
+            latents = img.new_empty((0,) + tuple(img.shape[1:]))
+        else:
+            latents = self.model.denoise(img, img_ids, txt, txt_ids, vec, timesteps, guidance=guidance, use_graph=use_graph)
         if world > 1:
             latents = fdist.gather_latents(latents, num_images, dst=0)
             if latents is None:  # only the gather rank decodes / returns the images

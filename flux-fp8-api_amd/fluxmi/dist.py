@@ -79,8 +79,9 @@ def allreduce_amax(amax: torch.Tensor) -> torch.Tensor:
     return amax
 
 
-def sync_calibration(f8_modules) -> int:
-    """Make the frozen F8Linear input scales identical on every replica: MAX all-reduce of every layer's 12 running-amax trials
+def sync_calibration(f8_modules, model=None) -> int:
+    """(Fallback; the exact scheme is Flux.enable_amax_exchange, which reduces every layer's amax INSIDE each calibrating step so
+    that later layers also see identically scaled inputs.)  Make the frozen F8Linear input scales identical on every replica: MAX all-reduce of every layer's 12 running-amax trials
     (one [n_layers, n_trials] tensor, ~15 KB), then input_scale = amax_to_scale(max(trials)) exactly as the reference computes it
     (float8_quantize.py:214-215,237-246: python_float / tensor, clamped at the format maximum).  The reference takes amax over the
     whole batch (float8_quantize.py:227); with one sample per GPU this is what makes a batch of N on N GPUs calibrate like a batch of
@@ -96,6 +97,10 @@ def sync_calibration(f8_modules) -> int:
         scale = (max_val / torch.clamp(t.max(), min=1e-12)).clamp(max=max_val)
         m.input_scale.copy_(scale)
         m.input_scale_reciprocal.copy_(scale.reciprocal())
+    # the engine caches state derived from the scales (64 KiB quantising-epilogue tables, the captured hipGraph that reads them):
+    # pass `model` (a modules.flux_model.Flux) to have it rebuilt; callers that do not MUST call model.rebind_weights() themselves
+    if model is not None and hasattr(model, "rebind_weights"):
+        model.rebind_weights()
     return len(mods)
 
 

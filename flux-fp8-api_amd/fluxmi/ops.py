@@ -92,6 +92,8 @@ def lora_fuse_f8(w8: torch.Tensor, w_scale: torch.Tensor, w_scale_recip: torch.T
     R = lora_B.shape[1]
     work = torch.empty(2 * N * K, dtype=torch.float32, device=w8.device)
     tmp = torch.zeros(1, dtype=torch.float32, device=w8.device)
+    if w8.dtype != torch.float8_e4m3fn:
+        raise TypeError(f"fluxmi: LoRA fuse needs float8_e4m3fn weights (the GEMM kernels fix the weight operand format), got {w8.dtype}")
     call("fluxmi_lora_fuse_f8", _p(w8), _p(w_scale), _p(w_scale_recip), _p(lora_B.float().contiguous()),
          _p(lora_A.float().contiguous()), N, K, R, n_chunks, float(lora_scale), _p(work), _p(tmp), _stream())
 

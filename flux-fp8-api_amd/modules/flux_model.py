@@ -187,8 +187,10 @@ class Flux(nn.Module):
         self.requires_grad_(False)
         self._engine = None
         self._engine_keep = None
+        self._engine_device = None
         self._lock = threading.Lock()  # the C handle is not re-entrant (the reference's api.py calls from a threadpool)
         self._prep_key = None
+        self._amax_xchg = None  # (device array, ctypes callback) of the batch-sharded calibration exchange, see enable_amax_exchange
 
     # ---- engine plumbing ---------------------------------------------------------------------------------
     def linear_modules(self) -> List[nn.Module]:
@@ -214,7 +216,7 @@ class Flux(nn.Module):
         with self._lock:
             if self._engine is not None:
                 _lib.call("fluxmi_engine_destroy", self._engine)
-            self._engine, self._engine_keep, self._prep_key = None, None, None
+            self._engine, self._engine_keep, self._prep_key, self._engine_device = None, None, None, None
 
     def __del__(self):
         try:
@@ -291,13 +293,15 @@ class Flux(nn.Module):
         fr = ops.timestep_freqs_host(128)
         _lib.call("fluxmi_engine_set_tables", h, fr.numpy().ctypes.data_as(C.POINTER(C.c_float)),
                   om.numpy().ctypes.data_as(C.POINTER(C.c_float)), ax.numpy().ctypes.data_as(C.POINTER(C.c_int)))
-        self._engine, self._engine_keep, self._prep_key = h, (keep_l, keep_n, lin, nrm), None
+        self._engine, self._engine_keep, self._prep_key, self._engine_device = h, (keep_l, keep_n, lin, nrm), None, device
+        if self._amax_xchg is not None:
+            self._install_amax_exchange()
 
     def rebind_weights(self):
         """Call after weight surgery (LoRA fuse, set_weight_tensor) so the engine sees the new pointers."""
         if self._engine is None:
             return
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = self._engine_device  # the device the engine was created on (not necessarily torch's current device)
         lin, keep_l = self._linear_table(dev)
         with self._lock:
             _lib.call("fluxmi_engine_rebind", self._engine, lin, len(lin))
@@ -310,6 +314,44 @@ class Flux(nn.Module):
         ii = img_ids.to(torch.bfloat16).contiguous()
         ti = txt_ids.to(torch.bfloat16).contiguous()
         _lib.call("fluxmi_engine_prepare", self._engine, B, Li, Lt, ops._p(ii), ops._p(ti), ops._stream())
+
+    # ---- batch-sharded calibration ------------------------------------------------------------------
+    def enable_amax_exchange(self, reduce_fn=None):
+        """Keep the F8Linear input scales of batch-sharded replicas IDENTICAL to those of the whole batch on one GPU: the reference
+        takes amax over the whole batch (float8_quantize.py:227), so during the calibrating steps every layer's running amax is
+        MAX-reduced across the ranks before its scale update (fluxmi_engine_set_amax_exchange).  `reduce_fn(tensor)` performs the
+        in-place reduction of a small fp32 device tensor on the current stream; default: torch.distributed all_reduce(MAX) over
+        RCCL.  Pass reduce_fn=False to uninstall."""
+        if reduce_fn is False:
+            self._amax_xchg = None
+            if self._engine is not None:
+                with self._lock:
+                    _lib.call("fluxmi_engine_set_amax_exchange", self._engine, None, 0, None, None)
+            return
+        if reduce_fn is None:
+            import torch.distributed as td
+
+            reduce_fn = lambda t: td.all_reduce(t, op=td.ReduceOp.MAX)
+        self._amax_xchg = {"fn": reduce_fn, "buf": None, "cb": None, "error": None}
+        if self._engine is not None:
+            with self._lock:
+                self._install_amax_exchange()
+
+    def _install_amax_exchange(self):
+        x = self._amax_xchg
+        n = len(self.linear_modules())
+        x["buf"] = torch.zeros(n, dtype=torch.float32, device=self._engine_device)
+
+        def hook(user, first, count, stream):
+            try:  # called by the engine between the amax reduction of layers [first, first+count) and their scale update
+                x["fn"](x["buf"][first:first + count])
+                return 0
+            except Exception as e:  # an exception must not cross the C ABI
+                x["error"] = e
+                return 1
+
+        x["cb"] = _lib.AMAX_HOOK(hook)
+        _lib.call("fluxmi_engine_set_amax_exchange", self._engine, ops._p(x["buf"]), n, x["cb"], None)
 
     # ---- calibration bookkeeping (mirrors F8Linear.trial_index / input_scale_initialized) -----------------
     def calibration_state(self):
@@ -412,6 +454,14 @@ class Flux(nn.Module):
         """The Euler loop of FluxPipeline.generate (reference flux_pipeline.py:619-651) run natively: calibrating
         steps unfused, every later step one replay of a captured hipGraph.  Returns the final latent tokens."""
         bf = lambda t: t.to(torch.bfloat16).contiguous()
+        if img.shape[0] > 8:
+            # the engine takes at most 8 samples per pass (modulation GEMV staging); the reference has no num_images limit, so
+            # larger batches run as consecutive passes (samples never interact).  Only frozen models: a calibrating pass per chunk
+            # would advance the F8Linear trial counters once per chunk instead of once per step.
+            if self.calibration_state()[0] is False:
+                raise ValueError("fluxmi: batches larger than 8 need frozen F8Linear input scales (run the calibration warm-up first)")
+            return torch.cat([self.denoise(img[i:i + 8], img_ids[i:i + 8], txt[i:i + 8], txt_ids[i:i + 8], y[i:i + 8], timesteps,
+                                           guidance=guidance, use_graph=use_graph) for i in range(0, img.shape[0], 8)], 0)
         img = bf(img).clone()
         txt, y = bf(txt), bf(y)
         self._ensure_engine(img.device)

@@ -203,6 +203,8 @@ def load_autoencoder(config: ModelSpec, state_dict=None):
         path = getattr(config, "ae_path", None)
         if not path or not os.path.exists(path):
             return None
+        from safetensors.torch import load_file as load_sft
+
         state_dict = load_sft(path, device="cpu")
     ae = AutoEncoder(config.ae_params)
     missing, unexpected = ae.load_state_dict(state_dict, strict=False)

@@ -266,6 +266,32 @@ def test_optional_models_absent_offline():
     assert util.load_autoencoder(cfg) is None
 
 
+def test_autoencoder_loads_from_ae_path(tmp_path):
+    """config.ae_path pointing at a real BFL-layout `ae.sft` (reference util.py:283-296): the file is read and loaded -- the round-1
+    loader hit a NameError here (advisor finding), which no test reached because every test injected the state dict."""
+    import torch
+    from safetensors.torch import save_file
+
+    import util
+    from modules.autoencoder import AutoEncoder
+
+    cfg = util.load_config(util.ModelVersion.flux_dev, flow_dtype="bfloat16")
+    cfg.ae_params.resolution, cfg.ae_params.ch, cfg.ae_params.ch_mult, cfg.ae_params.num_res_blocks = 32, 32, [1, 2], 1
+    cfg.ae_device = "cpu"
+    torch.manual_seed(0)
+    ref = AutoEncoder(cfg.ae_params)
+    path = str(tmp_path / "ae.sft")
+    save_file({k: v.contiguous() for k, v in ref.state_dict().items()}, path)
+    cfg.ae_path = path
+    ae = util.load_autoencoder(cfg)
+    assert ae is not None and ae.encoder_loaded
+    for k, v in ref.state_dict().items():
+        assert torch.equal(ae.state_dict()[k].float(), v.to(torch.bfloat16).float()), k
+    # decoder-only checkpoints are accepted, encoder then refuses to run
+    save_file({k: v.contiguous() for k, v in ref.state_dict().items() if k.startswith("decoder.")}, path)
+    assert util.load_autoencoder(cfg).encoder_loaded is False
+
+
 def test_native_text_modules_keep_hf_state_dict_keys():
     """T5EncoderNative / ClipTextNative expose transformers' parameter names (so HF checkpoints load as they are), accept the tied
     T5 embedding and both CLIP key layouts, and refuse to run without a GPU."""

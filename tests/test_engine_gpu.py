@@ -248,6 +248,71 @@ def test_lora_fuse_end_to_end(dev):
         assert_f8_close(model.get_submodule(name).float8_data, oracle.lin[name].float8_data, max_ulp=1, min_exact=0.99, what="unfuse " + name)
 
 
+def test_batch_sharded_calibration_matches_whole_batch(dev):
+    """SURVEY.md 8e-3 / float8_quantize.py:227: the reference takes amax over the WHOLE batch, so a batch of 2 sharded over two replicas
+    must calibrate exactly like a batch of 2 on one GPU.  Two engines (one sample each) run the 13 calibrating + 3 frozen steps
+    concurrently from two host threads with the per-layer amax exchange installed (Flux.enable_amax_exchange; here the reduction is a
+    rendezvous between the two threads, over RCCL it is all_reduce(MAX)) -> every input scale and the latents are BIT-identical to
+    the single-engine batch-2 run.  Without the exchange the scales differ (checked)."""
+    import threading
+
+    from fluxmi import synth
+
+    cfg = tiny_config()
+    B, H, W, Lt = 2, 64, 64, 32
+    inp = to_dev(synth.make_inputs(cfg.params, H, W, Lt, batch=B, seed=31, real_tokens=8), dev)
+    inp["img"][1] *= 1.7  # make the two samples' activation ranges differ
+    inp["txt"][1] *= 2.5
+    ts = fo.get_schedule(16, (H // 16) * (W // 16))
+    whole, _, _ = build(cfg, QUANTS["fp8"], dev)
+    ref = whole.denoise(inp["img"], inp["img_ids"], inp["txt"], inp["txt_ids"], inp["y"], ts, guidance=3.5)
+    assert whole.calibration_state()[0]
+    names = [n for n, m in whole.named_modules() if m in set(whole.f8_modules())]
+
+    def run_pair(exchange):
+        reps = [build(cfg, QUANTS["fp8"], dev)[0] for _ in range(2)]
+        bar = threading.Barrier(2)
+        slot = [None, None]
+        outs, errs = [None, None], []
+
+        def make_reduce(r):
+            def reduce_fn(t):
+                slot[r] = t
+                bar.wait(timeout=120)
+                m = torch.maximum(slot[0], slot[1])
+                bar.wait(timeout=120)
+                t.copy_(m)
+            return reduce_fn
+
+        def work(r):
+            try:
+                if exchange:
+                    reps[r].enable_amax_exchange(make_reduce(r))
+                sl = slice(r, r + 1)
+                outs[r] = reps[r].denoise(inp["img"][sl], inp["img_ids"][sl], inp["txt"][sl], inp["txt_ids"][sl], inp["y"][sl], ts, guidance=3.5)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa
+                errs.append(e)
+                bar.abort()
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        [t.start() for t in th]
+        [t.join(timeout=600) for t in th]
+        assert not errs, errs
+        return reps, torch.cat(outs, 0)
+
+    reps, lat = run_pair(True)
+    for n in names:
+        s_ref = whole.get_submodule(n).input_scale.item()
+        for r in range(2):
+            assert reps[r].get_submodule(n).input_scale.item() == s_ref, f"{n}: replica {r} scale differs from the whole-batch run"
+    assert torch.equal(lat, ref), f"sharded latents differ from the whole-batch run: rel-L2 {rel_l2(lat, ref):.3e}"
+    reps2, _ = run_pair(False)
+    differ = sum(reps2[0].get_submodule(n).input_scale.item() != reps2[1].get_submodule(n).input_scale.item() for n in names)
+    print(f"without the exchange {differ}/{len(names)} input scales differ between the replicas; with it 0 (and == the batch-2 run)")
+    assert differ > 0
+
+
 def test_pipeline_generate_latents(dev):
     """Pipeline surface: load from a ModelSpec, calibrate via compile(), generate from embeddings (drop-in call shape)."""
     from flux_pipeline import FluxPipeline
