@@ -149,26 +149,45 @@ struct LnModArgs {
   const float* q_scale[2];
   int B, L, split, H;
 };
+// One wave per row, four rows per workgroup.  Round 1 kept x, scale and shift of the row in registers (72 packed + ~40 unpacked =
+// 124 VGPRs -> 4 waves per SIMD -> the 4608 rows of a 1024x1024 step need 1.125 rounds of the chip, i.e. the kernel took two wave
+// lifetimes: 18 us for 42 MB).  Now the workgroup stages bf16(1 + scale) and shift of its stream in LDS once (12 KiB at H = 3072;
+// a quarter of the L2 traffic) and the wave holds only its packed row: <= 80 VGPRs -> 6 waves per SIMD -> every row is resident at
+// once (single round), and the modulation vectors cost ds_read_b128 instead of global loads.
 template <int NCH, bool OUT_FP8, int FMT>
-__global__ void __launch_bounds__(256) ln_modulate_kernel(const LnModArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.B * a.L) return;
-  const int b = row / a.L, l = row % a.L, st = (l < a.split) ? 0 : 1;
+__global__ void __launch_bounds__(256, 5) ln_modulate_kernel(const LnModArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lnm_smem[];  // [m1 = bf16(1+scale) | shift], H bf16 each
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 4;
+  const int rows = a.B * a.L;
+  const int row = row0 + wave;
+  const int rowc = min(row, rows - 1);
+  const int b = rowc / a.L, l = rowc % a.L, st = (l < a.split) ? 0 : 1;
+  // the workgroup's table belongs to the (batch, stream) of its first row; a wave of another (batch, stream) -- only when the
+  // split or L is not a multiple of 4 -- reads its vectors from global memory instead
+  const int b0 = row0 / a.L, st0 = ((row0 % a.L) < a.split) ? 0 : 1;
+  const bool from_lds = (b == b0) && (st == st0);
+  u16* m1_lds = (u16*)lnm_smem;
+  u16* sh_lds = m1_lds + a.H;
+  {
+    const u16* sc0 = a.scale[st0] + (long long)b0 * a.mod_bstride;
+    const u16* sh0 = a.shift[st0] + (long long)b0 * a.mod_bstride;
+    for (int c = threadIdx.x * 8; c < a.H; c += 256 * 8) {
+      float fs[8], m1[8];
+      unpack8(*(const uint4*)(sc0 + c), fs);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m1[j] = 1.0f + fs[j];
+      *(uint4*)(m1_lds + c) = pack8(m1);                       // bf16(1 + scale): the reference materialises it (flux_model.py:367)
+      *(uint4*)(sh_lds + c) = *(const uint4*)(sh0 + c);
+    }
+  }
   const u16* xr = a.x + (long long)b * a.x_bstride + (long long)l * a.ldx;
   const long long orow = (long long)b * a.out_bstride + (long long)l * a.ldo;
-  // everything the row needs is requested up front (x, scale, shift: 3 x NCH independent 16 B loads per lane) and kept packed, so
-  // one memory latency covers all of it; a wave per row means the kernel is latency-, not bandwidth-shaped (18 waves per CU).
-  const u16* sh = a.shift[st] + (long long)b * a.mod_bstride;
-  const u16* sc = a.scale[st] + (long long)b * a.mod_bstride;
-  uint4 xr4[NCH], sc4[NCH], sh4[NCH];
+  uint4 xr4[NCH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int c = (lane + 64 * k) * 8;
-    const bool ok = c < a.H;
-    xr4[k] = ok ? *(const uint4*)(xr + c) : make_uint4(0, 0, 0, 0);
-    sc4[k] = ok ? *(const uint4*)(sc + c) : make_uint4(0, 0, 0, 0);
-    sh4[k] = ok ? *(const uint4*)(sh + c) : make_uint4(0, 0, 0, 0);
+    xr4[k] = (c < a.H) ? *(const uint4*)(xr + c) : make_uint4(0, 0, 0, 0);
   }
   float qs = 1.f;
   if (OUT_FP8) qs = *a.q_scale[st];
@@ -194,19 +213,30 @@ __global__ void __launch_bounds__(256) ln_modulate_kernel(const LnModArgs a) {
   }
   const float var = wave_sum(sq) / (float)a.H;
   const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  __syncthreads();  // the table is complete (every wave reaches this: no early exit above)
+  if (row >= rows) return;
+  const u16* scg = a.scale[st] + (long long)b * a.mod_bstride;
+  const u16* shg = a.shift[st] + (long long)b * a.mod_bstride;
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int c = (lane + 64 * k) * 8;
     if (c < a.H) {
-      float v[8], fs[8], fh[8], y[8];
+      float v[8], m1[8], fh[8], y[8];
       unpack8(xr4[k], v);
-      unpack8(sc4[k], fs);
-      unpack8(sh4[k], fh);
+      if (from_lds) {
+        unpack8(*(const uint4*)(m1_lds + c), m1);
+        unpack8(*(const uint4*)(sh_lds + c), fh);
+      } else {
+        float fs[8];
+        unpack8(*(const uint4*)(scg + c), fs);
+        unpack8(*(const uint4*)(shg + c), fh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m1[j] = rbf(1.0f + fs[j]);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float n = rbf((v[j] - mean) * rstd);
-        const float m1 = rbf(1.0f + fs[j]);
-        y[j] = rbf(rbf(m1 * n) + fh[j]);
+        y[j] = rbf(rbf(m1[j] * n) + fh[j]);
       }
       if (OUT_FP8) {
         uint2 o;
@@ -491,11 +521,12 @@ int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void
   a.B = B; a.L = L; a.split = split; a.H = H;
   const dim3 grid((B * L + 3) / 4), block(256);
   const int nch = (H + 511) / 512;
+  const size_t lds = (size_t)H * 4;  // bf16(1 + scale) and shift of the workgroup's stream
 #define LNM(N_)                                                                                                       \
   do {                                                                                                                \
-    if (!out_fp8) hipLaunchKernelGGL((ln_modulate_kernel<N_, false, FLUXMI_FMT_E5M2>), grid, block, 0, s, a);           \
-    else if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((ln_modulate_kernel<N_, true, FLUXMI_FMT_E5M2>), grid, block, 0, s, a); \
-    else hipLaunchKernelGGL((ln_modulate_kernel<N_, true, FLUXMI_FMT_E4M3>), grid, block, 0, s, a);                     \
+    if (!out_fp8) hipLaunchKernelGGL((ln_modulate_kernel<N_, false, FLUXMI_FMT_E5M2>), grid, block, lds, s, a);           \
+    else if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((ln_modulate_kernel<N_, true, FLUXMI_FMT_E5M2>), grid, block, lds, s, a); \
+    else hipLaunchKernelGGL((ln_modulate_kernel<N_, true, FLUXMI_FMT_E4M3>), grid, block, lds, s, a);                     \
   } while (0)
   if (nch <= 1) LNM(1);
   else if (nch <= 2) LNM(2);

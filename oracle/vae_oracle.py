@@ -82,3 +82,37 @@ def encode(sd, params, x, noise=None, autocast=True):
     mean, logvar = torch.chunk(encode_moments(sd, params, x, autocast), 2, dim=1)
     z = mean if noise is None else mean + torch.exp(0.5 * logvar.float()) * noise.to(mean.dtype)
     return params["scale_factor"] * (z - params["shift_factor"])
+
+
+# ---- real-size fixture (oracle/gen_golden_vae_full.py, tests/test_engine_gpu.py::test_vae_full_size_matches_reference_fixture) ----------
+FULL_PARAMS = dict(resolution=256, in_channels=3, ch=128, out_ch=3, ch_mult=[1, 2, 4, 4], num_res_blocks=2, z_channels=16,
+                   scale_factor=0.3611, shift_factor=0.1159)  # reference util.py:99-110
+
+
+def synth_state_dict(shapes, seed=7):
+    """Deterministic weights for a VAE with the given {key: shape} (BFL `ae.sft` layout), bf16-representable (ae_dtype = bfloat16):
+    convolutions ~ N(0, 1/fan_in), norm weights 1 + 0.1 N(0,1), biases 0.05 N(0,1).  Filled in sorted key order from ONE seeded CPU
+    generator, so the reference module and the native module get identical tensors."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        if "norm" in k and k.endswith(".weight"):
+            t = 1 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            t = 0.05 * torch.randn(shp, generator=g)
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = torch.randn(shp, generator=g) / max(fan_in, 1) ** 0.5
+        sd[k] = t.to(torch.bfloat16).float()
+    return sd
+
+
+def full_inputs(seed=11):
+    """(latent z [1,16,32,32] fp32, image x [1,3,256,256] in [-1,1], bf16-representable as the pipeline hands it over)"""
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(1, 16, 32, 32, generator=g)
+    x = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    return z, x

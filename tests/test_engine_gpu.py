@@ -397,6 +397,37 @@ def test_vae_encoder_matches_reference_fixture(dev):
         ae.encode(x)
 
 
+def test_vae_full_size_matches_reference_fixture(dev):
+    """The REAL FLUX autoencoder geometry (ch 128, ch_mult [1,2,4,4], 2 res blocks, z 16; reference util.py:99-110) on a 256x256
+    image: native decode / encode_moments vs the unmodified reference's fp32 outputs stored in tests/golden/g11_vae_full.safetensors
+    (oracle/gen_golden_vae_full.py; weights rebuilt from the same seed on both sides).  Gate as at the small geometry: the native bf16
+    path must be as close to the fp32 reference as the reference's own torch.autocast(bf16) run is (x1.5)."""
+    import os
+    import sys
+
+    from safetensors.torch import load_file
+
+    import vae_oracle as vo
+    from modules.autoencoder import AutoEncoder, AutoEncoderParams
+
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_vae_full.safetensors"))
+    ae = AutoEncoder(AutoEncoderParams(**vo.FULL_PARAMS))
+    sd = vo.synth_state_dict({k: v.shape for k, v in ae.state_dict().items()}, seed=7)
+    ae.load_state_dict(sd, strict=True)
+    ae.to(dev)
+    z, x = vo.full_inputs()
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    out = ae.decode(z.to(dev)).float().cpu()
+    assert out.shape == g["dec_ref_fp32"].shape and torch.isfinite(out).all()
+    e_nat, e_ref = rel(out, g["dec_ref_fp32"]), rel(g["dec_ref_autocast"], g["dec_ref_fp32"])
+    mom = ae.encode_moments(x.to(dev)).float().cpu()
+    assert mom.shape == g["enc_moments_fp32"].shape and torch.isfinite(mom).all()
+    m_nat, m_ref = rel(mom, g["enc_moments_fp32"]), rel(g["enc_moments_autocast"], g["enc_moments_fp32"])
+    print(f"full-size VAE: decode native vs fp32 reference {e_nat:.3e} (reference autocast {e_ref:.3e}); encode moments {m_nat:.3e} "
+          f"(reference autocast {m_ref:.3e})")
+    assert e_nat <= 1.5 * e_ref and m_nat <= 1.5 * m_ref
+
+
 def test_pipeline_img2img_through_vae_encoder(dev):
     """generate(init_image=..., strength=...) on the drop-in surface (reference flux_pipeline.py:459-523, 583-603): the init image is
     resized / centre-cropped, VAE-encoded natively, blended with the noise at t = timesteps[int((1 - strength) * num_steps)] and the

@@ -287,11 +287,14 @@ def test_gemv(ops, dev, B):
 
 
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,Lt", [(40, 12), (42, 13)])
 @pytest.mark.parametrize("H", [256, 3072])
-def test_ln_modulate(ops, dev, H):
-    """K4(+K2): (1+scale)*LayerNorm(x)+shift with the reference's bf16 rounding points (flux_model.py:367-368)."""
+def test_ln_modulate(ops, dev, H, L, Lt):
+    """K4(+K2): (1+scale)*LayerNorm(x)+shift with the reference's bf16 rounding points (flux_model.py:367-368).
+    (42, 13): a workgroup's four rows straddle the txt|img split and the batch boundary (the rows that do not belong to the
+    workgroup's LDS-staged stream take their modulation vectors from global memory)."""
     torch.manual_seed(9)
-    B, L, Lt = 2, 40, 12
+    B = 2
     x = (torch.randn(B, L, H) * 2 + 0.3).bfloat16()
     mods = (torch.randn(B, 4 * H) * 0.5).bfloat16()  # txt shift|scale, img shift|scale, row stride 4H
     sh0, sc0, sh1, sc1 = mods[:, :H], mods[:, H:2 * H], mods[:, 2 * H:3 * H], mods[:, 3 * H:]
