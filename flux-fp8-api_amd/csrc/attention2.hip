@@ -213,6 +213,39 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       cur[t][r] = p;
       l4[e & 3] = ls;
     };
+    // VAR & 4: the same work skewed by one gap -- gap g runs fma(score g+1), exp2(score g) and the row-sum add / bf16 pack of score
+    // g-1 -- so that nothing inside a gap depends on anything else inside it: no trans-op wait states, no fma -> exp -> add -> cvt
+    // latency chain in front of the next MFMA (round-2 A/B: profiles/r02_attention_ab.txt)
+    auto soft2 = [&](auto GC) {
+      constexpr int g = decltype(GC)::value, ea = g + 1, eb = g, ec = g - 1;
+      float xa = 0.f, xb = cur[eb >> 4][eb & 15], xc = 0.f, ls = 0.f;
+      if constexpr (ea <= 31) xa = cur[ea >> 4][ea & 15];
+      if constexpr (ec >= 0) { xc = cur[ec >> 4][ec & 15]; ls = l4[ec & 3]; }
+      if constexpr (ea <= 31 && ec >= 0) asm volatile("" : "+v"(xa), "+v"(xb), "+v"(xc));
+      else if constexpr (ea <= 31) asm volatile("" : "+v"(xa), "+v"(xb));
+      else asm volatile("" : "+v"(xb), "+v"(xc));
+      if constexpr (ea <= 31) xa = __builtin_fmaf(xa, c, nmc);
+      xb = __builtin_amdgcn_exp2f(xb);
+      if constexpr (ec >= 0) {
+        ls += xc;
+        if constexpr (ec & 1) {
+          constexpr int tc = ec >> 4, rc = ec & 15, f = tc * 2 + (rc >> 3), q = (rc & 7) >> 1;
+          int w;
+          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[tc][rc - 1]), "v"(xc));
+          pc[f][q] = w;
+        }
+      }
+      if constexpr (ea <= 31 && ec >= 0) asm volatile("" : "+v"(xa), "+v"(xb), "+v"(ls));
+      else if constexpr (ea <= 31) asm volatile("" : "+v"(xa), "+v"(xb));
+      else asm volatile("" : "+v"(xb), "+v"(ls));
+      if constexpr (ea <= 31) cur[ea >> 4][ea & 15] = xa;
+      cur[eb >> 4][eb & 15] = xb;
+      if constexpr (ec >= 0) l4[ec & 3] = ls;
+    };
+    auto gapwork = [&](auto GC) {
+      if constexpr (VAR & 4) soft2(GC); else soft(GC);
+    };
+    if constexpr (VAR & 4) cur[0][0] = __builtin_fmaf(cur[0][0], c, nmc);  // stage A of score 0 (the other 31 ride in the gaps)
     // -- B: S_{j+1} = K_{j+1} Q^T, two alternating accumulators; K fragments two chunks ahead; one score of P_j per gap
     {
 #pragma unroll
@@ -228,7 +261,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[cc % 3][t], qf[cc], nxt[t], 0, 0, 0);
         fence();
         if constexpr (cc + 2 < 8) kf[(cc + 2) % 3][t] = k_frag(KS, cc + 2, t);
-        soft(std::integral_constant<int, s>{});
+        gapwork(std::integral_constant<int, s>{});
         if constexpr (!(VAR & 1)) {
           if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
           if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
@@ -258,7 +291,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s % 3], __builtin_bit_cast(v8bf, pp[ch4]), o[db], 0, 0, 0);
         fence();
         if constexpr (s + 2 < 16) vf[(s + 2) % 3] = v_frag(VS, (s + 2) >> 2, (s + 2) & 3);
-        soft(std::integral_constant<int, 16 + s>{});
+        gapwork(std::integral_constant<int, 16 + s>{});
         rmax(SC);
         if constexpr (VAR & 1) {
           if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
@@ -271,13 +304,19 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     } else {
       static_for<16>([&](auto SC) {
         constexpr int s = decltype(SC)::value;
-        soft(std::integral_constant<int, 16 + s>{});
+        gapwork(std::integral_constant<int, 16 + s>{});
         rmax(SC);
       });
       if constexpr (VAR & 1) {
         dma_k(PAR, (j + 4) * KT, 0); dma_k(PAR, (j + 4) * KT, 1);
         dma_v(VR, (j + 2) * KT, 0); dma_v(VR, (j + 2) * KT, 1);
       }
+    }
+    if constexpr (VAR & 4) {  // stage C of score 31: row sum + the last bf16 pair
+      l4[3] += cur[1][15];
+      int w;
+      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[1][14]), "v"(cur[1][15]));
+      pc[3][3] = w;
     }
     mx = finish_max(m0);
   };
@@ -333,13 +372,16 @@ template <int VAR> static int launch2(const AttnArgs& a, int fmt, hipStream_t s)
   return 0;
 }
 
-// FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 0 = refills in the PV half, bit 1 = exact (undeferred) running max
+// FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 0 = refills in the PV half, bit 1 = exact (undeferred) running max,
+// bit 2 = softmax work skewed by one gap (no dependent chain inside a gap)
 int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s) {
   const char* e = getenv("FLUXMI_ATTN_VAR");
-  switch (e ? atoi(e) & 3 : 0) {
+  switch (e ? atoi(e) & 7 : 0) {
     case 1: return launch2<1>(a, fmt, s);
     case 2: return launch2<2>(a, fmt, s);
-    case 3: return launch2<3>(a, fmt, s);
+    case 4: return launch2<4>(a, fmt, s);
+    case 5: return launch2<5>(a, fmt, s);
+    case 6: return launch2<6>(a, fmt, s);
     default: return launch2<0>(a, fmt, s);
   }
 }

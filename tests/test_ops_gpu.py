@@ -459,7 +459,8 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     VT = _vt_layout(v, L)
     d = lambda t: t.to(dev)
     outs = {}
-    for name, env in (("deferred", {}), ("exact", {"FLUXMI_ATTN_VAR": "2"}), ("dma_in_pv", {"FLUXMI_ATTN_VAR": "1"}), ("round1", {"FLUXMI_ATTN_V": "1"})):
+    for name, env in (("deferred", {}), ("exact", {"FLUXMI_ATTN_VAR": "2"}), ("dma_in_pv", {"FLUXMI_ATTN_VAR": "1"}), ("gap_skew", {"FLUXMI_ATTN_VAR": "4"}),
+                      ("gap_skew_exact", {"FLUXMI_ATTN_VAR": "6"}), ("round1", {"FLUXMI_ATTN_V": "1"})):
         for kk in ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V"):
             monkeypatch.delenv(kk, raising=False)
         for kk, vv in env.items():
@@ -467,9 +468,10 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
         outs[name] = ops.attention(d(q), d(k), d(VT)).cpu()
         err = (outs[name].double() - ref).abs().max().item()
         assert torch.isfinite(outs[name]).all() and err <= 2e-2 * v.abs().max().item(), f"{name}: max abs err {err:.3e} vs fp64"
-    for name in ("exact", "dma_in_pv", "round1"):
+    for name in ("exact", "dma_in_pv", "gap_skew", "gap_skew_exact", "round1"):
         dd = (outs["deferred"].float() - outs[name].float()).abs().max().item()
         assert dd <= 2e-2 * v.abs().max().item(), f"deferred vs {name}: {dd:.3e}"
+    assert torch.equal(outs["deferred"], outs["dma_in_pv"]) and torch.equal(outs["deferred"], outs["gap_skew"]), "schedule variants must not change bits"
     same = (outs["deferred"] == outs["exact"]).float().mean().item()
     print(f"L={L}: max |err| vs fp64 deferred {(outs['deferred'].double() - ref).abs().max().item():.2e} / exact "
           f"{(outs['exact'].double() - ref).abs().max().item():.2e} / round-1 {(outs['round1'].double() - ref).abs().max().item():.2e}; "

@@ -1,5 +1,5 @@
 """Interleaved A/B of the attention kernels in ONE process (guide rule 24): round-1 kernel (FLUXMI_ATTN_V=1) vs the round-2 pipeline and
-its variants (FLUXMI_ATTN_VAR bit 0 = refills in the PV half, bit 1 = exact running max), Flux-dev shapes, random data.
+its variants (FLUXMI_ATTN_VAR bit 0 = refills in the PV half, bit 1 = exact running max, bit 2 = softmax work skewed by one MFMA gap), Flux-dev shapes, random data.
     python tools/attn_ab.py [--rounds 5] [--iters 20] [--L 4608 2816]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,8 @@ ap.add_argument("--L", type=int, nargs="+", default=[4608, 2816, 8192]); ap.add_
 ap.add_argument("--rounds", type=int, default=5)
 a = ap.parse_args()
 dev = torch.device("cuda:0"); torch.manual_seed(0)
-VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}), ("r2", {}), ("r2 dma-in-pv", {"FLUXMI_ATTN_VAR": "1"}), ("r2 exact-max", {"FLUXMI_ATTN_VAR": "2"})]
+VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}), ("r2", {}), ("r2 gap-skew", {"FLUXMI_ATTN_VAR": "4"}), ("r2 gap-skew+dma-pv", {"FLUXMI_ATTN_VAR": "5"}),
+            ("r2 exact-max", {"FLUXMI_ATTN_VAR": "2"})]
 
 
 def setenv(env):
@@ -44,4 +45,4 @@ for L in a.L:
     fl = 4 * L * L * 128 * H * B
     for n, _ in VARIANTS:
         ts = sorted(res[n]); t = ts[len(ts) // 2]
-        print(f"L={L:5d} {n:14s}: median {fl / t / 1e12:7.1f} TF/s ({t * 1e6:6.1f} us)  best {fl / ts[0] / 1e12:7.1f}  frac of 2.5 PF {fl / t / 2.5e15:.3f}", flush=True)
+        print(f"L={L:5d} {n:20s}: median {fl / t / 1e12:7.1f} TF/s ({t * 1e6:6.1f} us)  best {fl / ts[0] / 1e12:7.1f}  frac of 2.5 PF {fl / t / 2.5e15:.3f}", flush=True)
