@@ -42,7 +42,8 @@ constexpr int VRING2 = RD2 * K_BYTES;
 constexpr float DEFER_LOG2 = 8.0f;  // rescale only when a row max grew by more than 2^8 (in the exp2 domain)
 // VAR bit 1 (A/B + the THR sweep of the tests): exact max tracking, i.e. rescale whenever any row max grows
 
-// VAR bit 0: LDS-DMA refills in the PV half instead of the QK^T half (A/B knob)
+// VAR bit 0: shallow V-fragment prefetch (A/B knob); measured and dropped in round 2 (profiles/r02_attention_ab.txt): refills in the PV
+// half (-0.4 %), softmax work skewed by one gap so that nothing inside a gap depends on anything in it (-4 %: +17 register moves)
 template <int FMT, int VAR>
 __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs a) {
   constexpr int QB = NW2 * 32;
@@ -82,6 +83,14 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f;
   float l4[4] = {0.f, 0.f, 0.f, 0.f};
+  // VAR & 4: the row sum as a fifth "d block" of the PV product -- an all-ones A fragment against the P fragments (4 MFMAs per tile,
+  // no LDS operand) instead of 32 v_add per tile: every row of the 32x32 result tile holds the sum over the tile's 64 keys
+  v16f lacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  v8bf ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
   const float c = a.scale_log2;
 
   unsigned kx[8], vx[4];
@@ -170,8 +179,13 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       const float m_new = fmaxf(m_run, mx);
       if (__any((m_new - m_run) * c > ((VAR & 2) ? 0.0f : DEFER_LOG2))) {
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        if constexpr (!(VAR & 4)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) l4[i] *= alpha;
+          for (int i = 0; i < 4; ++i) l4[i] *= alpha;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -198,54 +212,23 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       float sc = cur[t][r];
       asm volatile("" : "+v"(sc));
       float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c, nmc));
-      float ls = l4[e & 3] + p;
+      float ls = 0.f;
+      if constexpr (!(VAR & 4)) ls = l4[e & 3] + p;
       if constexpr (e & 1) {
         constexpr int f = t * 2 + (r >> 3), q = (r & 7) >> 1;
         // one v_cvt_pk_bf16_f32 for the pair (through pack_bf2 hipcc converts each half separately and ORs them: 4 instructions).
         // The s_nop is the trans-op -> VALU wait state hipcc would pad itself (p comes straight from v_exp_f32).
         int w;
         asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[t][r - 1]), "v"(p));
-        asm volatile("" : "+v"(p), "+v"(ls));
+        if constexpr (VAR & 4) asm volatile("" : "+v"(p)); else asm volatile("" : "+v"(p), "+v"(ls));
         pc[f][q] = w;
       } else {
-        asm volatile("" : "+v"(p), "+v"(ls));
+        if constexpr (VAR & 4) asm volatile("" : "+v"(p)); else asm volatile("" : "+v"(p), "+v"(ls));
       }
       cur[t][r] = p;
-      l4[e & 3] = ls;
+      if constexpr (!(VAR & 4)) l4[e & 3] = ls;
     };
-    // VAR & 4: the same work skewed by one gap -- gap g runs fma(score g+1), exp2(score g) and the row-sum add / bf16 pack of score
-    // g-1 -- so that nothing inside a gap depends on anything else inside it: no trans-op wait states, no fma -> exp -> add -> cvt
-    // latency chain in front of the next MFMA (round-2 A/B: profiles/r02_attention_ab.txt)
-    auto soft2 = [&](auto GC) {
-      constexpr int g = decltype(GC)::value, ea = g + 1, eb = g, ec = g - 1;
-      float xa = 0.f, xb = cur[eb >> 4][eb & 15], xc = 0.f, ls = 0.f;
-      if constexpr (ea <= 31) xa = cur[ea >> 4][ea & 15];
-      if constexpr (ec >= 0) { xc = cur[ec >> 4][ec & 15]; ls = l4[ec & 3]; }
-      if constexpr (ea <= 31 && ec >= 0) asm volatile("" : "+v"(xa), "+v"(xb), "+v"(xc));
-      else if constexpr (ea <= 31) asm volatile("" : "+v"(xa), "+v"(xb));
-      else asm volatile("" : "+v"(xb), "+v"(xc));
-      if constexpr (ea <= 31) xa = __builtin_fmaf(xa, c, nmc);
-      xb = __builtin_amdgcn_exp2f(xb);
-      if constexpr (ec >= 0) {
-        ls += xc;
-        if constexpr (ec & 1) {
-          constexpr int tc = ec >> 4, rc = ec & 15, f = tc * 2 + (rc >> 3), q = (rc & 7) >> 1;
-          int w;
-          asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[tc][rc - 1]), "v"(xc));
-          pc[f][q] = w;
-        }
-      }
-      if constexpr (ea <= 31 && ec >= 0) asm volatile("" : "+v"(xa), "+v"(xb), "+v"(ls));
-      else if constexpr (ea <= 31) asm volatile("" : "+v"(xa), "+v"(xb));
-      else asm volatile("" : "+v"(xb), "+v"(ls));
-      if constexpr (ea <= 31) cur[ea >> 4][ea & 15] = xa;
-      cur[eb >> 4][eb & 15] = xb;
-      if constexpr (ec >= 0) l4[ec & 3] = ls;
-    };
-    auto gapwork = [&](auto GC) {
-      if constexpr (VAR & 4) soft2(GC); else soft(GC);
-    };
-    if constexpr (VAR & 4) cur[0][0] = __builtin_fmaf(cur[0][0], c, nmc);  // stage A of score 0 (the other 31 ride in the gaps)
+    auto gapwork = [&](auto GC) { soft(GC); };
     // -- B: S_{j+1} = K_{j+1} Q^T, two alternating accumulators; K fragments two chunks ahead; one score of P_j per gap
     {
 #pragma unroll
@@ -262,12 +245,11 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         fence();
         if constexpr (cc + 2 < 8) kf[(cc + 2) % 3][t] = k_frag(KS, cc + 2, t);
         gapwork(std::integral_constant<int, s>{});
-        if constexpr (!(VAR & 1)) {
-          if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
-          if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
-          if constexpr (s == 11) dma_v(VR, (j + 2) * KT, 0);
-          if constexpr (s == 15) dma_v(VR, (j + 2) * KT, 1);
-        }
+        // refills ride in the QK^T half (in the PV half: -0.4 %, profiles/r02_attention_ab.txt)
+        if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
+        if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
+        if constexpr (s == 11) dma_v(VR, (j + 2) * KT, 0);
+        if constexpr (s == 15) dma_v(VR, (j + 2) * KT, 1);
         fence();
       });
     }
@@ -282,23 +264,20 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       asm volatile("" : "+v"(m0));
     };
     if constexpr (!FIRST) {
-      v8bf vf[3];
-      vf[0] = v_frag(VS, 0, 0);
-      vf[1] = v_frag(VS, 0, 1);
+      // V fragments VPF MFMAs ahead (PMC of the 2-ahead version: the waves sat a third of their cycles in s_waitcnt / s_barrier)
+      constexpr int VPF = (VAR & 1) ? 2 : 4;
+      v8bf vf[VPF + 1];
+#pragma unroll
+      for (int q = 0; q < VPF; ++q) vf[q] = v_frag(VS, q >> 2, q & 3);
       fence();
       static_for<16>([&](auto SC) {
         constexpr int s = decltype(SC)::value, ch4 = s >> 2, db = s & 3;
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s % 3], __builtin_bit_cast(v8bf, pp[ch4]), o[db], 0, 0, 0);
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s % (VPF + 1)], __builtin_bit_cast(v8bf, pp[ch4]), o[db], 0, 0, 0);
+        if constexpr ((VAR & 4) != 0 && db == 3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(v8bf, pp[ch4]), lacc, 0, 0, 0);
         fence();
-        if constexpr (s + 2 < 16) vf[(s + 2) % 3] = v_frag(VS, (s + 2) >> 2, (s + 2) & 3);
+        if constexpr (s + VPF < 16) vf[(s + VPF) % (VPF + 1)] = v_frag(VS, (s + VPF) >> 2, (s + VPF) & 3);
         gapwork(std::integral_constant<int, 16 + s>{});
         rmax(SC);
-        if constexpr (VAR & 1) {
-          if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
-          if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
-          if constexpr (s == 11) dma_v(VR, (j + 2) * KT, 0);
-          if constexpr (s == 15) dma_v(VR, (j + 2) * KT, 1);
-        }
         fence();
       });
     } else {
@@ -307,16 +286,6 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         gapwork(std::integral_constant<int, 16 + s>{});
         rmax(SC);
       });
-      if constexpr (VAR & 1) {
-        dma_k(PAR, (j + 4) * KT, 0); dma_k(PAR, (j + 4) * KT, 1);
-        dma_v(VR, (j + 2) * KT, 0); dma_v(VR, (j + 2) * KT, 1);
-      }
-    }
-    if constexpr (VAR & 4) {  // stage C of score 31: row sum + the last bf16 pair
-      l4[3] += cur[1][15];
-      int w;
-      asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[1][14]), "v"(cur[1][15]));
-      pc[3][3] = w;
     }
     mx = finish_max(m0);
   };
@@ -348,10 +317,14 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       const v8bf vfr = *(const v8bf*)(smem + vx[s >> 2] + vs * V_BYTES + (s & 3) * 4096);
       const v4i pf = odd_last ? pfa[s >> 2] : pfb[s >> 2];
       o[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, __builtin_bit_cast(v8bf, pf), o[s & 3], 0, 0, 0);
+      if constexpr (VAR & 4) {
+        if ((s & 3) == 3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(v8bf, pf), lacc, 0, 0, 0);
+      }
     }
   }
   const float l_part = (l4[0] + l4[1]) + (l4[2] + l4[3]);
-  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  // (VAR & 4: the MFMA contracted over both lane halves already)
+  const float l_tot = (VAR & 4) ? lacc[0] : l_part + __shfl_xor(l_part, 32, 64);
   const float inv = 1.0f / l_tot;
   store_o<FMT>(a, o, inv, b, h, qrow, hi);
 }
@@ -372,15 +345,15 @@ template <int VAR> static int launch2(const AttnArgs& a, int fmt, hipStream_t s)
   return 0;
 }
 
-// FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 0 = refills in the PV half, bit 1 = exact (undeferred) running max,
-// bit 2 = softmax work skewed by one gap (no dependent chain inside a gap)
+// FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 0 = V fragments 2 instead of 4 MFMAs ahead, bit 1 = exact (undeferred) running max,
+// bit 2 = row sums by an all-ones MFMA instead of 32 v_add per tile
 int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s) {
   const char* e = getenv("FLUXMI_ATTN_VAR");
   switch (e ? atoi(e) & 7 : 0) {
     case 1: return launch2<1>(a, fmt, s);
     case 2: return launch2<2>(a, fmt, s);
+    case 3: return launch2<3>(a, fmt, s);
     case 4: return launch2<4>(a, fmt, s);
-    case 5: return launch2<5>(a, fmt, s);
     case 6: return launch2<6>(a, fmt, s);
     default: return launch2<0>(a, fmt, s);
   }

@@ -29,13 +29,17 @@ CASES = {
                          w_seed=12, in_seed=22, trace="all"),
     "c2_19p38_L320": dict(depth=19, single=38, height=256, width=256, txt_len=64, quant=dict(modulation=True, embedders=False),
                           w_seed=13, in_seed=23, trace="blocks"),
+    # harness check only (no fixture): the same test code on a model that runs in a second
+    "tiny_2p2_L96": dict(depth=2, single=2, height=128, width=128, txt_len=32, quant=dict(modulation=True, embedders=False),
+                         w_seed=14, in_seed=24, trace="all",
+                         params=dict(hidden_size=256, num_heads=2, context_in_dim=128, vec_in_dim=64)),
 }
 T_CALIB, T_FROZEN, GUIDANCE = 1.0, 0.75, 3.5
 N_HEAD, N_STRIDED = 256, 768
 
 
 def params_for(case: dict) -> fo.FluxParams:
-    return fo.FluxParams(depth=case["depth"], depth_single_blocks=case["single"])
+    return fo.FluxParams(depth=case["depth"], depth_single_blocks=case["single"], **case.get("params", {}))
 
 
 def make_case(name: str, synth):

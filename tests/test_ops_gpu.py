@@ -442,8 +442,8 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     """The round-2 kernel rescales O / l / the pending P tile only when a row max grew by more than 2^8 (guide T13).  The branch is
     rare on random data, so it is FORCED: key rows are spiked against chosen query rows so that the row max jumps by far more than
     the threshold at chosen tiles (first tile, an odd tile, an even tile, the last tile), some rows several times; every row of the
-    full tensor is checked against fp64, and the three builds -- deferred, exact running max (FLUXMI_ATTN_VAR=2) and the
-    independently written round-1 kernel (FLUXMI_ATTN_V=1) -- must agree to rounding."""
+    full tensor is checked against fp64, and the builds -- deferred, exact running max (FLUXMI_ATTN_VAR=2), row sums by MFMA
+    (FLUXMI_ATTN_VAR=4) and the independently written round-1 kernel (FLUXMI_ATTN_V=1) -- must agree to rounding."""
     torch.manual_seed(81)
     B, H = 1, 2
     q = torch.randn(B, H, L, 128).bfloat16()
@@ -459,8 +459,8 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     VT = _vt_layout(v, L)
     d = lambda t: t.to(dev)
     outs = {}
-    for name, env in (("deferred", {}), ("exact", {"FLUXMI_ATTN_VAR": "2"}), ("dma_in_pv", {"FLUXMI_ATTN_VAR": "1"}), ("gap_skew", {"FLUXMI_ATTN_VAR": "4"}),
-                      ("gap_skew_exact", {"FLUXMI_ATTN_VAR": "6"}), ("round1", {"FLUXMI_ATTN_V": "1"})):
+    for name, env in (("deferred", {}), ("exact", {"FLUXMI_ATTN_VAR": "2"}), ("shallow_prefetch", {"FLUXMI_ATTN_VAR": "1"}),
+                      ("mfma_rowsum", {"FLUXMI_ATTN_VAR": "4"}), ("mfma_rowsum_exact", {"FLUXMI_ATTN_VAR": "6"}), ("round1", {"FLUXMI_ATTN_V": "1"})):
         for kk in ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V"):
             monkeypatch.delenv(kk, raising=False)
         for kk, vv in env.items():
@@ -468,10 +468,10 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
         outs[name] = ops.attention(d(q), d(k), d(VT)).cpu()
         err = (outs[name].double() - ref).abs().max().item()
         assert torch.isfinite(outs[name]).all() and err <= 2e-2 * v.abs().max().item(), f"{name}: max abs err {err:.3e} vs fp64"
-    for name in ("exact", "dma_in_pv", "gap_skew", "gap_skew_exact", "round1"):
+    for name in ("exact", "shallow_prefetch", "mfma_rowsum", "mfma_rowsum_exact", "round1"):
         dd = (outs["deferred"].float() - outs[name].float()).abs().max().item()
         assert dd <= 2e-2 * v.abs().max().item(), f"deferred vs {name}: {dd:.3e}"
-    assert torch.equal(outs["deferred"], outs["dma_in_pv"]) and torch.equal(outs["deferred"], outs["gap_skew"]), "schedule variants must not change bits"
+    assert torch.equal(outs["deferred"], outs["shallow_prefetch"]), "a schedule variant must not change bits"
     same = (outs["deferred"] == outs["exact"]).float().mean().item()
     print(f"L={L}: max |err| vs fp64 deferred {(outs['deferred'].double() - ref).abs().max().item():.2e} / exact "
           f"{(outs['exact'].double() - ref).abs().max().item():.2e} / round-1 {(outs['round1'].double() - ref).abs().max().item():.2e}; "

@@ -1,5 +1,5 @@
 """Interleaved A/B of the attention kernels in ONE process (guide rule 24): round-1 kernel (FLUXMI_ATTN_V=1) vs the round-2 pipeline and
-its variants (FLUXMI_ATTN_VAR bit 0 = refills in the PV half, bit 1 = exact running max, bit 2 = softmax work skewed by one MFMA gap), Flux-dev shapes, random data.
+its variants (FLUXMI_ATTN_VAR bit 0 = shallow V-fragment prefetch, bit 1 = exact running max, bit 2 = row sums by an all-ones MFMA), Flux-dev shapes, random data.
     python tools/attn_ab.py [--rounds 5] [--iters 20] [--L 4608 2816]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,7 @@ ap.add_argument("--L", type=int, nargs="+", default=[4608, 2816, 8192]); ap.add_
 ap.add_argument("--rounds", type=int, default=5)
 a = ap.parse_args()
 dev = torch.device("cuda:0"); torch.manual_seed(0)
-VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}), ("r2", {}), ("r2 gap-skew", {"FLUXMI_ATTN_VAR": "4"}), ("r2 gap-skew+dma-pv", {"FLUXMI_ATTN_VAR": "5"}),
+VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}), ("r2 (V 4 ahead)", {}), ("r2 V 2 ahead", {"FLUXMI_ATTN_VAR": "1"}), ("r2 rowsum-by-MFMA", {"FLUXMI_ATTN_VAR": "4"}),
             ("r2 exact-max", {"FLUXMI_ATTN_VAR": "2"})]
 
 
