@@ -69,11 +69,11 @@ def linear_flops_per_step(Li, Lt, H=3072):
 
 
 def kernel_source_key():
-    """content hash of the GEMM / attention kernel sources: counter files collected for other sources are reported as stale (null)"""
+    """content hash of the GEMM kernel sources + dispatcher: counter files collected for other sources are reported as stale (null)"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "flux-fp8-api_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.startswith(("gemm", "attention", "common", "api")) and f.endswith((".hip", ".h", ".cpp")):
+        if f.startswith(("gemm", "common", "api")) and f.endswith((".hip", ".h", ".cpp")):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -191,52 +191,73 @@ def read_pmc(kind, cfg_id):
         return None
 
 
-def collect_pmc(cfg_id, Li, Lt, table):
-    """Live rocprofv3 PMC passes (separate --pmc runs, never combined with traces: MI355X_MICROARCH.md 'HBM' / 'rocprofv3 PMC slots'):
-    FETCH_SIZE (x2: gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE -> HBM bytes per launch; SQ_VALU_MFMA_BUSY_CYCLES over
-    GRBM_GUI_ACTIVE/8 x 1024 SIMDs -> matrix-pipe busy fraction.  Writes profiles/r02_{traffic,mfma}_config<id>.json."""
-    out_dir = os.path.join(ROOT, "gpurun_out", f"pmc_config{cfg_id}")
+def pmc_dir(cfg_id):
+    return os.path.join(ROOT, "gpurun_out", f"pmc_config{cfg_id}")
+
+
+def collect_pmc(cfg_id, Li, Lt):
+    """Live rocprofv3 PMC passes (separate --pmc runs, never combined with traces: MI355X_MICROARCH.md 'HBM' / 'rocprofv3 PMC slots') over
+    tools/gemm_probe.py --cfg -1 (the production dispatch) for each of the step's GEMM shapes; raw CSVs under gpurun_out/pmc_config<id>/."""
+    out_dir = pmc_dir(cfg_id)
     os.makedirs(out_dir, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
-    per_traffic, per_busy = {}, {}
     for name, Ms, N, K, cnt, epi in gemm_shapes(Li, Lt):
-        M = sum(Ms)
         tag = name.split("(")[0].replace(".", "_")
-        vals = {}
         for pi, counters in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"])):
             d = os.path.join(out_dir, f"{tag}_p{pi}")
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
-                   sys.executable, os.path.join(ROOT, "tools", "gemm_probe.py"), "--shape", f"{M},{N},{K}", "--cfg", "-1", "--iters", "4",
+                   sys.executable, os.path.join(ROOT, "tools", "gemm_probe.py"), "--shape", f"{sum(Ms)},{N},{K}", "--cfg", "-1", "--iters", "4",
                    "--epi", {"bf16": "bf16", "gate_resid": "gate", "gelu_quant": "gelu", "split": "bf16"}[epi]]
             try:
                 subprocess.run(cmd, env=env, cwd="/tmp", check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
-                import csv
-                import glob
+            except Exception:  # noqa
+                pass
 
-                for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                    with open(path) as f:
-                        for row in csv.DictReader(f):
-                            if "gemm" in row.get("Kernel_Name", ""):
-                                vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-            except Exception as ex:  # noqa
-                vals["error"] = str(ex)
-        mean = lambda k: (sum(vals[k]) / len(vals[k])) if vals.get(k) else None
-        fs, ws, ga, mb = mean("FETCH_SIZE"), mean("WRITE_SIZE"), mean("GRBM_GUI_ACTIVE"), mean("SQ_VALU_MFMA_BUSY_CYCLES")
+
+def summarize_pmc(cfg_id, Li, Lt):
+    """raw CSVs -> profiles/r02_{traffic,mfma}_config<id>.json, keyed by the kernel-source hash.  HBM bytes per launch =
+    (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 tallies a 128-B fabric read at 64 B: MI355X_MICROARCH.md 'HBM'); matrix-pipe busy fraction =
+    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs).  The first dispatch of every kernel (cold caches, lazy init) is
+    dropped; the 256x256 kernels of a launch are summed with its 128x128 peel."""
+    import csv
+    import glob
+
+    out_dir = pmc_dir(cfg_id)
+    per_traffic, per_busy = {}, {}
+    for name, Ms, N, K, cnt, epi in gemm_shapes(Li, Lt):
+        tag = name.split("(")[0].replace(".", "_")
+        vals = {}
+        for pi in range(3):
+            for path in glob.glob(os.path.join(out_dir, f"{tag}_p{pi}", "**", "*counter_collection.csv"), recursive=True):
+                seen = {}
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        kn = row.get("Kernel_Name", "")
+                        if "gemm" not in kn:
+                            continue
+                        key = (kn, row["Counter_Name"])
+                        seen[key] = seen.get(key, 0) + 1
+                        if seen[key] == 1:
+                            continue  # first dispatch of this kernel
+                        vals.setdefault(row["Counter_Name"], {}).setdefault(kn, []).append(float(row["Counter_Value"]))
+        tot = lambda c: sum(sum(v) / len(v) for v in vals.get(c, {}).values()) if vals.get(c) else None
+        fs, ws, ga, mb = tot("FETCH_SIZE"), tot("WRITE_SIZE"), tot("GRBM_GUI_ACTIVE"), tot("SQ_VALU_MFMA_BUSY_CYCLES")
         if fs is not None and ws is not None:
-            per_traffic[name] = (2.0 * fs + ws) * 1024.0  # KiB counters
+            per_traffic[name] = (2.0 * fs + ws) * 1024.0
         if ga and mb:
             per_busy[name] = mb / (ga / 8.0 * 1024.0)
     key = kernel_source_key()
-    w = {r["launch"]: r["per_step"] for r in table}
+    w = {name: cnt for name, _m, _n, _k, cnt, _e in gemm_shapes(Li, Lt)}
+    how = "bench.py --pmc: rocprofv3 --kernel-trace --pmc <counters> -- python tools/gemm_probe.py --shape M,N,K --cfg -1 (one pass per counter set)"
     if per_traffic:
-        tot = sum(per_traffic[n] * w[n] for n in per_traffic) / sum(w[n] for n in per_traffic)
-        json.dump({"source_key": key, "bytes_per_launch": tot, "per_launch": per_traffic,
-                   "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/gemm_probe.py --cfg -1; (2*FETCH_SIZE + WRITE_SIZE) KiB"},
-                  open(pmc_file("traffic", cfg_id), "w"), indent=1)
+        tot_b = sum(per_traffic[n] * w[n] for n in per_traffic) / sum(w[n] for n in per_traffic)
+        with open(pmc_file("traffic", cfg_id), "w") as f:
+            json.dump({"source_key": key, "bytes_per_launch": tot_b, "per_launch": per_traffic, "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB", "how": how}, f, indent=1)
     if per_busy:
-        json.dump({"source_key": key, "per_launch": per_busy,
-                   "how": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), tools/gemm_probe.py --cfg -1"},
-                  open(pmc_file("mfma", cfg_id), "w"), indent=1)
+        with open(pmc_file("mfma", cfg_id), "w") as f:
+            json.dump({"source_key": key, "per_launch": per_busy,
+                       "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)", "how": how}, f, indent=1)
+    return per_traffic, per_busy
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -284,6 +305,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--pmc", action="store_true", help="collect the rocprofv3 PMC counters live (adds ~2 min)")
+    ap.add_argument("--pmc-summarize", action="store_true", help="no GPU: rebuild profiles/r02_*_config<id>.json from gpurun_out/pmc_config<id>/")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--depth", type=int, default=None, help="debug only: fewer blocks (the result is then flagged invalid)")
     args = ap.parse_args()
@@ -291,6 +313,10 @@ def main():
 
     import torch
 
+    if args.pmc_summarize:
+        Li, Lt = (C["height"] // 16) * (C["width"] // 16), C["txt_len"]
+        print(json.dumps(summarize_pmc(args.config, Li, Lt), indent=1))
+        return
     if args.cpu_baseline_only:
         print(json.dumps({"config": args.config, "workload": C["name"], "cpu_baseline": cpu_baseline(args.config)}), flush=True)
         return
@@ -396,8 +422,10 @@ def main():
             lin_flops = linear_flops_per_step(Li, Lt)
             fp8 = C["quant"] is not None
             fl, by, sec, gemm_table = measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=fp8)
+            attn_row = measure_attention(torch, ops, dev, Li + Lt)
             if args.pmc and world == 1 and fp8:
-                collect_pmc(args.config, Li, Lt, gemm_table)
+                collect_pmc(args.config, Li, Lt)
+                summarize_pmc(args.config, Li, Lt)
             traffic, busy = read_pmc("traffic", args.config), read_pmc("mfma", args.config)
             busy_w = None
             if busy:
@@ -418,7 +446,7 @@ def main():
                          "traffic_note": None if traffic else "no PMC file for the current kernel sources (run bench.py --pmc)",
                          "flops_per_launch": fl, "algorithmic_bytes_per_launch": by, "avg_launch_us": round(sec * 1e6, 2),
                          "mfma_busy_frac_pmc": busy_w, "launches": gemm_table,
-                         "attention": measure_attention(torch, ops, dev, Li + Lt)})
+                         "attention": attn_row})
             result = {
                 "metric": "denoise it/s, " + C["name"],
                 "value": round(its, 4), "unit": "it/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup,

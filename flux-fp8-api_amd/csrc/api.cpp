@@ -114,6 +114,25 @@ int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs_in, int n_in, int N, int K, i
     if (best_k > 0) {
       std::vector<FluxmiGemmGroup> big, small;
       for (size_t q = 0; q < gs.size(); ++q) (q < (size_t)best_k ? small : big).push_back(gs[order[q]]);
+      if (hybrid >= 2) {
+        // FLUXMI_GEMM_HYBRID=2: the thin 128x128 launch runs on a side stream BESIDE the 256x256 launch (fork / join through events,
+        // which hipGraph capture records as edges): its workgroups fill the CUs the last round of the big grid leaves idle instead of
+        // running after it.  The two launches write disjoint rows.
+        static thread_local hipStream_t side = nullptr;
+        static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        if (!side) {
+          FLUXMI_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+          FLUXMI_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+          FLUXMI_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        FLUXMI_CHECK_HIP(hipEventRecord(ev_fork, s));
+        FLUXMI_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        FLUXMI_TRY(run_gemm_chunk(small.data(), (int)small.size(), N, K, is_fp8, act_fmt, epi, 2, side));
+        FLUXMI_CHECK_HIP(hipEventRecord(ev_join, side));
+        FLUXMI_TRY(run_gemm_chunk(big.data(), (int)big.size(), N, K, is_fp8, act_fmt, epi, -1, s));
+        FLUXMI_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
+        return 0;
+      }
       FLUXMI_TRY(run_gemm_chunk(big.data(), (int)big.size(), N, K, is_fp8, act_fmt, epi, -1, s));
       return run_gemm_chunk(small.data(), (int)small.size(), N, K, is_fp8, act_fmt, epi, 2, s);
     }

@@ -198,6 +198,15 @@ def attention(q, k, v, pe):
     return x.reshape(*x.shape[:-2], -1)
 
 
+def attention_exact(q, k, v, pe):
+    """Same contract as `attention` with the softmax evaluated in fp64 and rounded once: an equally valid evaluation of
+    flux_model.py:41-45 (SDPA's internal order / precision is implementation-defined).  The tests use it to measure how far a block's
+    output moves under rounding-level changes of the attention output -- the noise floor the HIP engine is gated against."""
+    q, k = apply_rope(q, k, pe)
+    x = attention_fp64(q, k, v).to(q.dtype).transpose(1, 2)
+    return x.reshape(*x.shape[:-2], -1)
+
+
 def attention_fp64(q, k, v):
     """softmax(q k^T / sqrt(d)) v in fp64 on already-rotated bf16 q,k (independent check)."""
     s = (q.double() @ k.double().transpose(-1, -2)) / math.sqrt(q.shape[-1])
@@ -290,8 +299,8 @@ class FluxOracle:
         out = self.lin[prefix + ".lin"](F.silu(vec), trace, prefix + ".lin")
         return out[:, None, :].chunk(n, dim=-1)
 
-    def double_block(self, i, img, txt, vec, pe, trace=None):
-        """flux_model.py:356-400 (bf16 flow: no clamp)."""
+    def double_block(self, i, img, txt, vec, pe, trace=None, attn_fn=None):
+        """flux_model.py:356-400 (bf16 flow: no clamp).  attn_fn: alternative evaluation of `attention` (tests' noise probe)."""
         pre = f"double_blocks.{i}"
         H = self.p.num_heads
         im = self._modulation(pre + ".img_mod", vec, 6, trace)
@@ -309,7 +318,7 @@ class FluxOracle:
         q = torch.cat((tq, iq), dim=2)
         k = torch.cat((tk, ik), dim=2)
         v = torch.cat((tv, iv), dim=2)
-        attn = attention(q, k, v, pe)
+        attn = (attn_fn or attention)(q, k, v, pe)
         Lt = txt.shape[1]
         t_attn, i_attn = attn[:, :Lt], attn[:, Lt:]
         if trace is not None:
@@ -332,7 +341,7 @@ class FluxOracle:
         txt = txt + tm[5] * self.lin[pre + ".txt_mlp.2"](F.gelu(h, approximate="tanh"), trace, pre + ".txt_mlp.2")
         return img, txt
 
-    def single_block(self, i, x, vec, pe, trace=None):
+    def single_block(self, i, x, vec, pe, trace=None, attn_fn=None):
         """flux_model.py:467-485."""
         pre = f"single_blocks.{i}"
         Hd = self.p.hidden_size
@@ -343,7 +352,7 @@ class FluxOracle:
         q, k, v = split_heads(qkv, self.p.num_heads)
         q = rms_norm(q, self.sd[pre + ".norm.query_norm.scale"])
         k = rms_norm(k, self.sd[pre + ".norm.key_norm.scale"])
-        attn = attention(q, k, v, pe)
+        attn = (attn_fn or attention)(q, k, v, pe)
         cat = torch.cat((attn, F.gelu(mlp, approximate="tanh")), 2)
         out = self.lin[pre + ".linear2"](cat, trace, pre + ".linear2")
         if trace is not None:
