@@ -280,9 +280,10 @@ int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, 
   a.B = B; a.L = L; a.Lp = Lp; a.H = H;
   a.scale_log2 = 0.08838834764831845f * 1.4426950408889634f;  // 128^-0.5 * log2(e)
   {
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("FLUXMI_ATTN_ABL"); abl = e ? atoi(e) : 0; }
-    a.abl = abl;
+    const char* e = getenv("FLUXMI_ATTN_ABL");  // read per call (A/B probes flip it inside one process)
+    a.abl = e ? atoi(e) : 0;
+    // the regrouped fp8 epilogue stores 16 B per lane: rows that are not 16-byte aligned keep the 4-byte stores
+    if (out_fp8 && ((((uintptr_t)out) | (uintptr_t)ld_out | (uintptr_t)col_off) & 15)) a.abl |= 8;
   }
   // round-2 pipeline (attention2.hip) by default; FLUXMI_ATTN_V=1 selects the round-1 kernel below (kept for A/B and as the
   // independently written cross-check of tests/test_ops_gpu.py::test_attention_v1_v2_agree)

@@ -18,6 +18,10 @@
 //      the rescale leaves the steady state;
 //   3. keeps four independent row-sum accumulators (no dependent chain) and scalar f32 VALU ops (packed f32 VALU beside MFMAs is
 //      an anti-lever on CDNA4, MI355X_MICROARCH.md).
+//   4. (VAR bit 0) folds the softmax scale and the running max into the MATRIX pipe: Q is pre-multiplied by scale*log2(e) while its
+//      fragments are built, and the first MFMA of every S accumulator starts from C = -M (M = the deferred running max, one 16-register
+//      block per lane, rewritten only in the rescale branch), so S arrives as s - M and the per-score fma disappears: exp2, row-sum
+//      add, half a cvt_pk and half a max3 per MFMA gap.  The rescale decision becomes `row max of the shifted tile > 2^8`.
 // Correctness of the deferred rescale with a pending tile: when the branch fires with f = 2^((m_old - m_new) c), everything still at
 // the old max is scaled exactly once -- O (tiles <= j-2), l (tiles <= j-1) and the bf16 fragments of P_{j-1} (re-rounded) -- and
 // P_j is exponentiated after the decision.  tests/test_ops_gpu.py forces the branch (spiked key rows) and sweeps THR.
@@ -42,8 +46,10 @@ constexpr int VRING2 = RD2 * K_BYTES;
 constexpr float DEFER_LOG2 = 8.0f;  // rescale only when a row max grew by more than 2^8 (in the exp2 domain)
 // VAR bit 1 (A/B + the THR sweep of the tests): exact max tracking, i.e. rescale whenever any row max grows
 
-// VAR bit 0: shallow V-fragment prefetch (A/B knob); measured and dropped in round 2 (profiles/r02_attention_ab.txt): refills in the PV
-// half (-0.4 %), softmax work skewed by one gap so that nothing inside a gap depends on anything in it (-4 %: +17 register moves)
+// VAR bit 0: scale + running max folded into the QK^T MFMAs, bit 1: exact max, bit 2: Q arithmetic under the K/V prologue DMA.
+// Measured and dropped in round 2 (profiles/r02_attention_ab.txt): refills in the PV half (-0.4 %), softmax work skewed by one gap so that
+// nothing inside a gap depends on anything in it (-4 %: +17 register moves), row sums by an all-ones MFMA (-4 %), V fragments 2 instead of
+// 4 MFMAs ahead (-0.5 %)
 template <int FMT, int VAR>
 __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs a) {
   constexpr int QB = NW2 * 32;
@@ -60,8 +66,11 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   const int qld = min(qrow, a.L - 1);
   const long long bh = (long long)b * a.H + h;
 
+  constexpr bool FOLD = (VAR & 1) != 0;
+  const float c = a.scale_log2;
   v8bf qf[8];
-  load_q_frags(a, b, h, qld, hi, qf);
+  if constexpr (!(VAR & 4)) load_q_frags(a, b, h, qld, hi, FOLD ? c : 1.0f, qf, [] {});
+  if ((a.abl & 4) && wave >= NW2 / 2) __builtin_amdgcn_s_setprio(1);
 
   const auto krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.K + bh * a.L * 128), 0, a.L * 256, 0x00020000);
   const auto vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.VT + bh * 128 * a.Lp), 0, 128 * a.Lp * 2, 0x00020000);
@@ -83,15 +92,11 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -1e30f;
   float l4[4] = {0.f, 0.f, 0.f, 0.f};
-  // VAR & 4: the row sum as a fifth "d block" of the PV product -- an all-ones A fragment against the P fragments (4 MFMAs per tile,
-  // no LDS operand) instead of 32 v_add per tile: every row of the 32x32 result tile holds the sum over the tile's 64 keys
-  v16f lacc;
+  // FOLD: M = deferred running max in the exp2 domain; ninit = sixteen copies of -M, the C operand of the first QK^T MFMAs
+  float m_cur = 0.f;
+  v16f ninit;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
-  v8bf ones;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-  const float c = a.scale_log2;
+  for (int r = 0; r < 16; ++r) ninit[r] = 0.f;
 
   unsigned kx[8], vx[4];
   {
@@ -127,11 +132,15 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   // the next V^T row into a ring slot nobody reads any more, so the vmcnt arithmetic is the same in every step and the step body
   // has no branch (a wave-uniform branch per refill split the step into basic blocks and let MachineSink drag the pinned VALU
   // work out of its MFMA gaps).
-  {
+  auto prologue_dma = [&] {
     auto iss_k = [&](int t) { dma_k(t, t * KT, 0); dma_k(t, t * KT, 1); };
     auto iss_v = [&](int t) { dma_v(t, t * KT, 0); dma_v(t, t * KT, 1); };
     iss_k(0); iss_k(1); iss_v(0); iss_k(2); iss_v(1); iss_k(3);
-  }
+  };
+  // VAR & 4: the Q loads are issued first and are OLDER than the twelve DMA pieces, so the wait hipcc puts in front of the QKNorm / RoPE
+  // arithmetic is vmcnt(12) and that arithmetic runs under the DMA latency
+  if constexpr ((VAR & 4) != 0) load_q_frags(a, b, h, qld, hi, FOLD ? c : 1.0f, qf, prologue_dma);
+  else prologue_dma();
   wait_vm<5 * LPW2>();
   __builtin_amdgcn_s_barrier();
   v16f sa[2], sb[2];
@@ -161,6 +170,17 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       for (int r = 0; r < 16; ++r) m0 = fmaxf(m0, sa[t][r]);
     mx = finish_max(m0);
   }
+  if constexpr (FOLD) {  // M = exact max of tile 0; S_0 -> S_0 - M; nothing to rescale in step 0
+    m_cur = mx;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[t][r] -= m_cur;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ninit[r] = -m_cur;
+    asm volatile("" : "+v"(ninit));  // sixteen live registers, not a splat hipcc re-materialises in front of every MFMA pair
+    mx = 0.f;
+  }
 
   // ---- one step, compile-time ring slot PAR = j % 4; FIRST: no pending tile (j == 0) ------------------------------------------------
   // cur = S_j (raw scores, turned into P_j in place), nxt = S_{j+1}, pp = bf16 fragments of P_{j-1} (consumed), pc = of P_j (produced)
@@ -175,34 +195,46 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!(a.abl & 2)) __builtin_amdgcn_s_barrier();
     // -- A: running max with deferred rescale (wave-uniform branch, out of the steady state)
-    {
-      const float m_new = fmaxf(m_run, mx);
-      if (__any((m_new - m_run) * c > ((VAR & 2) ? 0.0f : DEFER_LOG2))) {
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        if constexpr (!(VAR & 4)) {
+    auto rescale_state = [&](float alpha) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) l4[i] *= alpha;
-        } else {
+      for (int i = 0; i < 4; ++i) l4[i] *= alpha;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
-        }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      if constexpr (!FIRST) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        if constexpr (!FIRST) {
+          for (int e = 0; e < 4; ++e) {
+            const unsigned w = (unsigned)pp[i][e];
+            pp[i][e] = (int)pack_bf2(__uint_as_float(w << 16) * alpha, __uint_as_float(w & 0xffff0000u) * alpha);
+          }
+      }
+    };
+    float nmc = 0.f;
+    if constexpr (FOLD) {
+      // mx = row max of S_j - M.  Rows that grew are moved to their new max (delta = max(mx, 0)); S_j itself was produced with the old M
+      if (__any(mx > ((VAR & 2) ? 0.0f : DEFER_LOG2))) {
+        const float delta = fmaxf(mx, 0.f);
+        rescale_state(__builtin_amdgcn_exp2f(-delta));
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const unsigned w = (unsigned)pp[i][e];
-              pp[i][e] = (int)pack_bf2(__uint_as_float(w << 16) * alpha, __uint_as_float(w & 0xffff0000u) * alpha);
-            }
-        }
+          for (int r = 0; r < 16; ++r) cur[t][r] -= delta;
+        m_cur += delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ninit[r] = -m_cur;
+        asm volatile("" : "+v"(ninit));
+      }
+    } else {
+      const float m_new = fmaxf(m_run, mx);
+      if (__any((m_new - m_run) * c > ((VAR & 2) ? 0.0f : DEFER_LOG2))) {
+        rescale_state(__builtin_amdgcn_exp2f((m_run - m_new) * c));
         m_run = m_new;
       }
+      nmc = -m_run * c;
     }
-    const float nmc = -m_run * c;
     // score e (0..31) of S_j -> P_j in place; every second one packs a bf16 pair of the P fragment
     // Pure VALU nodes carry no chain: left alone, the DAG scheduler floats every fma / exp of the step above the first MFMA and
     // MachineSink drags results down to their users.  Passing the input and the outputs of a gap's work through (empty) asm
@@ -211,30 +243,34 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       constexpr int e = decltype(EC)::value, t = e >> 4, r = e & 15;
       float sc = cur[t][r];
       asm volatile("" : "+v"(sc));
-      float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c, nmc));
-      float ls = 0.f;
-      if constexpr (!(VAR & 4)) ls = l4[e & 3] + p;
+      float p = FOLD ? __builtin_amdgcn_exp2f(sc) : __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c, nmc));
+      float ls = l4[e & 3] + p;
       if constexpr (e & 1) {
         constexpr int f = t * 2 + (r >> 3), q = (r & 7) >> 1;
         // one v_cvt_pk_bf16_f32 for the pair (through pack_bf2 hipcc converts each half separately and ORs them: 4 instructions).
         // The s_nop is the trans-op -> VALU wait state hipcc would pad itself (p comes straight from v_exp_f32).
         int w;
         asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[t][r - 1]), "v"(p));
-        if constexpr (VAR & 4) asm volatile("" : "+v"(p)); else asm volatile("" : "+v"(p), "+v"(ls));
+        asm volatile("" : "+v"(p), "+v"(ls));
         pc[f][q] = w;
       } else {
-        if constexpr (VAR & 4) asm volatile("" : "+v"(p)); else asm volatile("" : "+v"(p), "+v"(ls));
+        asm volatile("" : "+v"(p), "+v"(ls));
       }
       cur[t][r] = p;
-      if constexpr (!(VAR & 4)) l4[e & 3] = ls;
+      l4[e & 3] = ls;
     };
     auto gapwork = [&](auto GC) { soft(GC); };
     // -- B: S_{j+1} = K_{j+1} Q^T, two alternating accumulators; K fragments two chunks ahead; one score of P_j per gap
     {
+      if constexpr (FOLD) {
+        nxt[0] = ninit;
+        nxt[1] = ninit;
+      } else {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) nxt[t][r] = 0.f;
+          for (int r = 0; r < 16; ++r) nxt[t][r] = 0.f;
+      }
       v8bf kf[3][2];
       kf[0][0] = k_frag(KS, 0, 0); kf[0][1] = k_frag(KS, 0, 1);
       kf[1][0] = k_frag(KS, 1, 0); kf[1][1] = k_frag(KS, 1, 1);
@@ -265,7 +301,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     };
     if constexpr (!FIRST) {
       // V fragments VPF MFMAs ahead (PMC of the 2-ahead version: the waves sat a third of their cycles in s_waitcnt / s_barrier)
-      constexpr int VPF = (VAR & 1) ? 2 : 4;
+      constexpr int VPF = 4;
       v8bf vf[VPF + 1];
 #pragma unroll
       for (int q = 0; q < VPF; ++q) vf[q] = v_frag(VS, q >> 2, q & 3);
@@ -273,7 +309,6 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       static_for<16>([&](auto SC) {
         constexpr int s = decltype(SC)::value, ch4 = s >> 2, db = s & 3;
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s % (VPF + 1)], __builtin_bit_cast(v8bf, pp[ch4]), o[db], 0, 0, 0);
-        if constexpr ((VAR & 4) != 0 && db == 3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(v8bf, pp[ch4]), lacc, 0, 0, 0);
         fence();
         if constexpr (s + VPF < 16) vf[(s + VPF) % (VPF + 1)] = v_frag(VS, (s + VPF) >> 2, (s + VPF) & 3);
         gapwork(std::integral_constant<int, 16 + s>{});
@@ -317,14 +352,10 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       const v8bf vfr = *(const v8bf*)(smem + vx[s >> 2] + vs * V_BYTES + (s & 3) * 4096);
       const v4i pf = odd_last ? pfa[s >> 2] : pfb[s >> 2];
       o[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, __builtin_bit_cast(v8bf, pf), o[s & 3], 0, 0, 0);
-      if constexpr (VAR & 4) {
-        if ((s & 3) == 3) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, __builtin_bit_cast(v8bf, pf), lacc, 0, 0, 0);
-      }
     }
   }
   const float l_part = (l4[0] + l4[1]) + (l4[2] + l4[3]);
-  // (VAR & 4: the MFMA contracted over both lane halves already)
-  const float l_tot = (VAR & 4) ? lacc[0] : l_part + __shfl_xor(l_part, 32, 64);
+  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
   const float inv = 1.0f / l_tot;
   store_o<FMT>(a, o, inv, b, h, qrow, hi);
 }
@@ -345,8 +376,8 @@ template <int VAR> static int launch2(const AttnArgs& a, int fmt, hipStream_t s)
   return 0;
 }
 
-// FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 0 = V fragments 2 instead of 4 MFMAs ahead, bit 1 = exact (undeferred) running max,
-// bit 2 = row sums by an all-ones MFMA instead of 32 v_add per tile
+// FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 0 = scale and running max folded into the QK^T MFMAs, bit 1 = exact (undeferred)
+// running max, bit 2 = Q arithmetic under the prologue DMA
 int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s) {
   const char* e = getenv("FLUXMI_ATTN_VAR");
   switch (e ? atoi(e) & 7 : 0) {
@@ -354,7 +385,8 @@ int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s) {
     case 2: return launch2<2>(a, fmt, s);
     case 3: return launch2<3>(a, fmt, s);
     case 4: return launch2<4>(a, fmt, s);
-    case 6: return launch2<6>(a, fmt, s);
+    case 5: return launch2<5>(a, fmt, s);
+    case 7: return launch2<7>(a, fmt, s);
     default: return launch2<0>(a, fmt, s);
   }
 }

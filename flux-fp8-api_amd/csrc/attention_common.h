@@ -16,7 +16,8 @@ struct AttnArgs {
   const float* q_scale[2]; int split;
   int B, L, Lp, H;
   float scale_log2;
-  int abl;  // timing-only ablations (FLUXMI_ATTN_ABL): 1 = no LDS-DMA in the tile loop, 2 = no barrier
+  int abl;  // A/B knobs (FLUXMI_ATTN_ABL, read per call): 1 = no LDS-DMA in the tile loop (round-1 kernel), 2 = no barrier (both timing-only),
+            // 4 = s_setprio 1 for the younger half of the workgroup, 8 = round-1 fp8 store (16 x 4 B per lane)
 };
 
 namespace {
@@ -42,22 +43,48 @@ constexpr int A_STAGE = K_BYTES + V_BYTES;
 // Q fragments (MFMA B operand): 8 x (8 bf16); lane (l31, hi) holds d = c*16 + hi*8 + [0,8) of query row `qld` of (b, h).
 // raw-Q mode (a.Q == nullptr): the row comes straight from the qkv GEMM output and QKNorm + RoPE are applied here
 // (flux_model.py:158-176,60-65), so the normalised / rotated Q tensor never exists in HBM.
-__device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, int qld, int hi, v8bf (&qf)[8]) {
+// `between()` runs after the global loads have been ISSUED and before their results are used: a kernel puts its K/V LDS-DMA prologue
+// there (vmcnt is in-order, so the wait for the older Q loads leaves the DMA pieces in flight and the norm / RoPE arithmetic runs
+// under their latency).  `fold` != 1: the fragments are multiplied by it (softmax scale * log2 e folded into Q, attention2.hip)
+// and rounded to bf16 again.
+template <class F>
+__device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, int qld, int hi, float fold, v8bf (&qf)[8], F&& between) {
   const long long bh = (long long)b * a.H + h;
   if (a.Q) {
     const u16* qp = a.Q + (bh * a.L + qld) * 128 + hi * 8;
+    uint4 raw[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) qf[c] = *(const v8bf*)(qp + c * 16);
+    for (int c = 0; c < 8; ++c) raw[c] = *(const uint4*)(qp + c * 16);
+    between();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (fold != 1.0f) {
+        float y[8];
+        unpack8(raw[c], y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] *= fold;
+        raw[c] = pack8(y);
+      }
+      qf[c] = __builtin_bit_cast(v8bf, raw[c]);
+    }
   } else {
     const long long tok = (long long)b * a.L + qld;
     const u16* qp = a.qraw + tok * a.ldq + (long long)h * 128 + hi * 8;
     const u16* pp = a.pe + (tok * 64 + hi * 4) * 2;  // (cos, sin) of pairs d/2
     const u16* wn = a.qn[qld < a.split ? 0 : 1] + hi * 8;
+    uint4 raw[8], rw[8], rcs[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      raw[c] = *(const uint4*)(qp + c * 16);
+      rw[c] = *(const uint4*)(wn + c * 16);
+      rcs[c] = *(const uint4*)(pp + c * 16);
+    }
+    between();
     float x[8][8];
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      unpack8(*(const uint4*)(qp + c * 16), x[c]);
+      unpack8(raw[c], x[c]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) ss += x[c][j] * x[c][j];
     }
@@ -70,8 +97,8 @@ __device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, in
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float w[8], cs[8], y[8];
-      unpack8(*(const uint4*)(wn + c * 16), w);
-      unpack8(*(const uint4*)(pp + c * 16), cs);
+      unpack8(rw[c], w);
+      unpack8(rcs[c], cs);
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[c][j] = rbf((x[c][j] * rinv) * w[j]);
 #pragma unroll
@@ -80,10 +107,17 @@ __device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, in
         y[2 * p] = rbf(rbf(cc * x[c][2 * p]) + rbf((-sn) * x[c][2 * p + 1]));
         y[2 * p + 1] = rbf(rbf(sn * x[c][2 * p]) + rbf(cc * x[c][2 * p + 1]));
       }
+      if (fold != 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] *= fold;
+      }
       const uint4 pk = pack8(y);
       qf[c] = __builtin_bit_cast(v8bf, pk);
     }
   }
+}
+__device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, int qld, int hi, v8bf (&qf)[8]) {
+  load_q_frags(a, b, h, qld, hi, 1.0f, qf, [] {});
 }
 
 // normalise the O^T accumulators by the row sum and store one query row per lane (bf16, or fp8 with the consumer's input scale)
@@ -94,14 +128,31 @@ __device__ __forceinline__ void store_o(const AttnArgs& a, const v16f (&o)[4], f
   if (a.out_fp8) {
     const float qs = *a.q_scale[qrow < a.split ? 0 : 1];
     unsigned char* op = (unsigned char*)a.out + orow;
+    unsigned w[4][4];
 #pragma unroll
     for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + g * 8 + hi * 4;
-        *(unsigned*)(op + d) = cvt4_fp8<FMT>(q_prepare<FMT>(rbf(o[db][g * 4 + 0] * inv), qs), q_prepare<FMT>(rbf(o[db][g * 4 + 1] * inv), qs),
-                                             q_prepare<FMT>(rbf(o[db][g * 4 + 2] * inv), qs), q_prepare<FMT>(rbf(o[db][g * 4 + 3] * inv), qs));
-      }
+      for (int g = 0; g < 4; ++g)
+        w[db][g] = cvt4_fp8<FMT>(q_prepare<FMT>(rbf(o[db][g * 4 + 0] * inv), qs), q_prepare<FMT>(rbf(o[db][g * 4 + 1] * inv), qs),
+                                 q_prepare<FMT>(rbf(o[db][g * 4 + 2] * inv), qs), q_prepare<FMT>(rbf(o[db][g * 4 + 3] * inv), qs));
+    if (a.abl & 8) {  // round-1 store: 16 x 4 B per lane (A/B)
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(unsigned*)(op + db * 32 + g * 8 + hi * 4) = w[db][g];
+      return;
+    }
+    // word (db, g) of lane half `hi` covers d = db*32 + g*8 + hi*4 + [0,4).  One v_permlane32_swap of words g and g+2 leaves the
+    // lower lane with (g, hi 0), (g, hi 1) and the upper lane with (g+2, hi 0), (g+2, hi 1): after two swaps per d-block each lane
+    // owns 16 contiguous bytes -> 4 x global_store_dwordx4 per lane instead of 16 x dword (the store tail is issue-bound)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const auto s0 = __builtin_amdgcn_permlane32_swap(w[db][0], w[db][2], false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(w[db][1], w[db][3], false, false);
+      uint4 v;
+      v.x = s0[0]; v.y = s0[1]; v.z = s1[0]; v.w = s1[1];
+      *(uint4*)(op + db * 32 + hi * 16) = v;
+    }
   } else {
     u16* op = (u16*)a.out + orow;
 #pragma unroll

@@ -28,8 +28,13 @@ __device__ __forceinline__ u16 f2bf(float f) {
 }
 // round an fp32 value through bf16 (the reference materialised a bf16 tensor here)
 __device__ __forceinline__ float rbf(float f) { return (float)((bf16)f); }
+// two floats -> packed bf16 pair (RNE).  Written as ONE vector fptrunc so that hipcc selects a single v_cvt_pk_bf16_f32 for the pair;
+// two scalar casts + shift + or compile to two half-used v_cvt_pk_bf16_f32 plus two integer ops (4 instructions, same bits).
+typedef float v2f_pk_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const v2f_pk_t x = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
 }
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);

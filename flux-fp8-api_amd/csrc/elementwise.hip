@@ -250,6 +250,143 @@ __global__ void __launch_bounds__(256, 5) ln_modulate_kernel(const LnModArgs a) 
   }
 }
 
+// Streaming variant (round 2, FLUXMI_LN_V=2).  The one-wave-per-row kernel above puts EVERY row of a step on the chip at once, so all
+// waves move through the same phases together -- load (HBM busy, VALU idle), moments + modulate + quantise (~20 VALU ops per element:
+// VALU busy, HBM idle), store -- and the launch costs the SUM of its HBM and VALU time (18.5 us for 42 MB at L = 4608; either alone
+// is ~9 us).  Here one 8-wave workgroup per CU walks a contiguous block of rows; a wave owns every 8th row of it and issues the loads
+// of its NEXT row before it starts the arithmetic of the current one, so HBM and VALU time overlap inside each wave; both streams'
+// bf16(1 + scale) | shift vectors of the workgroup's batch element sit in LDS (4 x H bf16).
+// FULL: H == NCH * 512, i.e. no column guard anywhere (a guarded load sits in its own basic block and hipcc then waits vmcnt(0) at the
+// join -- the prefetch would be waited for right after its issue).  The next-row load is unconditional for the same reason (the
+// last iteration re-loads the wave's last row).
+template <int NCH, bool OUT_FP8, int FMT, bool FULL>
+__global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs a, int rows_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lnm_smem[];  // [stream][m1 | shift][H] bf16
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row, batch and stream live in SGPRs
+  const int rows = a.B * a.L;
+  const int r_begin = blockIdx.x * rows_per_wg, r_end = min(rows, r_begin + rows_per_wg);
+  const int b0 = r_begin / a.L;
+  auto load_row = [&](int row, uint4 (&dst)[NCH]) {
+    const int b = row / a.L, l = row - b * a.L;
+    const u16* xr = a.x + (long long)b * a.x_bstride + (long long)l * a.ldx;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = (lane + 64 * k) * 8;
+      if (FULL) dst[k] = *(const uint4*)(xr + c);
+      else dst[k] = (c < a.H) ? *(const uint4*)(xr + c) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  int row = r_begin + wave;
+  uint4 cur[NCH];
+  load_row(min(row, r_end - 1), cur);
+  u16* tab = (u16*)lnm_smem;
+  for (int st = 0; st < 2; ++st) {
+    const u16* sc0 = a.scale[st] + (long long)b0 * a.mod_bstride;
+    const u16* sh0 = a.shift[st] + (long long)b0 * a.mod_bstride;
+    for (int c = threadIdx.x * 8; c < a.H; c += 512 * 8) {
+      float fs[8], m1[8];
+      unpack8(*(const uint4*)(sc0 + c), fs);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m1[j] = 1.0f + fs[j];
+      *(uint4*)(tab + (st * 2) * a.H + c) = pack8(m1);          // bf16(1 + scale): the reference materialises it (flux_model.py:367)
+      *(uint4*)(tab + (st * 2 + 1) * a.H + c) = *(const uint4*)(sh0 + c);
+    }
+  }
+  float qs2[2] = {1.f, 1.f};
+  if (OUT_FP8) { qs2[0] = *a.q_scale[0]; qs2[1] = *a.q_scale[1]; }
+  __syncthreads();
+  while (row < r_end) {
+    const int nrow = row + 8;
+    uint4 nxt[NCH];
+    load_row(min(nrow, r_end - 1), nxt);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch on top (hipcc sinks it below the first reduction otherwise)
+    const int b = row / a.L, l = row - b * a.L, st = (l < a.split) ? 0 : 1;
+    const float qs = st ? qs2[1] : qs2[0];
+    const long long orow = (long long)b * a.out_bstride + (long long)l * a.ldo;
+    // pairs of elements in packed f32 VALU ops (v_pk_add / v_pk_mul / v_pk_fma: two elements per instruction) -- the kernel is VALU-bound
+    v2f_t sum2 = {0.f, 0.f};
+    float xv[NCH][8];  // the row in fp32, unpacked once for the three passes
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      unpack8(cur[k], xv[k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(xv[k][j]));  // opaque: hipcc would re-unpack the packed row in every pass
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) sum2 += (v2f_t){xv[k][j], xv[k][j + 1]};
+    }
+    // (the order of the fp32 additions differs from the one-wave-per-row kernel's; both are within fp32 rounding of the exact
+    // mean, and LayerNorm's output is rounded to bf16 -- tests/test_ops_gpu.py::test_ln_modulate holds both to the same gate)
+    const float mean = wave_sum(sum2[0] + sum2[1]) / (float)a.H;
+    const v2f_t mean2 = {mean, mean};
+    v2f_t sq2 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = (lane + 64 * k) * 8;
+      if (FULL || c < a.H) {
+        const float* v = xv[k];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const v2f_t d = (v2f_t){v[j], v[j + 1]} - mean2;
+          sq2 = __builtin_elementwise_fma(d, d, sq2);
+        }
+      }
+    }
+    const float sq = sq2[0] + sq2[1];
+    const float var = wave_sum(sq) / (float)a.H;
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    // rows of another batch element than the table's (B > 1, a workgroup straddling two of them): vectors from global memory
+    const bool from_lds = b == b0;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int c = (lane + 64 * k) * 8;
+      if (FULL || c < a.H) {
+        float m1[8], fh[8], y[8];
+        const float* v = xv[k];
+        if (from_lds) {
+          unpack8(*(const uint4*)(tab + (st * 2) * a.H + c), m1);
+          unpack8(*(const uint4*)(tab + (st * 2 + 1) * a.H + c), fh);
+        } else {
+          const u16* scg = (st ? a.scale[1] : a.scale[0]) + (long long)b * a.mod_bstride;
+          const u16* shg = (st ? a.shift[1] : a.shift[0]) + (long long)b * a.mod_bstride;
+          float fs[8];
+          unpack8(*(const uint4*)(scg + c), fs);
+          unpack8(*(const uint4*)(shg + c), fh);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) m1[j] = rbf(1.0f + fs[j]);
+        }
+        const v2f_t rstd2 = {rstd, rstd}, qs2v = {qs, qs};
+        float q[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          // one v_cvt_pk_bf16_f32 per rounded PAIR (rbf2); same operations in the same order as the scalar form
+          const v2f_t n = rbf2(((v2f_t){v[j], v[j + 1]} - mean2) * rstd2);
+          const v2f_t yy = rbf2(rbf2((v2f_t){m1[j], m1[j + 1]} * n) + (v2f_t){fh[j], fh[j + 1]});
+          y[j] = yy[0]; y[j + 1] = yy[1];
+          if (OUT_FP8) {
+            const v2f_t t = rbf2(yy * qs2v);
+            const float mx = fp8_max<FMT>();
+            // clamp that propagates NaN like torch.clamp (one compare on |t| per element; +-inf saturate)
+            q[j] = fabsf(t[0]) > mx ? copysignf(mx, t[0]) : t[0];
+            q[j + 1] = fabsf(t[1]) > mx ? copysignf(mx, t[1]) : t[1];
+          }
+        }
+        if (OUT_FP8) {
+          uint2 o;
+          o.x = cvt4_fp8<FMT>(q[0], q[1], q[2], q[3]);
+          o.y = cvt4_fp8<FMT>(q[4], q[5], q[6], q[7]);
+          *(uint2*)((unsigned char*)a.out + orow + c) = o;
+        } else {
+          *(uint4*)((u16*)a.out + orow + c) = pack8(y);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) cur[k] = nxt[k];
+    row = nrow;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // unfused elementwise ops (calibration / mixed-precision path)
 // ---------------------------------------------------------------------------------------------
@@ -519,8 +656,35 @@ int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void
   a.shift[1] = (const u16*)shift1; a.scale[1] = (const u16*)scale1;
   a.mod_bstride = mod_bstride; a.q_scale[0] = q0; a.q_scale[1] = q1;
   a.B = B; a.L = L; a.split = split; a.H = H;
-  const dim3 grid((B * L + 3) / 4), block(256);
   const int nch = (H + 511) / 512;
+  // FLUXMI_LN_V (read per call): 2 = streaming kernel (one 8-wave workgroup per CU, next row's loads under this row's arithmetic),
+  // 1 = one wave per row, every row resident at once
+  int lnv = 2;
+  { const char* e = getenv("FLUXMI_LN_V"); if (e) lnv = atoi(e); }
+  if (lnv == 2) {
+    const int rows = B * L;
+    const int n_wg = min(256, (rows + 7) / 8);
+    const int rows_per_wg = (rows + n_wg - 1) / n_wg;
+    const dim3 grid((rows + rows_per_wg - 1) / rows_per_wg), block(512);
+    const size_t lds = (size_t)H * 8;
+#define LNS2(N_, F_)                                                                                                             \
+  do {                                                                                                                           \
+    if (!out_fp8) hipLaunchKernelGGL((ln_modulate_stream_kernel<N_, false, FLUXMI_FMT_E5M2, F_>), grid, block, lds, s, a, rows_per_wg);           \
+    else if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((ln_modulate_stream_kernel<N_, true, FLUXMI_FMT_E5M2, F_>), grid, block, lds, s, a, rows_per_wg); \
+    else hipLaunchKernelGGL((ln_modulate_stream_kernel<N_, true, FLUXMI_FMT_E4M3, F_>), grid, block, lds, s, a, rows_per_wg);                     \
+  } while (0)
+#define LNS(N_) do { if (H == N_ * 512) LNS2(N_, true); else LNS2(N_, false); } while (0)
+    if (nch <= 1) LNS(1);
+    else if (nch <= 2) LNS(2);
+    else if (nch <= 4) LNS(4);
+    else if (nch <= 6) LNS(6);
+    else LNS(8);
+#undef LNS2
+#undef LNS
+    FLUXMI_LAUNCH_CHECK();
+    return 0;
+  }
+  const dim3 grid((B * L + 3) / 4), block(256);
   const size_t lds = (size_t)H * 4;  // bf16(1 + scale) and shift of the workgroup's stream
 #define LNM(N_)                                                                                                       \
   do {                                                                                                                \

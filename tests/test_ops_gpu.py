@@ -287,12 +287,16 @@ def test_gemv(ops, dev, B):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("L,Lt", [(40, 12), (42, 13)])
+@pytest.mark.parametrize("variant", ["stream", "row_per_wave"])
+@pytest.mark.parametrize("L,Lt", [(40, 12), (42, 13), (1300, 500)])
 @pytest.mark.parametrize("H", [256, 3072])
-def test_ln_modulate(ops, dev, H, L, Lt):
+def test_ln_modulate(ops, dev, H, L, Lt, variant, monkeypatch):
     """K4(+K2): (1+scale)*LayerNorm(x)+shift with the reference's bf16 rounding points (flux_model.py:367-368).
-    (42, 13): a workgroup's four rows straddle the txt|img split and the batch boundary (the rows that do not belong to the
-    workgroup's LDS-staged stream take their modulation vectors from global memory)."""
+    (42, 13): a workgroup's rows straddle the txt|img split and the batch boundary (the rows that do not belong to the
+    workgroup's LDS-staged table take their modulation vectors from global memory); (1300, 500): 256 workgroups with 10-11 rows each,
+    i.e. the streaming kernel's prefetch loop runs (every wave owns two rows, some a single one).
+    Both kernels: the streaming one (default, FLUXMI_LN_V=2) and the one-wave-per-row one (FLUXMI_LN_V=1)."""
+    monkeypatch.setenv("FLUXMI_LN_V", "2" if variant == "stream" else "1")
     torch.manual_seed(9)
     B = 2
     x = (torch.randn(B, L, H) * 2 + 0.3).bfloat16()
@@ -442,8 +446,10 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     """The round-2 kernel rescales O / l / the pending P tile only when a row max grew by more than 2^8 (guide T13).  The branch is
     rare on random data, so it is FORCED: key rows are spiked against chosen query rows so that the row max jumps by far more than
     the threshold at chosen tiles (first tile, an odd tile, an even tile, the last tile), some rows several times; every row of the
-    full tensor is checked against fp64, and the builds -- deferred, exact running max (FLUXMI_ATTN_VAR=2), row sums by MFMA
-    (FLUXMI_ATTN_VAR=4) and the independently written round-1 kernel (FLUXMI_ATTN_V=1) -- must agree to rounding."""
+    full tensor is checked against fp64, and the builds -- deferred, exact running max (FLUXMI_ATTN_VAR bit 1), scale + running max
+    folded into the QK^T MFMAs (bit 0), Q arithmetic under the prologue DMA (bit 2) and the independently written round-1 kernel
+    (FLUXMI_ATTN_V=1) -- must agree to rounding.  The fused fp8 output through the regrouped 16-byte stores must equal the round-1
+    4-byte stores bit for bit."""
     torch.manual_seed(81)
     B, H = 1, 2
     q = torch.randn(B, H, L, 128).bfloat16()
@@ -459,23 +465,39 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     VT = _vt_layout(v, L)
     d = lambda t: t.to(dev)
     outs = {}
-    for name, env in (("deferred", {}), ("exact", {"FLUXMI_ATTN_VAR": "2"}), ("shallow_prefetch", {"FLUXMI_ATTN_VAR": "1"}),
-                      ("mfma_rowsum", {"FLUXMI_ATTN_VAR": "4"}), ("mfma_rowsum_exact", {"FLUXMI_ATTN_VAR": "6"}), ("round1", {"FLUXMI_ATTN_V": "1"})):
-        for kk in ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V"):
+    knobs = ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V", "FLUXMI_ATTN_ABL")
+    variants = (("deferred", {}), ("exact", {"FLUXMI_ATTN_VAR": "2"}), ("fold", {"FLUXMI_ATTN_VAR": "1"}), ("fold_exact", {"FLUXMI_ATTN_VAR": "3"}),
+                ("prologue", {"FLUXMI_ATTN_VAR": "4"}), ("fold_prologue", {"FLUXMI_ATTN_VAR": "5"}), ("fold_exact_prologue", {"FLUXMI_ATTN_VAR": "7"}),
+                ("setprio", {"FLUXMI_ATTN_ABL": "4"}), ("round1", {"FLUXMI_ATTN_V": "1"}))
+    s0, s1 = torch.tensor(3000.0), torch.tensor(9000.0)
+    for name, env in variants:
+        for kk in knobs:
             monkeypatch.delenv(kk, raising=False)
         for kk, vv in env.items():
             monkeypatch.setenv(kk, vv)
         outs[name] = ops.attention(d(q), d(k), d(VT)).cpu()
         err = (outs[name].double() - ref).abs().max().item()
         assert torch.isfinite(outs[name]).all() and err <= 2e-2 * v.abs().max().item(), f"{name}: max abs err {err:.3e} vs fp64"
-    for name in ("exact", "shallow_prefetch", "mfma_rowsum", "mfma_rowsum_exact", "round1"):
+        # fused fp8 output: regrouped 16-byte stores == 4-byte stores
+        f8_new = ops.attention(d(q), d(k), d(VT), q_scale0=d(s0), q_scale1=d(s1), split=L // 3).cpu()
+        monkeypatch.setenv("FLUXMI_ATTN_ABL", str(int(env.get("FLUXMI_ATTN_ABL", "0")) | 8))
+        f8_old = ops.attention(d(q), d(k), d(VT), q_scale0=d(s0), q_scale1=d(s1), split=L // 3).cpu()
+        assert torch.equal(f8_new.view(torch.uint8), f8_old.view(torch.uint8)), f"{name}: fp8 store variants differ"
+    for kk in knobs:
+        monkeypatch.delenv(kk, raising=False)
+    for name, _ in variants[1:]:
         dd = (outs["deferred"].float() - outs[name].float()).abs().max().item()
         assert dd <= 2e-2 * v.abs().max().item(), f"deferred vs {name}: {dd:.3e}"
-    assert torch.equal(outs["deferred"], outs["shallow_prefetch"]), "a schedule variant must not change bits"
+    # schedule-only variants must not change bits
+    assert torch.equal(outs["deferred"], outs["prologue"]) and torch.equal(outs["deferred"], outs["setprio"])
+    assert torch.equal(outs["fold"], outs["fold_prologue"]) and torch.equal(outs["fold_exact"], outs["fold_exact_prologue"])
     same = (outs["deferred"] == outs["exact"]).float().mean().item()
-    print(f"L={L}: max |err| vs fp64 deferred {(outs['deferred'].double() - ref).abs().max().item():.2e} / exact "
-          f"{(outs['exact'].double() - ref).abs().max().item():.2e} / round-1 {(outs['round1'].double() - ref).abs().max().item():.2e}; "
-          f"deferred == exact on {same:.4f} of the outputs")
+    same_f = (outs["deferred"] == outs["fold"]).float().mean().item()
+    e = lambda n: (outs[n].double() - ref).abs().max().item()
+    r = lambda n: ((outs[n].double() - ref).norm() / ref.norm()).item()
+    print(f"L={L}: max |err| vs fp64 deferred {e('deferred'):.2e} / exact {e('exact'):.2e} / fold {e('fold'):.2e} / fold_exact {e('fold_exact'):.2e} / "
+          f"round-1 {e('round1'):.2e}; rel-L2 deferred {r('deferred'):.3e} fold {r('fold'):.3e} round-1 {r('round1'):.3e}; "
+          f"deferred == exact on {same:.4f}, == fold on {same_f:.4f} of the outputs")
 
 
 @pytest.mark.parametrize("L,Lt", [(320, 64), (200, 40)])

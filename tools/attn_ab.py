@@ -1,5 +1,6 @@
 """Interleaved A/B of the attention kernels in ONE process (guide rule 24): round-1 kernel (FLUXMI_ATTN_V=1) vs the round-2 pipeline and
-its variants (FLUXMI_ATTN_VAR bit 0 = shallow V-fragment prefetch, bit 1 = exact running max, bit 2 = row sums by an all-ones MFMA), Flux-dev shapes, random data.
+its variants (FLUXMI_ATTN_VAR bit 0 = scale + running max folded into the QK^T MFMAs, bit 1 = exact running max, bit 2 = Q arithmetic under the
+prologue DMA; FLUXMI_ATTN_ABL 4 = s_setprio 1 for the younger half, 8 = round-1 fp8 stores, 2 = no barrier [timing only]), Flux-dev shapes, random data.
     python tools/attn_ab.py [--rounds 5] [--iters 20] [--L 4608 2816]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,12 +13,14 @@ ap.add_argument("--L", type=int, nargs="+", default=[4608, 2816, 8192]); ap.add_
 ap.add_argument("--rounds", type=int, default=5)
 a = ap.parse_args()
 dev = torch.device("cuda:0"); torch.manual_seed(0)
-VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}), ("r2 (V 4 ahead)", {}), ("r2 V 2 ahead", {"FLUXMI_ATTN_VAR": "1"}), ("r2 rowsum-by-MFMA", {"FLUXMI_ATTN_VAR": "4"}),
-            ("r2 exact-max", {"FLUXMI_ATTN_VAR": "2"})]
+VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}), ("r2 base + old stores", {"FLUXMI_ATTN_ABL": "8"}), ("r2 base", {}), ("r2 fold", {"FLUXMI_ATTN_VAR": "1"}),
+            ("r2 prologue", {"FLUXMI_ATTN_VAR": "4"}), ("r2 fold+prologue", {"FLUXMI_ATTN_VAR": "5"}),
+            ("r2 fold+prol+setprio", {"FLUXMI_ATTN_VAR": "5", "FLUXMI_ATTN_ABL": "4"}), ("r2 fold+prol nobarrier*", {"FLUXMI_ATTN_VAR": "5", "FLUXMI_ATTN_ABL": "2"}),
+            ("r2 fold exact-max", {"FLUXMI_ATTN_VAR": "3"})]
 
 
 def setenv(env):
-    for k in ("FLUXMI_ATTN_V", "FLUXMI_ATTN_VAR"):
+    for k in ("FLUXMI_ATTN_V", "FLUXMI_ATTN_VAR", "FLUXMI_ATTN_ABL"):
         os.environ.pop(k, None)
     os.environ.update(env)
 
@@ -45,4 +48,4 @@ for L in a.L:
     fl = 4 * L * L * 128 * H * B
     for n, _ in VARIANTS:
         ts = sorted(res[n]); t = ts[len(ts) // 2]
-        print(f"L={L:5d} {n:20s}: median {fl / t / 1e12:7.1f} TF/s ({t * 1e6:6.1f} us)  best {fl / ts[0] / 1e12:7.1f}  frac of 2.5 PF {fl / t / 2.5e15:.3f}", flush=True)
+        print(f"L={L:5d} {n:24s}: median {fl / t / 1e12:7.1f} TF/s ({t * 1e6:6.1f} us)  best {fl / ts[0] / 1e12:7.1f}  frac of 2.5 PF {fl / t / 2.5e15:.3f}", flush=True)
