@@ -114,25 +114,8 @@ int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs_in, int n_in, int N, int K, i
     if (best_k > 0) {
       std::vector<FluxmiGemmGroup> big, small;
       for (size_t q = 0; q < gs.size(); ++q) (q < (size_t)best_k ? small : big).push_back(gs[order[q]]);
-      if (hybrid >= 2) {
-        // FLUXMI_GEMM_HYBRID=2: the thin 128x128 launch runs on a side stream BESIDE the 256x256 launch (fork / join through events,
-        // which hipGraph capture records as edges): its workgroups fill the CUs the last round of the big grid leaves idle instead of
-        // running after it.  The two launches write disjoint rows.
-        static thread_local hipStream_t side = nullptr;
-        static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-        if (!side) {
-          FLUXMI_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-          FLUXMI_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-          FLUXMI_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        }
-        FLUXMI_CHECK_HIP(hipEventRecord(ev_fork, s));
-        FLUXMI_CHECK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-        FLUXMI_TRY(run_gemm_chunk(small.data(), (int)small.size(), N, K, is_fp8, act_fmt, epi, 2, side));
-        FLUXMI_CHECK_HIP(hipEventRecord(ev_join, side));
-        FLUXMI_TRY(run_gemm_chunk(big.data(), (int)big.size(), N, K, is_fp8, act_fmt, epi, -1, s));
-        FLUXMI_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
-        return 0;
-      }
+      // (running the thin launch on a side stream BESIDE the big one, fork / join through events, was measured slower: 45.47 vs
+      // 45.13 ms per step, profiles/r02_gemm_ab.txt -- its workgroups take CUs from the big grid's first rounds, not its last)
       FLUXMI_TRY(run_gemm_chunk(big.data(), (int)big.size(), N, K, is_fp8, act_fmt, epi, -1, s));
       return run_gemm_chunk(small.data(), (int)small.size(), N, K, is_fp8, act_fmt, epi, 2, s);
     }
@@ -244,12 +227,13 @@ int fluxmi_rope_table(const void* ids, const float* omega, const int* axis, void
   return fluxmi_k_rope_table(ids, omega, axis, pe, rows, n_axes, pairs, (hipStream_t)stream);
 }
 int fluxmi_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0, const void* q_scale1,
-                    const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H, int split, void* stream) {
-  return fluxmi_k_qkv_rope(qkv, ld, pe, q_scale0, k_scale0, q_scale1, k_scale1, Q, K, VT, B, L, Lp, H, split, (hipStream_t)stream);
+                    const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H, int split, int k_f16, void* stream) {
+  return fluxmi_k_qkv_rope(qkv, ld, pe, q_scale0, k_scale0, q_scale1, k_scale1, Q, K, VT, B, L, Lp, H, split, k_f16, (hipStream_t)stream);
 }
 int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
-                     const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream) {
-  return fluxmi_k_attention(Q, K, VT, out, ld_out, col_off, out_fp8, q_scale0, q_scale1, split, B, L, Lp, H, fmt, (hipStream_t)stream);
+                     const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, int k_f16, void* stream) {
+  return fluxmi_k_attention(Q, K, VT, out, ld_out, col_off, out_fp8, q_scale0, q_scale1, split, B, L, Lp, H, fmt, (hipStream_t)stream,
+                            nullptr, 0, nullptr, nullptr, nullptr, k_f16);
 }
 int fluxmi_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int upsample, void* stream) {
   return fluxmi_k_im2col3x3(x, col, B, H, W, C, upsample, (hipStream_t)stream);
@@ -277,9 +261,9 @@ int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void
 }
 int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, const void* qn_scale0, const void* qn_scale1, const void* K,
                           const void* VT, void* out, long long ld_out, int col_off, int out_fp8, const float* q_scale0,
-                          const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream) {
+                          const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, int k_f16, void* stream) {
   return fluxmi_k_attention(nullptr, K, VT, out, ld_out, col_off, out_fp8, q_scale0, q_scale1, split, B, L, Lp, H, fmt, (hipStream_t)stream,
-                            qkv, ld_qkv, pe, qn_scale0, qn_scale1);
+                            qkv, ld_qkv, pe, qn_scale0, qn_scale1, k_f16);
 }
 int fluxmi_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, void* stream) {
   return fluxmi_k_timestep_embedding(t, freqs, out, B, half, time_factor, (hipStream_t)stream);

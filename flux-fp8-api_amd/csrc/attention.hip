@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(NW * 64, 2) attention_kernel(const AttnArgs a)
 
 int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
                        const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt,
-                       hipStream_t s, const void* qraw, long long ldq, const void* pe, const void* qn0, const void* qn1) {
+                       hipStream_t s, const void* qraw, long long ldq, const void* pe, const void* qn0, const void* qn1, int k_f16) {
   FLUXMI_REQUIRE(Q || (qraw && pe && qn0 && qn1 && ldq % 8 == 0), "attention: need Q, or raw q + pe + both q-norm scales (ld %% 8 == 0)");
   FLUXMI_REQUIRE(Lp % 64 == 0 && Lp >= L, "attention: Lp=%d must be a multiple of 64 and >= L=%d", Lp, L);
   FLUXMI_REQUIRE(!out_fp8 || (q_scale0 && q_scale1), "attention: fp8 output needs q_scale pointers");
@@ -279,6 +279,7 @@ int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, 
   a.q_scale[0] = q_scale0; a.q_scale[1] = q_scale1; a.split = split;
   a.B = B; a.L = L; a.Lp = Lp; a.H = H;
   a.scale_log2 = 0.08838834764831845f * 1.4426950408889634f;  // 128^-0.5 * log2(e)
+  a.k_f16 = k_f16;
   {
     const char* e = getenv("FLUXMI_ATTN_ABL");  // read per call (A/B probes flip it inside one process)
     a.abl = e ? atoi(e) : 0;
@@ -291,6 +292,7 @@ int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, 
     const char* e = getenv("FLUXMI_ATTN_V");  // read per call (the tests compare the two kernels in one process)
     if (!(e && atoi(e) == 1)) return fluxmi_launch_attention2(a, fmt, s);
   }
+  FLUXMI_REQUIRE(!k_f16, "attention: the round-1 kernel (FLUXMI_ATTN_V=1) takes bf16 K only");
   // 8-wave workgroups (256 query rows, K/V tiles shared by twice as many rows) by default; FLUXMI_ATTN_NW=4 selects the 4-wave
   // kernel with two workgroups per CU
   static int nw = 0;

@@ -18,10 +18,13 @@
 //      the rescale leaves the steady state;
 //   3. keeps four independent row-sum accumulators (no dependent chain) and scalar f32 VALU ops (packed f32 VALU beside MFMAs is
 //      an anti-lever on CDNA4, MI355X_MICROARCH.md).
-//   4. (VAR bit 0) folds the softmax scale and the running max into the MATRIX pipe: Q is pre-multiplied by scale*log2(e) while its
-//      fragments are built, and the first MFMA of every S accumulator starts from C = -M (M = the deferred running max, one 16-register
-//      block per lane, rewritten only in the rescale branch), so S arrives as s - M and the per-score fma disappears: exp2, row-sum
-//      add, half a cvt_pk and half a max3 per MFMA gap.  The rescale decision becomes `row max of the shifted tile > 2^8`.
+//   4. (FOLD, when K arrives as fp16: AttnArgs.k_f16) folds the softmax scale and the running max into the MATRIX pipe: Q is
+//      multiplied by scale*log2(e) while its fragments are built and kept as fp16 (2^-11 relative rounding on the scaled values; the
+//      same fold in bf16 puts 2^-8 on every score and doubled the attention error against the oracle, profiles/r02_attention_ab.txt),
+//      QK^T runs on the f16 MFMA (same rate; K's bf16 values are exact in fp16), and the first MFMA of every S accumulator starts
+//      from C = -M (M = the deferred running max, one 16-register block per lane, rewritten only in the rescale branch), so S arrives
+//      as s - M and the per-score fma disappears: exp2, row-sum add, half a cvt_pk and half a max3 per MFMA gap.  The rescale
+//      decision becomes `row max of the shifted tile > 2^8`.
 // Correctness of the deferred rescale with a pending tile: when the branch fires with f = 2^((m_old - m_new) c), everything still at
 // the old max is scaled exactly once -- O (tiles <= j-2), l (tiles <= j-1) and the bf16 fragments of P_{j-1} (re-rounded) -- and
 // P_j is exponentiated after the decision.  tests/test_ops_gpu.py forces the branch (spiked key rows) and sweeps THR.
@@ -44,13 +47,14 @@ __device__ __forceinline__ void fence() {
 constexpr int NW2 = 8, RD2 = 4, LPW2 = 16 / NW2;
 constexpr int VRING2 = RD2 * K_BYTES;
 constexpr float DEFER_LOG2 = 8.0f;  // rescale only when a row max grew by more than 2^8 (in the exp2 domain)
-// VAR bit 1 (A/B + the THR sweep of the tests): exact max tracking, i.e. rescale whenever any row max grows
-
-// VAR bit 0: scale + running max folded into the QK^T MFMAs, bit 1: exact max, bit 2: Q arithmetic under the K/V prologue DMA.
+// EXACT (tests + A/B): exact max tracking, i.e. rescale whenever any row max grows.
 // Measured and dropped in round 2 (profiles/r02_attention_ab.txt): refills in the PV half (-0.4 %), softmax work skewed by one gap so that
 // nothing inside a gap depends on anything in it (-4 %: +17 register moves), row sums by an all-ones MFMA (-4 %), V fragments 2 instead of
-// 4 MFMAs ahead (-0.5 %)
-template <int FMT, int VAR>
+// 4 MFMAs ahead (-0.5 %), Q arithmetic under the prologue DMA (-0.7 %), s_setprio 1 for the younger half (-0.3 %), no barrier at all
+// (+0.4 ... 1.8 %, timing only: the barrier is not what the waves wait for)
+// LAG (A/B, FLUXMI_ATTN_VAR bit 0): the consumers of a score's exp2 -- row-sum add, cvt_pk of the pair -- run one gap later, so no
+// instruction of a gap reads the v_exp_f32 result of the same gap (no trans-use wait states, no dependent chain inside the gap)
+template <int FMT, bool FOLD, bool EXACT, bool LAG>
 __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs a) {
   constexpr int QB = NW2 * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -66,11 +70,14 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   const int qld = min(qrow, a.L - 1);
   const long long bh = (long long)b * a.H + h;
 
-  constexpr bool FOLD = (VAR & 1) != 0;
   const float c = a.scale_log2;
-  v8bf qf[8];
-  if constexpr (!(VAR & 4)) load_q_frags(a, b, h, qld, hi, FOLD ? c : 1.0f, qf, [] {});
-  if ((a.abl & 4) && wave >= NW2 / 2) __builtin_amdgcn_s_setprio(1);
+  v8bf qf[8];  // FOLD: eight fp16 per fragment in the same registers
+  load_q_frags<FOLD>(a, b, h, qld, hi, c, qf);
+  // S^T tile += K fragment . Q fragment (f16 MFMA for the folded kernel)
+  auto mfma_qk = [](v8bf kfr, v8bf qfr, v16f acc) -> v16f {
+    if constexpr (FOLD) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, kfr), __builtin_bit_cast(v8h, qfr), acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qfr, acc, 0, 0, 0);
+  };
 
   const auto krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.K + bh * a.L * 128), 0, a.L * 256, 0x00020000);
   const auto vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.VT + bh * 128 * a.Lp), 0, 128 * a.Lp * 2, 0x00020000);
@@ -132,15 +139,11 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   // the next V^T row into a ring slot nobody reads any more, so the vmcnt arithmetic is the same in every step and the step body
   // has no branch (a wave-uniform branch per refill split the step into basic blocks and let MachineSink drag the pinned VALU
   // work out of its MFMA gaps).
-  auto prologue_dma = [&] {
+  {
     auto iss_k = [&](int t) { dma_k(t, t * KT, 0); dma_k(t, t * KT, 1); };
     auto iss_v = [&](int t) { dma_v(t, t * KT, 0); dma_v(t, t * KT, 1); };
     iss_k(0); iss_k(1); iss_v(0); iss_k(2); iss_v(1); iss_k(3);
-  };
-  // VAR & 4: the Q loads are issued first and are OLDER than the twelve DMA pieces, so the wait hipcc puts in front of the QKNorm / RoPE
-  // arithmetic is vmcnt(12) and that arithmetic runs under the DMA latency
-  if constexpr ((VAR & 4) != 0) load_q_frags(a, b, h, qld, hi, FOLD ? c : 1.0f, qf, prologue_dma);
-  else prologue_dma();
+  }
   wait_vm<5 * LPW2>();
   __builtin_amdgcn_s_barrier();
   v16f sa[2], sb[2];
@@ -156,8 +159,8 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       for (int r = 0; r < 16; ++r) sa[t][r] = 0.f;
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) {
-      sa[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_frag(0, cc, 0), qf[cc], sa[0], 0, 0, 0);
-      sa[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_frag(0, cc, 1), qf[cc], sa[1], 0, 0, 0);
+      sa[0] = mfma_qk(k_frag(0, cc, 0), qf[cc], sa[0]);
+      sa[1] = mfma_qk(k_frag(0, cc, 1), qf[cc], sa[1]);
     }
   }
   if (ragged && ntiles == 1) mask_tile(sa, 0);
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     float nmc = 0.f;
     if constexpr (FOLD) {
       // mx = row max of S_j - M.  Rows that grew are moved to their new max (delta = max(mx, 0)); S_j itself was produced with the old M
-      if (__any(mx > ((VAR & 2) ? 0.0f : DEFER_LOG2))) {
+      if (__any(mx > (EXACT ? 0.0f : DEFER_LOG2))) {
         const float delta = fmaxf(mx, 0.f);
         rescale_state(__builtin_amdgcn_exp2f(-delta));
 #pragma unroll
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       }
     } else {
       const float m_new = fmaxf(m_run, mx);
-      if (__any((m_new - m_run) * c > ((VAR & 2) ? 0.0f : DEFER_LOG2))) {
+      if (__any((m_new - m_run) * c > (EXACT ? 0.0f : DEFER_LOG2))) {
         rescale_state(__builtin_amdgcn_exp2f((m_run - m_new) * c));
         m_run = m_new;
       }
@@ -244,20 +247,48 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       float sc = cur[t][r];
       asm volatile("" : "+v"(sc));
       float p = FOLD ? __builtin_amdgcn_exp2f(sc) : __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c, nmc));
-      float ls = l4[e & 3] + p;
-      if constexpr (e & 1) {
-        constexpr int f = t * 2 + (r >> 3), q = (r & 7) >> 1;
-        // one v_cvt_pk_bf16_f32 for the pair (through pack_bf2 hipcc converts each half separately and ORs them: 4 instructions).
-        // The s_nop is the trans-op -> VALU wait state hipcc would pad itself (p comes straight from v_exp_f32).
-        int w;
-        asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[t][r - 1]), "v"(p));
-        asm volatile("" : "+v"(p), "+v"(ls));
-        pc[f][q] = w;
+      if constexpr (LAG) {
+        if constexpr (e >= 1) {
+          constexpr int pe = e - 1, pt = pe >> 4, pr = pe & 15;
+          const float pv = cur[pt][pr];  // P value of the previous gap
+          float ls = l4[pe & 3] + pv;
+          if constexpr (pe & 1) {
+            constexpr int f = pt * 2 + (pr >> 3), q = (pr & 7) >> 1;
+            int w;
+            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[pt][pr - 1]), "v"(pv));
+            pc[f][q] = w;
+          }
+          asm volatile("" : "+v"(ls));
+          l4[pe & 3] = ls;
+        }
+        asm volatile("" : "+v"(p));
+        cur[t][r] = p;
       } else {
-        asm volatile("" : "+v"(p), "+v"(ls));
+        float ls = l4[e & 3] + p;
+        if constexpr (e & 1) {
+          constexpr int f = t * 2 + (r >> 3), q = (r & 7) >> 1;
+          // one v_cvt_pk_bf16_f32 for the pair (through pack_bf2 hipcc converts each half separately and ORs them: 4 instructions).
+          // The s_nop is the trans-op -> VALU wait state hipcc would pad itself (p comes straight from v_exp_f32).
+          int w;
+          asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[t][r - 1]), "v"(p));
+          asm volatile("" : "+v"(p), "+v"(ls));
+          pc[f][q] = w;
+        } else {
+          asm volatile("" : "+v"(p), "+v"(ls));
+        }
+        cur[t][r] = p;
+        l4[e & 3] = ls;
       }
-      cur[t][r] = p;
-      l4[e & 3] = ls;
+    };
+    // LAG: the last score's consumers, after the last gap of the step
+    auto soft_tail = [&] {
+      if constexpr (LAG) {
+        const float pv = cur[1][15];
+        l4[3] += pv;
+        int w;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[1][14]), "v"(pv));
+        pc[3][3] = w;
+      }
     };
     auto gapwork = [&](auto GC) { soft(GC); };
     // -- B: S_{j+1} = K_{j+1} Q^T, two alternating accumulators; K fragments two chunks ahead; one score of P_j per gap
@@ -277,7 +308,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       fence();
       static_for<16>([&](auto SC) {
         constexpr int s = decltype(SC)::value, cc = s >> 1, t = s & 1;
-        nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[cc % 3][t], qf[cc], nxt[t], 0, 0, 0);
+        nxt[t] = mfma_qk(kf[cc % 3][t], qf[cc], nxt[t]);
         fence();
         if constexpr (cc + 2 < 8) kf[(cc + 2) % 3][t] = k_frag(KS, cc + 2, t);
         gapwork(std::integral_constant<int, s>{});
@@ -322,6 +353,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         rmax(SC);
       });
     }
+    soft_tail();
     mx = finish_max(m0);
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -362,31 +394,30 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
 
 }  // namespace
 
-template <int VAR> static int launch2(const AttnArgs& a, int fmt, hipStream_t s) {
+template <bool FOLD, bool EXACT, bool LAG> static int launch2(const AttnArgs& a, int fmt, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E5M2, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
-    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E4M3, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, LAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, LAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
     attr = true;
   }
   const dim3 grid(((a.L + 255) / 256) * a.H * a.B);
-  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, VAR>), grid, dim3(512), 4 * A_STAGE, s, a);
-  else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, VAR>), grid, dim3(512), 4 * A_STAGE, s, a);
+  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, LAG>), grid, dim3(512), 4 * A_STAGE, s, a);
+  else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, LAG>), grid, dim3(512), 4 * A_STAGE, s, a);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }
 
-// FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 0 = scale and running max folded into the QK^T MFMAs, bit 1 = exact (undeferred)
-// running max, bit 2 = Q arithmetic under the prologue DMA
+// The kernel follows the K operand: fp16 K (AttnArgs.k_f16, produced by fluxmi_qkv_rope(k_f16 = 1)) -> folded kernel, bf16 K -> the
+// unfolded one.  FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 1 = exact instead of deferred max tracking, bit 0 = lagged
+// softmax consumers (folded kernel only).
 int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s) {
   const char* e = getenv("FLUXMI_ATTN_VAR");
-  switch (e ? atoi(e) & 7 : 0) {
-    case 1: return launch2<1>(a, fmt, s);
-    case 2: return launch2<2>(a, fmt, s);
-    case 3: return launch2<3>(a, fmt, s);
-    case 4: return launch2<4>(a, fmt, s);
-    case 5: return launch2<5>(a, fmt, s);
-    case 7: return launch2<7>(a, fmt, s);
-    default: return launch2<0>(a, fmt, s);
+  const int var = e ? atoi(e) : 0;
+  const bool exact = (var & 2) != 0, lag = (var & 1) != 0;
+  if (a.k_f16) {
+    if (lag) return exact ? launch2<true, true, true>(a, fmt, s) : launch2<true, false, true>(a, fmt, s);
+    return exact ? launch2<true, true, false>(a, fmt, s) : launch2<true, false, false>(a, fmt, s);
   }
+  return exact ? launch2<false, true, false>(a, fmt, s) : launch2<false, false, false>(a, fmt, s);
 }

@@ -16,8 +16,9 @@ struct AttnArgs {
   const float* q_scale[2]; int split;
   int B, L, Lp, H;
   float scale_log2;
+  int k_f16;  // K holds fp16: the folded kernel (scale * log2 e in Q, -max in the accumulator init), f16 MFMAs for QK^T
   int abl;  // A/B knobs (FLUXMI_ATTN_ABL, read per call): 1 = no LDS-DMA in the tile loop (round-1 kernel), 2 = no barrier (both timing-only),
-            // 4 = s_setprio 1 for the younger half of the workgroup, 8 = round-1 fp8 store (16 x 4 B per lane)
+            // 8 = round-1 fp8 store (16 x 4 B per lane)
 };
 
 namespace {
@@ -43,27 +44,25 @@ constexpr int A_STAGE = K_BYTES + V_BYTES;
 // Q fragments (MFMA B operand): 8 x (8 bf16); lane (l31, hi) holds d = c*16 + hi*8 + [0,8) of query row `qld` of (b, h).
 // raw-Q mode (a.Q == nullptr): the row comes straight from the qkv GEMM output and QKNorm + RoPE are applied here
 // (flux_model.py:158-176,60-65), so the normalised / rotated Q tensor never exists in HBM.
-// `between()` runs after the global loads have been ISSUED and before their results are used: a kernel puts its K/V LDS-DMA prologue
-// there (vmcnt is in-order, so the wait for the older Q loads leaves the DMA pieces in flight and the norm / RoPE arithmetic runs
-// under their latency).  `fold` != 1: the fragments are multiplied by it (softmax scale * log2 e folded into Q, attention2.hip)
-// and rounded to bf16 again.
-template <class F>
-__device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, int qld, int hi, float fold, v8bf (&qf)[8], F&& between) {
+// F16: the fragments are multiplied by `fold` (softmax scale * log2 e, attention2.hip) and stored as fp16 -- the bf16 Q values times
+// the scale carry 2^-11 relative rounding error in fp16 (a bf16 re-rounding would put 2^-8 on every score; measured: it doubles the
+// attention error against the oracle) -- and are bit-cast into the v8bf slots.
+template <bool F16>
+__device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, int qld, int hi, float fold, v8bf (&qf)[8]) {
   const long long bh = (long long)b * a.H + h;
   if (a.Q) {
     const u16* qp = a.Q + (bh * a.L + qld) * 128 + hi * 8;
     uint4 raw[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) raw[c] = *(const uint4*)(qp + c * 16);
-    between();
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      if (fold != 1.0f) {
+      if (F16) {
         float y[8];
         unpack8(raw[c], y);
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] *= fold;
-        raw[c] = pack8(y);
+        raw[c] = pack8_f16(y);
       }
       qf[c] = __builtin_bit_cast(v8bf, raw[c]);
     }
@@ -79,7 +78,6 @@ __device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, in
       rw[c] = *(const uint4*)(wn + c * 16);
       rcs[c] = *(const uint4*)(pp + c * 16);
     }
-    between();
     float x[8][8];
     float ss = 0.f;
 #pragma unroll
@@ -107,17 +105,17 @@ __device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, in
         y[2 * p] = rbf(rbf(cc * x[c][2 * p]) + rbf((-sn) * x[c][2 * p + 1]));
         y[2 * p + 1] = rbf(rbf(sn * x[c][2 * p]) + rbf(cc * x[c][2 * p + 1]));
       }
-      if (fold != 1.0f) {
+      if (F16) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] *= fold;
       }
-      const uint4 pk = pack8(y);
+      const uint4 pk = F16 ? pack8_f16(y) : pack8(y);
       qf[c] = __builtin_bit_cast(v8bf, pk);
     }
   }
 }
 __device__ __forceinline__ void load_q_frags(const AttnArgs& a, int b, int h, int qld, int hi, v8bf (&qf)[8]) {
-  load_q_frags(a, b, h, qld, hi, 1.0f, qf, [] {});
+  load_q_frags<false>(a, b, h, qld, hi, 1.0f, qf);
 }
 
 // normalise the O^T accumulators by the row sum and store one query row per lane (bf16, or fp8 with the consumer's input scale)

@@ -49,6 +49,20 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return v;
 }
 
+// eight floats -> eight fp16 (RNE), packed like pack8
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_h2(float lo, float hi) {
+  const v2f_pk_t x = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2_t));
+}
+__device__ __forceinline__ uint4 pack8_f16(const float* f) {
+  uint4 v;
+  v.x = pack_h2(f[0], f[1]); v.y = pack_h2(f[2], f[3]);
+  v.z = pack_h2(f[4], f[5]); v.w = pack_h2(f[6], f[7]);
+  return v;
+}
+
 // ---- fp8 (OCP) conversion --------------------------------------------------------------------
 // float8_quantize.py:217-218 then `.to(fp8)`:  t = bf16(x * scale); clamp(t, +-max); RNE cast.
 // The clamp guarantees the hardware convert never sees an out-of-range value.

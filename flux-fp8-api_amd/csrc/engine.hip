@@ -105,6 +105,15 @@ int fuse_kv_level() {
   return lvl;
 }
 
+// FLUXMI_ATTN_F16K (default 1): the K relayout stores fp16 and the attention kernel runs its folded schedule (softmax scale in Q,
+// running max in the accumulator init; include/fluxmi.h, fluxmi_attention).  0 = bf16 K, unfolded kernel.  The fused-K GEMM epilogue
+// (FLUXMI_FUSE_KV=2) writes bf16 K and therefore switches it off.
+int attn_f16k() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("FLUXMI_ATTN_F16K"); v = (e ? atoi(e) : 1) && fuse_kv_level() < 2; }
+  return v;
+}
+
 int lin_count(const fluxmi_model_desc_t& d) { return 6 + (d.guidance_embed ? 2 : 0) + d.depth * 10 + d.depth_single * 3 + 2; }
 
 // double-block linear slots / single-block linear slots
@@ -481,14 +490,14 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
       }
       // K and V^T are relaid out once (every query block re-reads them); Q is normalised + rotated inside the attention kernel
       if (on(2) && !fuse_k)
-        FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, Lt, s));
+        FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, Lt, attn_f16k(), s));
       if (on(3)) {
         if (fused) {
           FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attn8, H, 0, 1, e->lin[li_p[0]].in_scale, e->lin[li_p[1]].in_scale, Lt, B, L, e->Lp,
-                                        heads, e->lin[li_p[0]].in_fmt, s, qkv, 3 * H, pe, ns[2], ns[0]));
+                                        heads, e->lin[li_p[0]].in_fmt, s, qkv, 3 * H, pe, ns[2], ns[0], attn_f16k()));
         } else {
           FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attnbf, H, 0, 0, nullptr, nullptr, Lt, B, L, e->Lp, heads, 0, s, qkv, 3 * H, pe,
-                                        ns[2], ns[0]));
+                                        ns[2], ns[0], attn_f16k()));
           for (int st = 0; st < 2; ++st)
             FLUXMI_TRY(stage_input(e, li_p[st], calib, trial, attnbf + (long long)roff[st] * H, H, XB, attn8 + (long long)roff[st] * H, H,
                                    XB, B, rows[st], H, s));
@@ -582,10 +591,10 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
       FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, 1, L2.in_fmt, FLUXMI_EPI_SPLIT, s));
     }
     if (on(2) && !fuse_k)
-      FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, L, s));
+      FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, L, attn_f16k(), s));
     if (on(3))
       FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s, qkv,
-                                    3 * H, pe, ns[0], ns[0]));
+                                    3 * H, pe, ns[0], ns[0], attn_f16k()));
   } else {
     if (on(0)) {
       FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, ms, ms + H, ms, ms + H, MC, nullptr, nullptr, B, L, L, H, 0, 0, s));
@@ -596,10 +605,10 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
       gs.push_back(mk_group(L1, L1.kind ? (const void*)a8 : (const void*)abf, H, lin1, 3 * H + Hm, B * L));
       FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, L1.kind, L1.in_fmt, FLUXMI_EPI_BF16, s));
     }
-    if (on(2)) FLUXMI_TRY(fluxmi_k_qkv_rope(lin1, 3 * H + Hm, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, L, s));
+    if (on(2)) FLUXMI_TRY(fluxmi_k_qkv_rope(lin1, 3 * H + Hm, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, L, attn_f16k(), s));
     if (on(3)) {
       FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, catbf, HC, 0, 0, nullptr, nullptr, L, B, L, e->Lp, heads, 0, s, lin1, 3 * H + Hm, pe,
-                                    ns[0], ns[0]));
+                                    ns[0], ns[0], attn_f16k()));
       FLUXMI_TRY(fluxmi_k_act(lin1 + 3 * H, catbf + H, B * L, Hm, 3 * H + Hm, HC, 0, s));
       FLUXMI_TRY(stage_input(e, l2, calib, trial, catbf, HC, 0, cat8, HC, 0, 1, B * L, HC, s));
     }

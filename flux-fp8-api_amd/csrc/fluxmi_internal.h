@@ -105,8 +105,8 @@ int fluxmi_k_text_attention(const void* q, const void* k, long long ld_qk, const
                             const float* rel_bias, int bias_ld, const void* v_bias, float scale, int causal, int L, int Lp, int H, hipStream_t s);
 int fluxmi_k_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0,
                       const void* q_scale1, const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H,
-                      int split, hipStream_t s);
+                      int split, int k_f16, hipStream_t s);
 int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
                        const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, hipStream_t s,
                        const void* qraw = nullptr, long long ldq = 0, const void* pe = nullptr, const void* qn0 = nullptr,
-                       const void* qn1 = nullptr);
+                       const void* qn1 = nullptr, int k_f16 = 0);

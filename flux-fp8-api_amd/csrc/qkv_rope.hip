@@ -20,6 +20,7 @@ struct QkvRopeArgs {
   const u16* qs[2]; const u16* ks[2];    // RMSNorm scales [128] per stream
   u16* Q; u16* K; u16* VT;
   int B, L, Lp, H, split;
+  int k_f16;  // K is stored as fp16 (exact for bf16 values in fp16's range): operand format of the folded QK^T of attention2.hip
 };
 
 __global__ void __launch_bounds__(256) qkv_rope_kernel(const QkvRopeArgs a) {
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(256) qkv_rope_kernel(const QkvRopeArgs a) {
       }
       if (ok) {
         u16* dst = (part == 0 ? a.Q : a.K) + (((long long)b * a.H + h) * a.L + l) * 128 + sub * 8;
-        *(uint4*)dst = pack8(y);
+        *(uint4*)dst = (part == 1 && a.k_f16) ? pack8_f16(y) : pack8(y);
       }
     }
     if (a.VT) {
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) qkv_rope_kernel(const QkvRopeArgs a) {
 
 int fluxmi_k_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0,
                       const void* q_scale1, const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H,
-                      int split, hipStream_t s) {
+                      int split, int k_f16, hipStream_t s) {
   FLUXMI_REQUIRE(Lp % 64 == 0 && Lp >= L, "qkv_rope: Lp=%d must be a multiple of 64 and >= L=%d", Lp, L);
   FLUXMI_REQUIRE(ld % 8 == 0, "qkv_rope: ld must be a multiple of 8");
   if (B * L * H == 0) return 0;
@@ -105,7 +106,7 @@ int fluxmi_k_qkv_rope(const void* qkv, long long ld, const void* pe, const void*
   a.qs[0] = (const u16*)q_scale0; a.ks[0] = (const u16*)k_scale0;
   a.qs[1] = (const u16*)q_scale1; a.ks[1] = (const u16*)k_scale1;
   a.Q = (u16*)Q; a.K = (u16*)K; a.VT = (u16*)VT;
-  a.B = B; a.L = L; a.Lp = Lp; a.H = H; a.split = split;
+  a.B = B; a.L = L; a.Lp = Lp; a.H = H; a.split = split; a.k_f16 = k_f16;
   hipLaunchKernelGGL(qkv_rope_kernel, dim3((L + 63) / 64, H, B), dim3(256), 0, s, a);
   FLUXMI_LAUNCH_CHECK();
   return 0;

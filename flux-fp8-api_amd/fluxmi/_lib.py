@@ -68,7 +68,7 @@ _SIGS = {
     "fluxmi_gate_residual": ([vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp], i32),
     "fluxmi_add": ([vp, vp, vp, i64, vp], i32),
     "fluxmi_rope_table": ([vp, vp, vp, vp, i64, i32, i32, vp], i32),
-    "fluxmi_qkv_rope": ([vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "fluxmi_qkv_rope": ([vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_build_quant_lut": ([vp, i32, i32, vp, vp], i32),
     "fluxmi_im2col3x3": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_groupnorm": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp], i32),
@@ -76,8 +76,8 @@ _SIGS = {
     "fluxmi_row_norm": ([vp, vp, vp, vp, i32, i32, i64, i64, C.c_float, i32, vp], i32),
     "fluxmi_act_mul": ([vp, vp, i32, i32, i64, i64, i32, vp], i32),
     "fluxmi_text_attention": ([vp, vp, i64, vp, i64, vp, i64, vp, i32, vp, C.c_float, i32, i32, i32, i32, vp], i32),
-    "fluxmi_attention": ([vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
-    "fluxmi_attention_rawq": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "fluxmi_attention": ([vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "fluxmi_attention_rawq": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_timestep_embedding": ([vp, vp, vp, i32, i32, f32, vp], i32),
     "fluxmi_euler": ([vp, vp, vp, vp, i64, vp], i32),
     "fluxmi_engine_num_linears": ([C.POINTER(ModelDesc)], i32),
@@ -105,8 +105,8 @@ for _name, (_args, _res) in _SIGS.items():
     _fn.argtypes = _args
     _fn.restype = _res
 
-if lib.fluxmi_abi_version() != 1:
-    raise ImportError(f"fluxmi: ABI version mismatch ({lib.fluxmi_abi_version()} != 1)")
+if lib.fluxmi_abi_version() != 2:
+    raise ImportError(f"fluxmi: ABI version mismatch ({lib.fluxmi_abi_version()} != 2)")
 
 
 def check(rc: int) -> None:

@@ -214,22 +214,24 @@ def rope_table(ids: torch.Tensor, axes_dim, theta) -> torch.Tensor:
     return pe
 
 
-def qkv_rope(qkv, pe, q_scale0, k_scale0, q_scale1=None, k_scale1=None, split=None, heads=None, skip_q=False):
-    """qkv bf16 [B,L,>=3*H*128] -> Q,K [B,H,L,128], VT [B,H,128,Lp].  skip_q: only K and VT (Q is returned as None)."""
+def qkv_rope(qkv, pe, q_scale0, k_scale0, q_scale1=None, k_scale1=None, split=None, heads=None, skip_q=False, k_f16=False):
+    """qkv bf16 [B,L,>=3*H*128] -> Q,K [B,H,L,128], VT [B,H,128,Lp].  skip_q: only K and VT (Q is returned as None).
+    k_f16: K is returned as float16 (the operand format of the attention kernel's folded schedule; pass it on to attention*)."""
     B, L, _ = qkv.shape
     split = L if split is None else split
     q_scale1 = q_scale0 if q_scale1 is None else q_scale1
     k_scale1 = k_scale0 if k_scale1 is None else k_scale1
     Lp = (L + 63) // 64 * 64
-    K = torch.empty((B, heads, L, 128), dtype=torch.bfloat16, device=qkv.device)
-    Q = None if skip_q else torch.empty_like(K)
+    K = torch.empty((B, heads, L, 128), dtype=torch.float16 if k_f16 else torch.bfloat16, device=qkv.device)
+    Q = None if skip_q else torch.empty((B, heads, L, 128), dtype=torch.bfloat16, device=qkv.device)
     VT = torch.empty((B, heads, 128, Lp), dtype=torch.bfloat16, device=qkv.device)
     call("fluxmi_qkv_rope", _p(qkv), qkv.stride(1), _p(pe), _p(q_scale0), _p(k_scale0), _p(q_scale1), _p(k_scale1), _p(Q), _p(K),
-         _p(VT), B, L, Lp, heads, split, _stream())
+         _p(VT), B, L, Lp, heads, split, int(k_f16), _stream())
     return Q, K, VT
 
 
 def attention(Q, K, VT, q_scale0=None, q_scale1=None, split=None, fmt=E5M2, out=None, col_off=0):
+    """K may be bfloat16 or float16 (float16 selects the folded kernel, see include/fluxmi.h)."""
     B, H, L, _ = Q.shape
     Lp = VT.shape[-1]
     split = L if split is None else split
@@ -238,7 +240,7 @@ def attention(Q, K, VT, q_scale0=None, q_scale1=None, split=None, fmt=E5M2, out=
     if out is None:
         out = torch.empty((B, L, H * 128), dtype=dtype_of(fmt) if out_fp8 else torch.bfloat16, device=Q.device)
     call("fluxmi_attention", _p(Q), _p(K), _p(VT), _p(out), out.stride(1), col_off, int(out_fp8), _p(q_scale0), _p(q_scale1), split,
-         B, L, Lp, H, fmt, _stream())
+         B, L, Lp, H, fmt, int(K.dtype == torch.float16), _stream())
     return out
 
 
@@ -253,7 +255,7 @@ def attention_rawq(qkv, pe, qn_scale0, K, VT, qn_scale1=None, q_scale0=None, q_s
     if out is None:
         out = torch.empty((B, L, H * 128), dtype=dtype_of(fmt) if out_fp8 else torch.bfloat16, device=K.device)
     call("fluxmi_attention_rawq", _p(qkv), qkv.stride(1), _p(pe), _p(qn_scale0), _p(qn_scale1), _p(K), _p(VT), _p(out), out.stride(1),
-         col_off, int(out_fp8), _p(q_scale0), _p(q_scale1), split, B, L, Lp, H, fmt, _stream())
+         col_off, int(out_fp8), _p(q_scale0), _p(q_scale1), split, B, L, Lp, H, fmt, int(K.dtype == torch.float16), _stream())
     return out
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FLUXMI_ABI_VERSION 1
+#define FLUXMI_ABI_VERSION 2
 
 /* fp8 format codes (torch.float8_e4m3fn / torch.float8_e5m2, float8_quantize.py:39,43) */
 #define FLUXMI_E4M3 0
@@ -143,20 +143,26 @@ int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void
 /* pe[rows, pairs, (cos,sin)] from position ids                                    flux_model.py:49-57,82-92 */
 int fluxmi_rope_table(const void* ids, const float* omega, const int* axis, void* pe, long long rows, int n_axes, int pairs,
                       void* stream);
-/* qkv split + QKNorm + RoPE + head-major relayout (V transposed); Q may be NULL      flux_model.py:351-354,158-176,60-65,380-382 */
+/* qkv split + QKNorm + RoPE + head-major relayout (V transposed); Q may be NULL      flux_model.py:351-354,158-176,60-65,380-382
+ * k_f16 != 0: K is stored as fp16 instead of bf16 (same bytes per element; the normalised + rotated bf16 values are exact in fp16
+ * unless |k| < 6.1e-5).  That is the operand format of the attention kernel's folded schedule, see fluxmi_attention. */
 int fluxmi_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q_scale0, const void* k_scale0,
                     const void* q_scale1, const void* k_scale1, void* Q, void* K, void* VT, int B, int L, int Lp, int H, int split,
-                    void* stream);
-/* softmax(QK^T/sqrt(128))V -> [B,L,H*128] (bf16, or fp8 with the consumer's input scale)   flux_model.py:41-45 */
+                    int k_f16, void* stream);
+/* softmax(QK^T/sqrt(128))V -> [B,L,H*128] (bf16, or fp8 with the consumer's input scale)   flux_model.py:41-45
+ * k_f16 != 0: K holds fp16 (fluxmi_qkv_rope(k_f16 = 1)).  The kernel then multiplies Q by 128^-0.5 * log2(e) while it builds its
+ * fragments (fp16, 2^-11 relative rounding), runs QK^T on the f16 MFMA and starts every score accumulator from minus the running
+ * maximum, so a score costs one exp2 instead of fma + exp2 (+4.7 % at L = 4608).  Q and V^T are bf16 either way. */
 int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
-                     const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream);
+                     const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, int k_f16,
+                     void* stream);
 
 /* The same with Q taken RAW from the qkv GEMM output (q at column 0 of `qkv`, row stride ld_qkv): QKNorm (qn_scale0 for rows
  * < split, qn_scale1 otherwise) + RoPE (pe) are applied while the query fragments are loaded, so Q never round-trips through HBM.
  * Pair with fluxmi_qkv_rope(..., Q = NULL, ...) which then produces K and V^T only.     flux_model.py:41-45,60-65,158-176 */
 int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, const void* qn_scale0, const void* qn_scale1, const void* K,
                           const void* VT, void* out, long long ld_out, int col_off, int out_fp8, const float* q_scale0,
-                          const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, void* stream);
+                          const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, int k_f16, void* stream);
 
 /* ---- VAE pieces (NHWC bf16) -------------------------------------------------------------------- */
 /* 3x3 patch matrix: x [B, Hi, Wi, C] -> col [B*H*W, 9*C], column (dy*3+dx)*C + c, (H, W) = the OUTPUT grid.  `upsample`:

@@ -1,6 +1,6 @@
-"""Interleaved A/B of the attention kernels in ONE process (guide rule 24): round-1 kernel (FLUXMI_ATTN_V=1) vs the round-2 pipeline and
-its variants (FLUXMI_ATTN_VAR bit 0 = scale + running max folded into the QK^T MFMAs, bit 1 = exact running max, bit 2 = Q arithmetic under the
-prologue DMA; FLUXMI_ATTN_ABL 4 = s_setprio 1 for the younger half, 8 = round-1 fp8 stores, 2 = no barrier [timing only]), Flux-dev shapes, random data.
+"""Interleaved A/B of the attention kernels in ONE process (guide rule 24): round-1 kernel (FLUXMI_ATTN_V=1) vs the round-2 pipeline with bf16 K
+(unfolded) and fp16 K (folded: softmax scale in Q, running max in the accumulator init, f16 MFMAs for QK^T); FLUXMI_ATTN_VAR bit 1 = exact running
+max, bit 0 = lagged softmax consumers, FLUXMI_ATTN_ABL 8 = round-1 fp8 stores, 2 = no barrier [timing only].  Flux-dev shapes, random data.
     python tools/attn_ab.py [--rounds 5] [--iters 20] [--L 4608 2816]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,10 +13,9 @@ ap.add_argument("--L", type=int, nargs="+", default=[4608, 2816, 8192]); ap.add_
 ap.add_argument("--rounds", type=int, default=5)
 a = ap.parse_args()
 dev = torch.device("cuda:0"); torch.manual_seed(0)
-VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}), ("r2 base + old stores", {"FLUXMI_ATTN_ABL": "8"}), ("r2 base", {}), ("r2 fold", {"FLUXMI_ATTN_VAR": "1"}),
-            ("r2 prologue", {"FLUXMI_ATTN_VAR": "4"}), ("r2 fold+prologue", {"FLUXMI_ATTN_VAR": "5"}),
-            ("r2 fold+prol+setprio", {"FLUXMI_ATTN_VAR": "5", "FLUXMI_ATTN_ABL": "4"}), ("r2 fold+prol nobarrier*", {"FLUXMI_ATTN_VAR": "5", "FLUXMI_ATTN_ABL": "2"}),
-            ("r2 fold exact-max", {"FLUXMI_ATTN_VAR": "3"})]
+VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}, False), ("r2 bf16 K, old stores", {"FLUXMI_ATTN_ABL": "8"}, False), ("r2 bf16 K", {}, False),
+            ("r2 fp16 K (folded)", {}, True), ("r2 folded, lagged consumers", {"FLUXMI_ATTN_VAR": "1"}, True), ("r2 folded, no barrier*", {"FLUXMI_ATTN_ABL": "2"}, True), ("r2 folded, exact max", {"FLUXMI_ATTN_VAR": "2"}, True),
+            ("r2 bf16 K, exact max", {"FLUXMI_ATTN_VAR": "2"}, False)]
 
 
 def setenv(env):
@@ -32,20 +31,22 @@ for L in a.L:
     vt = torch.randn(B, H, 128, Lp, device=dev).bfloat16()
     one = torch.tensor(1.0, device=dev)
     o8 = torch.empty(B, L, H * 128, dtype=torch.float8_e5m2, device=dev)
-    res = {n: [] for n, _ in VARIANTS}
-    for n, env in VARIANTS:
+    k16 = k.half()
+    res = {n: [] for n, _, _ in VARIANTS}
+    for n, env, f16 in VARIANTS:
         setenv(env)
-        for _ in range(3): ops.attention(q, k, vt, q_scale0=one, out=o8)
+        for _ in range(3): ops.attention(q, k16 if f16 else k, vt, q_scale0=one, out=o8)
     torch.cuda.synchronize()
     for r in range(a.rounds):
-        for n, env in VARIANTS:
+        for n, env, f16 in VARIANTS:
             setenv(env)
+            kk = k16 if f16 else k
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(a.iters): ops.attention(q, k, vt, q_scale0=one, out=o8)
+            for _ in range(a.iters): ops.attention(q, kk, vt, q_scale0=one, out=o8)
             e1.record(); torch.cuda.synchronize()
             res[n].append(e0.elapsed_time(e1) / a.iters * 1e-3)
     fl = 4 * L * L * 128 * H * B
-    for n, _ in VARIANTS:
+    for n, _, _ in VARIANTS:
         ts = sorted(res[n]); t = ts[len(ts) // 2]
         print(f"L={L:5d} {n:24s}: median {fl / t / 1e12:7.1f} TF/s ({t * 1e6:6.1f} us)  best {fl / ts[0] / 1e12:7.1f}  frac of 2.5 PF {fl / t / 2.5e15:.3f}", flush=True)
