@@ -51,10 +51,9 @@ constexpr float DEFER_LOG2 = 8.0f;  // rescale only when a row max grew by more 
 // Measured and dropped in round 2 (profiles/r02_attention_ab.txt): refills in the PV half (-0.4 %), softmax work skewed by one gap so that
 // nothing inside a gap depends on anything in it (-4 %: +17 register moves), row sums by an all-ones MFMA (-4 %), V fragments 2 instead of
 // 4 MFMAs ahead (-0.5 %), Q arithmetic under the prologue DMA (-0.7 %), s_setprio 1 for the younger half (-0.3 %), no barrier at all
-// (+0.4 ... 1.8 %, timing only: the barrier is not what the waves wait for)
-// LAG (A/B, FLUXMI_ATTN_VAR bit 0): the consumers of a score's exp2 -- row-sum add, cvt_pk of the pair -- run one gap later, so no
-// instruction of a gap reads the v_exp_f32 result of the same gap (no trans-use wait states, no dependent chain inside the gap)
-template <int FMT, bool FOLD, bool EXACT, bool LAG>
+// (+0.4 ... 1.8 %, timing only: the barrier is not what the waves wait for), the consumers of a score's exp2 (row-sum add, cvt_pk) run one
+// gap later so that nothing in a gap reads that gap's v_exp_f32 (270 fewer s_nop per four tiles, +-0 %: instruction issue is not the limit)
+template <int FMT, bool FOLD, bool EXACT>
 __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs a) {
   constexpr int QB = NW2 * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -247,48 +246,20 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       float sc = cur[t][r];
       asm volatile("" : "+v"(sc));
       float p = FOLD ? __builtin_amdgcn_exp2f(sc) : __builtin_amdgcn_exp2f(__builtin_fmaf(sc, c, nmc));
-      if constexpr (LAG) {
-        if constexpr (e >= 1) {
-          constexpr int pe = e - 1, pt = pe >> 4, pr = pe & 15;
-          const float pv = cur[pt][pr];  // P value of the previous gap
-          float ls = l4[pe & 3] + pv;
-          if constexpr (pe & 1) {
-            constexpr int f = pt * 2 + (pr >> 3), q = (pr & 7) >> 1;
-            int w;
-            asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[pt][pr - 1]), "v"(pv));
-            pc[f][q] = w;
-          }
-          asm volatile("" : "+v"(ls));
-          l4[pe & 3] = ls;
-        }
-        asm volatile("" : "+v"(p));
-        cur[t][r] = p;
-      } else {
-        float ls = l4[e & 3] + p;
-        if constexpr (e & 1) {
-          constexpr int f = t * 2 + (r >> 3), q = (r & 7) >> 1;
-          // one v_cvt_pk_bf16_f32 for the pair (through pack_bf2 hipcc converts each half separately and ORs them: 4 instructions).
-          // The s_nop is the trans-op -> VALU wait state hipcc would pad itself (p comes straight from v_exp_f32).
-          int w;
-          asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[t][r - 1]), "v"(p));
-          asm volatile("" : "+v"(p), "+v"(ls));
-          pc[f][q] = w;
-        } else {
-          asm volatile("" : "+v"(p), "+v"(ls));
-        }
-        cur[t][r] = p;
-        l4[e & 3] = ls;
-      }
-    };
-    // LAG: the last score's consumers, after the last gap of the step
-    auto soft_tail = [&] {
-      if constexpr (LAG) {
-        const float pv = cur[1][15];
-        l4[3] += pv;
+      float ls = l4[e & 3] + p;
+      if constexpr (e & 1) {
+        constexpr int f = t * 2 + (r >> 3), q = (r & 7) >> 1;
+        // one v_cvt_pk_bf16_f32 for the pair (through pack_bf2 hipcc converts each half separately and ORs them: 4 instructions).
+        // The s_nop is the trans-op -> VALU wait state hipcc would pad itself (p comes straight from v_exp_f32).
         int w;
-        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[1][14]), "v"(pv));
-        pc[3][3] = w;
+        asm volatile("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(cur[t][r - 1]), "v"(p));
+        asm volatile("" : "+v"(p), "+v"(ls));
+        pc[f][q] = w;
+      } else {
+        asm volatile("" : "+v"(p), "+v"(ls));
       }
+      cur[t][r] = p;
+      l4[e & 3] = ls;
     };
     auto gapwork = [&](auto GC) { soft(GC); };
     // -- B: S_{j+1} = K_{j+1} Q^T, two alternating accumulators; K fragments two chunks ahead; one score of P_j per gap
@@ -353,7 +324,6 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         rmax(SC);
       });
     }
-    soft_tail();
     mx = finish_max(m0);
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -394,30 +364,25 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
 
 }  // namespace
 
-template <bool FOLD, bool EXACT, bool LAG> static int launch2(const AttnArgs& a, int fmt, hipStream_t s) {
+template <bool FOLD, bool EXACT> static int launch2(const AttnArgs& a, int fmt, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, LAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
-    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, LAG>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
     attr = true;
   }
   const dim3 grid(((a.L + 255) / 256) * a.H * a.B);
-  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, LAG>), grid, dim3(512), 4 * A_STAGE, s, a);
-  else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, LAG>), grid, dim3(512), 4 * A_STAGE, s, a);
+  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT>), grid, dim3(512), 4 * A_STAGE, s, a);
+  else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT>), grid, dim3(512), 4 * A_STAGE, s, a);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }
 
 // The kernel follows the K operand: fp16 K (AttnArgs.k_f16, produced by fluxmi_qkv_rope(k_f16 = 1)) -> folded kernel, bf16 K -> the
-// unfolded one.  FLUXMI_ATTN_VAR (read per call: the tests sweep it): bit 1 = exact instead of deferred max tracking, bit 0 = lagged
-// softmax consumers (folded kernel only).
+// unfolded one.  FLUXMI_ATTN_VAR=2 (read per call: the tests sweep it) selects exact instead of deferred max tracking.
 int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s) {
   const char* e = getenv("FLUXMI_ATTN_VAR");
-  const int var = e ? atoi(e) : 0;
-  const bool exact = (var & 2) != 0, lag = (var & 1) != 0;
-  if (a.k_f16) {
-    if (lag) return exact ? launch2<true, true, true>(a, fmt, s) : launch2<true, false, true>(a, fmt, s);
-    return exact ? launch2<true, true, false>(a, fmt, s) : launch2<true, false, false>(a, fmt, s);
-  }
-  return exact ? launch2<false, true, false>(a, fmt, s) : launch2<false, false, false>(a, fmt, s);
+  const bool exact = e && (atoi(e) & 2);
+  if (a.k_f16) return exact ? launch2<true, true>(a, fmt, s) : launch2<true, false>(a, fmt, s);
+  return exact ? launch2<false, true>(a, fmt, s) : launch2<false, false>(a, fmt, s);
 }

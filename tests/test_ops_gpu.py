@@ -461,14 +461,15 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
                                              (L // 2, nt // 2, 6.0), (L // 2, nt // 2 + 1, 8.0)]):
         key = min(tile * 64 + 5 + t_i, L - 1)
         k[:, :, key] = (q[:, :, row].float() * gain).bfloat16()
+    k = torch.where(k.abs() < 6.2e-5, torch.zeros_like(k), k)  # below fp16's normal range a bf16 value is not exact in fp16 (engine: |k| ~ 1)
+    assert torch.equal(k.half().float(), k.float())
     ref = fo.attention_fp64(q, k, v).transpose(1, 2).reshape(B, L, H * 128)
     VT = _vt_layout(v, L)
     d = lambda t: t.to(dev)
-    assert torch.equal(k.half().float(), k.float()), "the test's K values must be exact in fp16"
     outs = {}
     knobs = ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V", "FLUXMI_ATTN_ABL")
     variants = (("deferred", {}, False), ("exact", {"FLUXMI_ATTN_VAR": "2"}, False), ("fold", {}, True), ("fold_exact", {"FLUXMI_ATTN_VAR": "2"}, True),
-                ("fold_lag", {"FLUXMI_ATTN_VAR": "1"}, True), ("fold_exact_lag", {"FLUXMI_ATTN_VAR": "3"}, True), ("round1", {"FLUXMI_ATTN_V": "1"}, False))
+                ("round1", {"FLUXMI_ATTN_V": "1"}, False))
     s0, s1 = torch.tensor(3000.0), torch.tensor(9000.0)
     for name, env, f16 in variants:
         for kk in knobs:
@@ -489,8 +490,6 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     for name, _, _ in variants[1:]:
         dd = (outs["deferred"].float() - outs[name].float()).abs().max().item()
         assert dd <= 2e-2 * v.abs().max().item(), f"deferred vs {name}: {dd:.3e}"
-    # a schedule variant must not change bits
-    assert torch.equal(outs["fold"], outs["fold_lag"]) and torch.equal(outs["fold_exact"], outs["fold_exact_lag"])
     e = lambda n: (outs[n].double() - ref).abs().max().item()
     r = lambda n: ((outs[n].double() - ref).norm() / ref.norm()).item()
     # the fold must not cost accuracy (a bf16 fold did: rel-L2 1.8e-3 -> 3.3e-3 on these inputs)

@@ -1,6 +1,6 @@
 """Interleaved A/B of the attention kernels in ONE process (guide rule 24): round-1 kernel (FLUXMI_ATTN_V=1) vs the round-2 pipeline with bf16 K
-(unfolded) and fp16 K (folded: softmax scale in Q, running max in the accumulator init, f16 MFMAs for QK^T); FLUXMI_ATTN_VAR bit 1 = exact running
-max, bit 0 = lagged softmax consumers, FLUXMI_ATTN_ABL 8 = round-1 fp8 stores, 2 = no barrier [timing only].  Flux-dev shapes, random data.
+(unfolded) and fp16 K (folded: softmax scale in Q, running max in the accumulator init, f16 MFMAs for QK^T); FLUXMI_ATTN_VAR=2 = exact running
+max, FLUXMI_ATTN_ABL 8 = round-1 fp8 stores, 2 = no barrier [timing only].  Flux-dev shapes, random data.
     python tools/attn_ab.py [--rounds 5] [--iters 20] [--L 4608 2816]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,7 @@ ap.add_argument("--rounds", type=int, default=5)
 a = ap.parse_args()
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 VARIANTS = [("round1", {"FLUXMI_ATTN_V": "1"}, False), ("r2 bf16 K, old stores", {"FLUXMI_ATTN_ABL": "8"}, False), ("r2 bf16 K", {}, False),
-            ("r2 fp16 K (folded)", {}, True), ("r2 folded, lagged consumers", {"FLUXMI_ATTN_VAR": "1"}, True), ("r2 folded, no barrier*", {"FLUXMI_ATTN_ABL": "2"}, True), ("r2 folded, exact max", {"FLUXMI_ATTN_VAR": "2"}, True),
+            ("r2 fp16 K (folded)", {}, True), ("r2 folded, no barrier*", {"FLUXMI_ATTN_ABL": "2"}, True), ("r2 folded, exact max", {"FLUXMI_ATTN_VAR": "2"}, True),
             ("r2 bf16 K, exact max", {"FLUXMI_ATTN_VAR": "2"}, False)]
 
 
