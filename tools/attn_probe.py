@@ -7,11 +7,14 @@ from fluxmi import ops
 
 ap = argparse.ArgumentParser(); ap.add_argument("--L", type=int, default=4608); ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--B", type=int, default=1)
+ap.add_argument("--bf16-k", action="store_true", help="bf16 K (unfolded kernel) instead of the engine's fp16 K (folded kernel)")
 a = ap.parse_args()
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 B, H, L = a.B, 24, a.L
 Lp = (L + 63) // 64 * 64
 q = torch.randn(B, H, L, 128, device=dev).bfloat16(); k = torch.randn(B, H, L, 128, device=dev).bfloat16()
+if not a.bf16_k:
+    k = k.half()
 vt = torch.randn(B, H, 128, Lp, device=dev).bfloat16()
 one = torch.tensor(1.0, device=dev)
 o8 = torch.empty(B, L, H * 128, dtype=torch.float8_e5m2, device=dev)
