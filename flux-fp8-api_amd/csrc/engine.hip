@@ -702,6 +702,30 @@ void free_ws(E* e) {
 
 }  // namespace
 
+// roctx ranges (rocprofv3 --marker-trace) around the phases of a denoise call, resolved at run time so that the library has no
+// hard dependency on the profiler: FLUXMI_ROCTX=1 turns them on.
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* on = getenv("FLUXMI_ROCTX");
+    if (!on || !atoi(on)) return;
+    void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+struct Range {
+  Range(const char* name) { if (roctx().push) roctx().push(name); }
+  ~Range() { if (roctx().pop) roctx().pop(); }
+};
+}  // namespace
+
 extern "C" {
 
 int fluxmi_engine_num_linears(const fluxmi_model_desc_t* desc) { return desc ? lin_count(*desc) : -1; }
@@ -865,30 +889,6 @@ int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, 
                       mode, trial_index, false, (hipStream_t)stream);
 }
 
-
-// roctx ranges (rocprofv3 --marker-trace) around the phases of a denoise call, resolved at run time so that the library has no
-// hard dependency on the profiler: FLUXMI_ROCTX=1 turns them on.
-namespace {
-struct Roctx {
-  int (*push)(const char*) = nullptr;
-  int (*pop)() = nullptr;
-  Roctx() {
-    const char* on = getenv("FLUXMI_ROCTX");
-    if (!on || !atoi(on)) return;
-    void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return;
-    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
-    pop = (int (*)())dlsym(h, "roctxRangePop");
-    if (!push || !pop) push = nullptr, pop = nullptr;
-  }
-};
-Roctx& roctx() { static Roctx r; return r; }
-struct Range {
-  Range(const char* name) { if (roctx().push) roctx().push(name); }
-  ~Range() { if (roctx().pop) roctx().pop(); }
-};
-}  // namespace
 
 int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const void* y, float guidance,
                           const double* timesteps_host, int n_steps, int* trial_index_inout, int use_graph, void* stream) {

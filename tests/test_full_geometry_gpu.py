@@ -243,7 +243,7 @@ def block_tolerance(ck, orc, tr, i, prev_img, prev_txt, out):
     three e5m2 re-quantisations behind the attention, and e5m2 turns a 1-ulp bf16 difference into a 12-25 % step on ~1 % of the
     elements.  The noise floor is measured, not assumed: the ORACLE's own block re-evaluated with an equally valid attention (exact
     fp64 softmax rounded once instead of torch's SDPA) moves by `noise`; the engine may be 1.75 x that (never tighter than 1e-2;
-    measured 0.87-1.16 x over the cases below)."""
+    measured 0.87-1.31 x over the cases below)."""
     with torch.inference_mode():
         ai, at = orc.double_block(i, prev_img, prev_txt, tr["vec"], tr["pe"], attn_fn=fo.attention_exact)
     noise = rel_l2(torch.cat((at[0], ai[0]), 0), out)
