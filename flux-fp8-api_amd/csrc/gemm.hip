@@ -28,14 +28,37 @@ namespace {
 template <int EPI, int FMT, int TM, int TN>
 __device__ __forceinline__ void tile_epilogue(const FluxmiGemmGroup& G, v16f (&acc)[TM][TN], float s, float qs,
                                               int mrow0, int ncol0, int M) {
+  // bias (and gate) words of all TN*4 column groups in ONE batch of loads: inside the loops each load sat behind its own null check, in
+  // its own basic block, and was waited for on the spot (TN*4 exposed L2 round trips per tile)
+  uint2 braw[TN][4], graw[TN][4];
+  const bool has_bias = G.bias != nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int n = ncol0 + j * 32 + g4 * 8;
+      braw[j][g4] = has_bias ? *(const uint2*)((const u16*)G.bias + n) : make_uint2(0, 0);
+      graw[j][g4] = EPI == FLUXMI_EPI_GATE_RESID ? *(const uint2*)((const u16*)G.gate + n) : make_uint2(0, 0);
+    }
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      asm volatile("" : "+v"(braw[j][g4].x), "+v"(braw[j][g4].y));
+      if constexpr (EPI == FLUXMI_EPI_GATE_RESID) asm volatile("" : "+v"(graw[j][g4].x), "+v"(graw[j][g4].y));
+    }
+  auto un4 = [](uint2 v, float* o) {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  };
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int n = ncol0 + j * 32 + g4 * 8;
-      float bias[4] = {0.f, 0.f, 0.f, 0.f}, gate[4] = {0.f, 0.f, 0.f, 0.f};
-      if (G.bias) load_bf<4>(G.bias, n, bias);
-      if constexpr (EPI == FLUXMI_EPI_GATE_RESID) load_bf<4>(G.gate, n, gate);
+      float bias[4], gate[4];
+      un4(braw[j][g4], bias);
+      un4(graw[j][g4], gate);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int m = mrow0 + i * 32;

@@ -85,6 +85,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
   const unsigned long long ub = ((unsigned long long)uni_u32((unsigned)(b >> 32)) << 32) | uni_u32((unsigned)b);
   return __builtin_amdgcn_make_buffer_rsrc((void*)ub, 0, uni_u32(bytes), 0x00020000);
 }
+// wave-uniform copies (SGPRs) of group fields that reach the kernel in VGPRs (see above): 64-bit pointers and strides held in VGPR pairs
+// across the epilogue were what hipcc spilled to scratch and reloaded, one s_waitcnt vmcnt(0) each
+template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
+  const unsigned long long b = (unsigned long long)p;
+  return (T*)(((unsigned long long)uni_u32((unsigned)(b >> 32)) << 32) | uni_u32((unsigned)b));
+}
+__device__ __forceinline__ long long uni_i64(long long v) {
+  const unsigned long long b = (unsigned long long)v;
+  return (long long)(((unsigned long long)uni_u32((unsigned)(b >> 32)) << 32) | uni_u32((unsigned)b));
+}
 __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (fluxmi_lds_ptr_t)lds, 16, voff, soff, 0, 0);
 }
@@ -156,6 +166,59 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
   constexpr int ROW_B = TN * 64;       // bytes per row (TN*32 bf16)
   constexpr int CH = ROW_B / 16;       // 16-B chunks per row
   const int l31 = lane & 31, hi = lane >> 5;
+  // ---- every global load of the epilogue is ISSUED HERE, in one batch.  Round 1 loaded the bias words inside the (j, g4) loops behind
+  // a per-load null check and the residual rows inside the per-row `m < M` guard of phase 2: each load sat in its own basic block, hipcc
+  // waited vmcnt(0) right behind it, and a tile paid TN*4 + (TM*32)/RPP exposed L2 / HBM round trips (8 + 16 on the ping-pong kernel,
+  // 16 + 32 on the one-wave-per-SIMD kernel: 10-35 us of a 60-200 us launch whose tiles run in a single round).
+  // bias words one 32-column block (j) ahead: braw[j & 1][g4] holds block j while block j+1 is in flight
+  const u16* bias_p = uni_ptr((const u16*)G.bias);
+  const u16* resid_p = uni_ptr((const u16*)G.resid);
+  const u16* gate_p = uni_ptr((const u16*)G.gate);
+  u16* c_p = uni_ptr((u16*)G.C);
+  const long long ldc_u = uni_i64(G.ldc), ldr_u = uni_i64(G.ldr);
+  uint2 braw[2][4];
+  const bool has_bias = bias_p != nullptr;
+  auto load_bias = [&](int j, uint2 (&dst)[4]) {
+    if (has_bias) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) dst[g4] = *(const uint2*)(bias_p + n_wave0 + j * 32 + g4 * 8 + hi * 4);
+    } else {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) dst[g4] = make_uint2(0, 0);
+    }
+  };
+  // called at the top of block j: issue block j+1, then pin block j (the empty asm keeps hipcc from sinking each load back into the
+  // basic block that uses it and waiting for it there)
+  auto bias_step = [&](int j) {
+    if (j + 1 < TN) load_bias(j + 1, braw[(j + 1) & 1]);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(braw[j & 1][g4].x), "+v"(braw[j & 1][g4].y));
+  };
+  auto bias_of = [&](int j, int g4, float* b) {
+    const uint2 v = braw[j & 1][g4];
+    b[0] = __uint_as_float(v.x << 16); b[1] = __uint_as_float(v.x & 0xffff0000u);
+    b[2] = __uint_as_float(v.y << 16); b[3] = __uint_as_float(v.y & 0xffff0000u);
+  };
+  load_bias(0, braw[0]);
+  // gate*y + x: the residual rows of phase 2 in batches of RB rows (row clamped instead of guarded: the load is unconditional, the store
+  // is not); batch 0 is issued here and flies under phase 1, batch b+1 is issued before batch b is consumed
+  constexpr int RPP0 = 64 / CH, NIT = (TM * 32) / RPP0, RB = NIT < 8 ? NIT : 8;
+  uint4 rres[2][EPI == FLUXMI_EPI_GATE_RESID ? RB : 1];
+  uint4 graw = make_uint4(0, 0, 0, 0);
+  auto load_resid = [&](int b, uint4 (&dst)[EPI == FLUXMI_EPI_GATE_RESID ? RB : 1]) {
+    if constexpr (EPI == FLUXMI_EPI_GATE_RESID) {
+      const int c = lane % CH, n = n_wave0 + c * 8;
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int m = min(m_wave0 + (b * RB + q) * RPP0 + lane / CH, M - 1);
+        dst[q] = *(const uint4*)(resid_p + (long long)m * ldr_u + n);
+      }
+    }
+  };
+  if constexpr (EPI == FLUXMI_EPI_GATE_RESID) {
+    graw = *(const uint4*)(gate_p + n_wave0 + (lane % CH) * 8);
+    load_resid(0, rres[0]);
+  }
   if constexpr ((EPI == FLUXMI_EPI_GELU_QUANT || EPI == FLUXMI_EPI_SPLIT) && TM == 4 && TN == 2) {
     // ---- table-driven quantising epilogue (8-wave 256x256 kernels; block-uniform branch: every wave of the workgroup takes it).
     // bf16(acc*s+bias) -> GELU -> bf16 -> x scale -> bf16 -> clamp -> fp8 is a pure function of the 16 bits of its input once the
@@ -174,17 +237,19 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
       // (2) meanwhile: h = bf16(acc*s + bias), packed two per register
       unsigned hp[TM][TN][4][2];
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j) {
+        bias_step(j);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          float bias[4] = {0.f, 0.f, 0.f, 0.f};
-          if (G.bias) load_bf<4>(G.bias, n_wave0 + j * 32 + g4 * 8 + hi * 4, bias);
+          float bias[4];
+          bias_of(j, g4, bias);
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             hp[i][j][g4][0] = pack_bf2(fmaf(acc[i][j][g4 * 4 + 0], s, bias[0]), fmaf(acc[i][j][g4 * 4 + 1], s, bias[1]));
             hp[i][j][g4][1] = pack_bf2(fmaf(acc[i][j][g4 * 4 + 2], s, bias[2]), fmaf(acc[i][j][g4 * 4 + 3], s, bias[3]));
           }
         }
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       // (3) gather + transpose: lane owns 4 consecutive columns of row ml -> one dword of the wave's fp8 tile
@@ -226,12 +291,13 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
     const int vcol0 = G.kv_col0 + G.heads * 128;
     if (G.vt_out && n_wave0 >= vcol0 && n_wave0 < vcol0 + G.heads * 128) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j) {
+        bias_step(j);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int dl = j * 32 + g4 * 8 + hi * 4;  // local d of this lane's 4 values
-          float bias[4] = {0.f, 0.f, 0.f, 0.f};
-          if (G.bias) load_bf<4>(G.bias, n_wave0 + dl, bias);
+          float bias[4];
+          bias_of(j, g4, bias);
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const int ml = i * 32 + l31;
@@ -245,6 +311,7 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
             }
           }
         }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       constexpr int KROW_B = TM * 64;        // bytes per d-row (TM*32 keys)
       constexpr int KCH = KROW_B / 16;       // 16-B chunks (8 keys) per d-row
@@ -261,12 +328,13 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
     }
   }
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+  for (int j = 0; j < TN; ++j) {
+    bias_step(j);
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int nl = j * 32 + g4 * 8 + hi * 4;  // local column of this lane's 4 values
-      float bias[4] = {0.f, 0.f, 0.f, 0.f};
-      if (G.bias) load_bf<4>(G.bias, n_wave0 + nl, bias);
+      float bias[4];
+      bias_of(j, g4, bias);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int ml = i * 32 + l31;
@@ -277,6 +345,7 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
         *(uint2*)(wbuf + ml * ROW_B + chunk * 16 + (nl & 4) * 2) = v;
       }
     }
+  }
   // the tile is private to this wave: no barrier, only the LDS write -> read ordering of one wave
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // phase 2: lane -> (row, 16-B chunk); 64 lanes cover (64/CH) rows x ROW_B bytes per pass
@@ -341,15 +410,41 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
       return;
     }
   }
+  if constexpr (EPI == FLUXMI_EPI_GATE_RESID) {
+    // x + bf16(gate * h), residual rows prefetched a batch ahead                                   flux_model.py:389-397,484
+    float g[8];
+    unpack8(graw, g);
+    const int c = lane % CH;
 #pragma unroll
-  for (int it = 0; it < (TM * 32) / RPP; ++it) {
-    const int ml = it * RPP + lane / CH, c = lane % CH;
-    const int m = m_wave0 + ml;
-    const uint4 raw = *(const uint4*)(wbuf + ml * ROW_B + ((c ^ (ml & (CH - 1))) * 16));
-    if (m < M) {
-      float h[8];
-      unpack8(raw, h);
-      row_epilogue<EPI, FMT>(G, qs, m, n_wave0 + c * 8, h);
+    for (int b = 0; b < NIT / RB; ++b) {
+      if (b + 1 < NIT / RB) load_resid(b + 1, rres[(b + 1) & 1]);
+      // pin batch b's loads above this point (hipcc otherwise sinks each into the guarded store block and waits for it there)
+#pragma unroll
+      for (int q = 0; q < RB; ++q) asm volatile("" : "+v"(rres[b & 1][q].x), "+v"(rres[b & 1][q].y), "+v"(rres[b & 1][q].z), "+v"(rres[b & 1][q].w));
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int ml = (b * RB + q) * RPP + lane / CH;
+        const int m = m_wave0 + ml;
+        const uint4 raw = *(const uint4*)(wbuf + ml * ROW_B + ((c ^ (ml & (CH - 1))) * 16));
+        float h[8], r[8], o[8];
+        unpack8(raw, h);
+        unpack8(rres[b & 1][q], r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = r[j] + rbf(g[j] * h[j]);
+        if (m < M) *(uint4*)(c_p + (long long)m * ldc_u + n_wave0 + c * 8) = pack8(o);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < (TM * 32) / RPP; ++it) {
+      const int ml = it * RPP + lane / CH, c = lane % CH;
+      const int m = m_wave0 + ml;
+      const uint4 raw = *(const uint4*)(wbuf + ml * ROW_B + ((c ^ (ml & (CH - 1))) * 16));
+      if (m < M) {
+        float h[8];
+        unpack8(raw, h);
+        row_epilogue<EPI, FMT>(G, qs, m, n_wave0 + c * 8, h);
+      }
     }
   }
 }

@@ -219,7 +219,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (NS == 3 ? 2 : 1) * WM * WN / 4) 
 // read step k and group 0 step k+1 after it; the slot refilled after barrier k held step k-1, last read (by group 1)
 // before that barrier.
 // -------------------------------------------------------------------------------------------------------------------
-template <bool FP8, int ACT_FMT, int VAR>
+// ESEL >= 0: compiled for ONE epilogue (see gemm_w1.hip), -1: run-time switch
+template <bool FP8, int ACT_FMT, int VAR, int ESEL>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams P) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NT = 512, TM = 4, TN = 2, NS = 4, D = 3;
   constexpr int WTM = 128, WTN = 64;
@@ -404,18 +405,23 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
   __builtin_amdgcn_s_barrier();  // every wave is done reading the ring before it is reused as epilogue scratch
   unsigned char* wbuf = smem + wave * (WTM * WTN * 2);
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
-  switch (P.epi) {
-    case FLUXMI_EPI_BF16: lds_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave, smem); break;
-    case FLUXMI_EPI_GELU_QUANT: lds_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave, smem); break;
-    case FLUXMI_EPI_GATE_RESID: lds_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave, smem); break;
-    case FLUXMI_EPI_SPLIT: lds_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave, smem); break;
-    case FLUXMI_EPI_QUANT: lds_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave, smem); break;
-    case FLUXMI_EPI_SILU_QUANT: lds_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, (float*)(smem + NS * STAGE), wave, smem); break;
-    default: break;
+  float* xchg = (float*)(smem + NS * STAGE);
+  if constexpr (ESEL >= 0) {
+    lds_epilogue<ESEL, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, xchg, wave, smem);
+  } else {
+    switch (P.epi) {
+      case FLUXMI_EPI_BF16: lds_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, xchg, wave, smem); break;
+      case FLUXMI_EPI_GELU_QUANT: lds_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, xchg, wave, smem); break;
+      case FLUXMI_EPI_GATE_RESID: lds_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, xchg, wave, smem); break;
+      case FLUXMI_EPI_SPLIT: lds_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, xchg, wave, smem); break;
+      case FLUXMI_EPI_QUANT: lds_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, xchg, wave, smem); break;
+      case FLUXMI_EPI_SILU_QUANT: lds_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane, xchg, wave, smem); break;
+      default: break;
+    }
   }
 }
 
-template <bool FP8, int ACT, int VAR>
+template <bool FP8, int ACT, int VAR, int ESEL = -1>
 int launch_pp(FluxmiGemmParams& p, hipStream_t s) {
   constexpr int BM = 256, BN = 256;
   int t = 0;
@@ -426,7 +432,7 @@ int launch_pp(FluxmiGemmParams& p, hipStream_t s) {
   p.tiles_m_total = t;
   p.group_m = 8;
   constexpr int SMEM = 4 * (BM + BN) * 64 + 8 * 128 * 4;  // ring + the K-epilogue's row-sum exchange (8 waves x 128 rows)
-  auto kern = gemm_pp_kernel<FP8, ACT, VAR>;
+  auto kern = gemm_pp_kernel<FP8, ACT, VAR, ESEL>;
   static bool attr_set = false;
   if (!attr_set) {
     FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -469,7 +475,20 @@ int launch_ring_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
     case 5: return launch_ring<256, 128, 4, 2, 4, false, FP8, ACT>(p, s);
     case 6: return launch_ring<128, 128, 2, 2, 4, false, FP8, ACT>(p, s);
     case 8: return launch_ring<256, 128, 2, 2, 3, true, FP8, ACT>(p, s);   // 72 KiB LDS, 4 waves: 2 blocks per CU
-    case 13: return launch_pp<FP8, ACT, 2>(p, s);
+    case 13:
+      // the step's hot epilogues get a kernel compiled for them alone (fp8 x e5m2 activations only: the calibrated path)
+      if constexpr (FP8 && ACT == FLUXMI_FMT_E5M2) {
+        static int esel = -1;  // FLUXMI_GEMM_ESEL=0: the run-time-switch kernel for every epilogue (A/B)
+        if (esel < 0) { const char* e = getenv("FLUXMI_GEMM_ESEL"); esel = e ? atoi(e) : 1; }
+        if (esel) switch (p.epi) {
+          case FLUXMI_EPI_BF16: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_BF16>(p, s);
+          case FLUXMI_EPI_GATE_RESID: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GATE_RESID>(p, s);
+          case FLUXMI_EPI_SPLIT: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_SPLIT>(p, s);
+          case FLUXMI_EPI_GELU_QUANT: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GELU_QUANT>(p, s);
+          default: break;
+        }
+      }
+      return launch_pp<FP8, ACT, 2>(p, s);
     case 12: return launch_pp<FP8, ACT, 10>(p, s);  // 13 with the second wave group's refill behind its MFMA block
 #ifdef FLUXMI_EXPERIMENTS  // variants measured and rejected in round 1 (profiles/r01_gemm_ablation*.txt); not built by default
     case 7: return launch_ring<256, 256, 2, 4, 4, true, FP8, ACT>(p, s);

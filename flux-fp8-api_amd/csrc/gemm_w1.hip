@@ -23,7 +23,10 @@ namespace {
 
 struct W1Frags { v8i fw[4]; v8i fa[4]; };
 
-template <bool FP8, int ACT_FMT, int ABL>
+// ESEL >= 0: the kernel is compiled for ONE epilogue (the hot ones get their own instantiation: with the run-time switch over six inlined
+// epilogues hipcc allocates registers for all of them at once and spilled ~110 ACCUMULATOR pairs to scratch right after the K loop -- on every
+// path, each reload behind an s_waitcnt vmcnt(0)); ESEL = -1 keeps the switch (cold epilogues)
+template <bool FP8, int ACT_FMT, int ABL, int ESEL>
 __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams P) {
   constexpr int BM = 256, BN = 256, NT = 256, TM = 4, TN = 4, NS = 4;
   constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
@@ -165,18 +168,22 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   __builtin_amdgcn_s_barrier();
   unsigned char* wbuf = smem + wave * (128 * 128 * 2);
   const int mw = m0 + wm * 128, nw = n0 + wn * 128;
-  switch (P.epi) {
-    case FLUXMI_EPI_BF16: lds_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_GELU_QUANT: lds_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_GATE_RESID: lds_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_SPLIT: lds_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_QUANT: lds_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_SILU_QUANT: lds_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    default: break;
+  if constexpr (ESEL >= 0) {
+    lds_epilogue<ESEL, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane);
+  } else {
+    switch (P.epi) {
+      case FLUXMI_EPI_BF16: lds_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+      case FLUXMI_EPI_GELU_QUANT: lds_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+      case FLUXMI_EPI_GATE_RESID: lds_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+      case FLUXMI_EPI_SPLIT: lds_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+      case FLUXMI_EPI_QUANT: lds_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+      case FLUXMI_EPI_SILU_QUANT: lds_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
+      default: break;
+    }
   }
 }
 
-template <bool FP8, int ACT, int ABL = 0>
+template <bool FP8, int ACT, int ABL = 0, int ESEL = -1>
 int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
   constexpr int BM = 256, BN = 256;
   int t = 0;
@@ -187,7 +194,7 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
   p.tiles_m_total = t;
   p.group_m = 8;
   constexpr int SMEM = 4 * (BM + BN) * 64;
-  auto kern = gemm_w1_kernel<FP8, ACT, ABL>;
+  auto kern = gemm_w1_kernel<FP8, ACT, ABL, ESEL>;
   static bool attr_set = false;
   if (!attr_set) {
     FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -222,6 +229,10 @@ int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStrea
         default: break;
       }
 #endif
+      // the step's K >= 8192 launches (mlp.2, linear2) all end in gate*y + x
+      static int esel = -1;  // FLUXMI_GEMM_ESEL=0: the run-time-switch kernel for every epilogue (A/B)
+      if (esel < 0) { const char* e = getenv("FLUXMI_GEMM_ESEL"); esel = e ? atoi(e) : 1; }
+      if (esel && p.epi == FLUXMI_EPI_GATE_RESID) return launch_w1<true, FLUXMI_FMT_E5M2, 0, FLUXMI_EPI_GATE_RESID>(p, s);
       return launch_w1<true, FLUXMI_FMT_E5M2>(p, s);
     }
     return launch_w1<true, FLUXMI_FMT_E4M3>(p, s);
