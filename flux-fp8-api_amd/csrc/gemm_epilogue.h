@@ -87,13 +87,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 // wave-uniform copies (SGPRs) of group fields that reach the kernel in VGPRs (see above): 64-bit pointers and strides held in VGPR pairs
 // across the epilogue were what hipcc spilled to scratch and reloaded, one s_waitcnt vmcnt(0) each
-template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
+// (returned as a GLOBAL address-space pointer: an integer round trip otherwise leaves a generic pointer, hipcc emits flat_load, and a
+// flat load both counts in lgkmcnt -- every LDS wait then waits for it -- and forces vmcnt(0) before it is issued)
+template <class T> using fluxmi_gptr = __attribute__((address_space(1))) T*;
+typedef int fluxmi_v2i __attribute__((ext_vector_type(2)));  // HIP's uint2 / uint4 classes cannot be copied out of a qualified address space
+template <class T> __device__ __forceinline__ fluxmi_gptr<T> uni_ptr(T* p) {
   const unsigned long long b = (unsigned long long)p;
-  return (T*)(((unsigned long long)uni_u32((unsigned)(b >> 32)) << 32) | uni_u32((unsigned)b));
+  return (fluxmi_gptr<T>)(((unsigned long long)uni_u32((unsigned)(b >> 32)) << 32) | uni_u32((unsigned)b));
 }
 __device__ __forceinline__ long long uni_i64(long long v) {
   const unsigned long long b = (unsigned long long)v;
   return (long long)(((unsigned long long)uni_u32((unsigned)(b >> 32)) << 32) | uni_u32((unsigned)b));
+}
+// per-tensor scale through the scalar unit (the pointer is wave-uniform, the value constant for the kernel: s_load_dword instead of a
+// vector load whose round trip the epilogue waited for)
+__device__ __forceinline__ float load_scale_u(const float* p) {
+  const unsigned long long b = (unsigned long long)p;
+  const unsigned long long ub = ((unsigned long long)uni_u32((unsigned)(b >> 32)) << 32) | uni_u32((unsigned)b);
+  if (!ub) return 1.0f;
+  return *(__attribute__((address_space(4))) const float*)ub;
 }
 __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (fluxmi_lds_ptr_t)lds, 16, voff, soff, 0, 0);
@@ -171,28 +183,31 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
   // waited vmcnt(0) right behind it, and a tile paid TN*4 + (TM*32)/RPP exposed L2 / HBM round trips (8 + 16 on the ping-pong kernel,
   // 16 + 32 on the one-wave-per-SIMD kernel: 10-35 us of a 60-200 us launch whose tiles run in a single round).
   // bias words one 32-column block (j) ahead: braw[j & 1][g4] holds block j while block j+1 is in flight
-  const u16* bias_p = uni_ptr((const u16*)G.bias);
-  const u16* resid_p = uni_ptr((const u16*)G.resid);
-  const u16* gate_p = uni_ptr((const u16*)G.gate);
-  u16* c_p = uni_ptr((u16*)G.C);
+  const fluxmi_gptr<const u16> bias_p = uni_ptr((const u16*)G.bias);
+  const fluxmi_gptr<const u16> resid_p = uni_ptr((const u16*)G.resid);
+  const fluxmi_gptr<const u16> gate_p = uni_ptr((const u16*)G.gate);
+  const fluxmi_gptr<u16> c_p = uni_ptr((u16*)G.C);
   const long long ldc_u = uni_i64(G.ldc), ldr_u = uni_i64(G.ldr);
   uint2 braw[2][4];
   const bool has_bias = bias_p != nullptr;
+  // no branch around the loads (an if / else whose else-arm zeroes the same registers makes hipcc wait vmcnt(0) before the branch): a
+  // group without bias reads the same offsets of its weight matrix instead (always mapped: n < N <= N*K elements) and the words are
+  // zeroed by a select once they are pinned
+  const fluxmi_gptr<const u16> bias_src = has_bias ? bias_p : uni_ptr((const u16*)G.W);
   auto load_bias = [&](int j, uint2 (&dst)[4]) {
-    if (has_bias) {
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) dst[g4] = *(const uint2*)(bias_p + n_wave0 + j * 32 + g4 * 8 + hi * 4);
-    } else {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) dst[g4] = make_uint2(0, 0);
-    }
+    for (int g4 = 0; g4 < 4; ++g4)
+      dst[g4] = __builtin_bit_cast(uint2, *(fluxmi_gptr<const fluxmi_v2i>)(bias_src + n_wave0 + j * 32 + g4 * 8 + hi * 4));
   };
   // called at the top of block j: issue block j+1, then pin block j (the empty asm keeps hipcc from sinking each load back into the
   // basic block that uses it and waiting for it there)
   auto bias_step = [&](int j) {
     if (j + 1 < TN) load_bias(j + 1, braw[(j + 1) & 1]);
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(braw[j & 1][g4].x), "+v"(braw[j & 1][g4].y));
+    for (int g4 = 0; g4 < 4; ++g4) {
+      asm volatile("" : "+v"(braw[j & 1][g4].x), "+v"(braw[j & 1][g4].y));
+      if (!has_bias) braw[j & 1][g4] = make_uint2(0, 0);
+    }
   };
   auto bias_of = [&](int j, int g4, float* b) {
     const uint2 v = braw[j & 1][g4];
@@ -211,12 +226,12 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
 #pragma unroll
       for (int q = 0; q < RB; ++q) {
         const int m = min(m_wave0 + (b * RB + q) * RPP0 + lane / CH, M - 1);
-        dst[q] = *(const uint4*)(resid_p + (long long)m * ldr_u + n);
+        dst[q] = __builtin_bit_cast(uint4, *(fluxmi_gptr<const v4i>)(resid_p + (long long)m * ldr_u + n));
       }
     }
   };
   if constexpr (EPI == FLUXMI_EPI_GATE_RESID) {
-    graw = *(const uint4*)(gate_p + n_wave0 + (lane % CH) * 8);
+    graw = __builtin_bit_cast(uint4, *(fluxmi_gptr<const v4i>)(gate_p + n_wave0 + (lane % CH) * 8));
     load_resid(0, rres[0]);
   }
   if constexpr ((EPI == FLUXMI_EPI_GELU_QUANT || EPI == FLUXMI_EPI_SPLIT) && TM == 4 && TN == 2) {
@@ -431,7 +446,7 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
         unpack8(rres[b & 1][q], r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = r[j] + rbf(g[j] * h[j]);
-        if (m < M) *(uint4*)(c_p + (long long)m * ldc_u + n_wave0 + c * 8) = pack8(o);
+        if (m < M) *(fluxmi_gptr<v4i>)(c_p + (long long)m * ldc_u + n_wave0 + c * 8) = __builtin_bit_cast(v4i, pack8(o));
       }
     }
   } else {

@@ -191,8 +191,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (NS == 3 ? 2 : 1) * WM * WN / 4) 
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
-  const float s = load_scale(G.sa_recip) * load_scale(G.sb_recip);
-  const float qs = G.q_scale ? *G.q_scale : 1.0f;
+  const float s = load_scale_u(G.sa_recip) * load_scale_u(G.sb_recip);
+  const float qs = load_scale_u(G.q_scale);
   __builtin_amdgcn_s_barrier();  // every wave is done reading the ring before it is reused as epilogue scratch
   unsigned char* wbuf = smem + wave * (WTM * WTN * 2);
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
@@ -399,8 +399,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
-  const float s = load_scale(G.sa_recip) * load_scale(G.sb_recip);
-  const float qs = G.q_scale ? *G.q_scale : 1.0f;
+  const float s = load_scale_u(G.sa_recip) * load_scale_u(G.sb_recip);
+  const float qs = load_scale_u(G.q_scale);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // every wave is done reading the ring before it is reused as epilogue scratch
   unsigned char* wbuf = smem + wave * (WTM * WTN * 2);

@@ -162,8 +162,8 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------------------
-  const float s = load_scale(G.sa_recip) * load_scale(G.sb_recip);
-  const float qs = G.q_scale ? *G.q_scale : 1.0f;
+  const float s = load_scale_u(G.sa_recip) * load_scale_u(G.sb_recip);
+  const float qs = load_scale_u(G.q_scale);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing don't-care refills must land before the ring is reused
   __builtin_amdgcn_s_barrier();
   unsigned char* wbuf = smem + wave * (128 * 128 * 2);

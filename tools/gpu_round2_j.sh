@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-2 GPU batch J: GEMM epilogues -- batched bias / gate / residual loads, one kernel per hot epilogue (no accumulator spills)
-O=gpurun_out/r02j; mkdir -p $O
+O=gpurun_out/${OUT:-r02j}; mkdir -p $O
 export TMPDIR=/tmp
 echo "== GEMM / engine correctness"
 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_engine_gpu.py -m gpu -q --maxfail=10 -p no:cacheprovider > $O/pytest_ops.log 2>&1; echo "rc=$?"; tail -6 $O/pytest_ops.log | cut -c1-200
