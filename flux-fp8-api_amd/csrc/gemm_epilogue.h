@@ -269,27 +269,18 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
       __builtin_amdgcn_s_barrier();
       // (3) gather + transpose: lane owns 4 consecutive columns of row ml -> one dword of the wave's fp8 tile
       unsigned char* tile = ring + 65536 + wave * 8192;
-      // all 32 table reads of a 32-row block first, then its 8 stores: the table and the transposition tile are both addressed through
-      // `ring`, so with reads and stores interleaved hipcc has to assume they alias and exposes the LDS latency of every group of four reads
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int ml = i * 32 + l31;
-        unsigned w[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const unsigned a = hp[i][j][g4][0], b = hp[i][j][g4][1];
             const unsigned q0 = ring[a & 0xffffu], q1 = ring[a >> 16], q2 = ring[b & 0xffffu], q3 = ring[b >> 16];
-            w[j][g4] = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
-          }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
             const int nl = j * 32 + g4 * 8 + hi * 4;
             const int chunk = (nl >> 4) ^ ((ml >> 1) & 3);
-            *(unsigned*)(tile + ml * 64 + chunk * 16 + (nl & 12)) = w[j][g4];
+            *(unsigned*)(tile + ml * 64 + chunk * 16 + (nl & 12)) = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
           }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
