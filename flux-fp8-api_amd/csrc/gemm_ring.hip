@@ -476,15 +476,15 @@ int launch_ring_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
     case 6: return launch_ring<128, 128, 2, 2, 4, false, FP8, ACT>(p, s);
     case 8: return launch_ring<256, 128, 2, 2, 3, true, FP8, ACT>(p, s);   // 72 KiB LDS, 4 waves: 2 blocks per CU
     case 13:
-      // the step's hot epilogues get a kernel compiled for them alone (fp8 x e5m2 activations only: the calibrated path)
-      if constexpr (FP8 && ACT == FLUXMI_FMT_E5M2) {
+      // the hot epilogues get a kernel compiled for them alone (fp8 x e5m2: the calibrated step; bf16: VAE / text encoders / bf16 flow)
+      if constexpr (ACT == FLUXMI_FMT_E5M2) {
         static int esel = -1;  // FLUXMI_GEMM_ESEL=0: the run-time-switch kernel for every epilogue (A/B)
         if (esel < 0) { const char* e = getenv("FLUXMI_GEMM_ESEL"); esel = e ? atoi(e) : 1; }
         if (esel) switch (p.epi) {
           case FLUXMI_EPI_BF16: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_BF16>(p, s);
           case FLUXMI_EPI_GATE_RESID: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GATE_RESID>(p, s);
-          case FLUXMI_EPI_SPLIT: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_SPLIT>(p, s);
-          case FLUXMI_EPI_GELU_QUANT: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GELU_QUANT>(p, s);
+          case FLUXMI_EPI_SPLIT: if constexpr (FP8) return launch_pp<FP8, ACT, 2, FLUXMI_EPI_SPLIT>(p, s); else break;
+          case FLUXMI_EPI_GELU_QUANT: if constexpr (FP8) return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GELU_QUANT>(p, s); else break;
           default: break;
         }
       }

@@ -237,6 +237,10 @@ int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStrea
     }
     return launch_w1<true, FLUXMI_FMT_E4M3>(p, s);
   }
-  if (act_fmt == FLUXMI_FMT_E5M2) return launch_w1<false, FLUXMI_FMT_E5M2>(p, s);
+  if (act_fmt == FLUXMI_FMT_E5M2) {  // bf16 operands (VAE convolutions, text encoders, bf16 flow): plain and residual epilogues specialised
+    if (p.epi == FLUXMI_EPI_GATE_RESID) return launch_w1<false, FLUXMI_FMT_E5M2, 0, FLUXMI_EPI_GATE_RESID>(p, s);
+    if (p.epi == FLUXMI_EPI_BF16) return launch_w1<false, FLUXMI_FMT_E5M2, 0, FLUXMI_EPI_BF16>(p, s);
+    return launch_w1<false, FLUXMI_FMT_E5M2>(p, s);
+  }
   return launch_w1<false, FLUXMI_FMT_E4M3>(p, s);
 }
