@@ -30,6 +30,9 @@
 
 namespace {
 constexpr int MAX_STEPS = 1024;
+// samples per engine pass: bounds the workspace (1.1 GB per 1024x1024 sample) and the step-ahead modulation table (2.1 MB per step and
+// sample); the host wrapper runs larger batches as equal consecutive passes
+constexpr int FLUXMI_ENGINE_MAX_BATCH = 32;
 struct Buf { void* p; size_t n; };
 }  // namespace
 
@@ -186,7 +189,9 @@ int small_linear(E* e, int li, const u16* x, long long ldx, u16* out, long long 
   g.W = l.weight; g.bias = l.bias; g.in_scale = l.in_scale; g.sa_recip = l.in_scale_recip; g.sb_recip = l.w_scale_recip;
   g.out = out; g.x = xin; g.ld_out = ld_out; g.ldx = ldx; g.N = l.N; g.K = l.K; g.w_fp8 = l.kind; g.pre_silu = pre_silu;
   g.act_fmt = l.in_fmt;
-  return fluxmi_launch_gemv(nullptr, &g, 1, e->B, 0, 0, s);
+  // the GEMV kernel stages at most 8 activation rows in LDS: larger batches go in row chunks (same per-row arithmetic)
+  for (int r0 = 0; r0 < e->B; r0 += 8) FLUXMI_TRY(fluxmi_launch_gemv(nullptr, &g, 1, std::min(8, e->B - r0), 0, 0, s, r0));
+  return 0;
 }
 
 int build_gemv_table(E* e, hipStream_t s) {
@@ -815,7 +820,8 @@ int fluxmi_engine_set_tables(fluxmi_engine_t* e, const float* freqs128, const fl
 
 int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void* img_ids, const void* txt_ids, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  FLUXMI_REQUIRE(e && B >= 1 && B <= 8 && Li >= 1 && Lt >= 0, "engine_prepare: bad shape B=%d Li=%d Lt=%d (B must be 1..8)", B, Li, Lt);
+  FLUXMI_REQUIRE(e && B >= 1 && B <= FLUXMI_ENGINE_MAX_BATCH && Li >= 1 && Lt >= 0, "engine_prepare: bad shape B=%d Li=%d Lt=%d (B must be 1..%d)", B, Li,
+                 Lt, FLUXMI_ENGINE_MAX_BATCH);
   FLUXMI_REQUIRE(img_ids && (Lt == 0 || txt_ids), "engine_prepare: NULL ids");
   const int H = e->d.hidden, Hm = e->d.mlp_hidden, L = Li + Lt, Lp = ((L + 63) / 64) * 64;
   if (B != e->B || Li != e->Li || Lt != e->Lt || !e->ws) {
@@ -856,6 +862,7 @@ int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void*
       off += (it.bytes + 255) & ~(size_t)255;
     }
     FLUXMI_TRY(build_gemv_table(e, s));
+    FLUXMI_TRY(fluxmi_gemm_sk_prepare());  // stream-K scratch of this device (allocated once; never inside a forward pass)
     // step-ahead modulation table: MODS_STEPS steps x B rows (59 MB per 28 steps at Flux-dev); engine_denoise never allocates
     const int rows_cap = MODS_STEPS * B;
     const size_t need = mods_table_bytes(e, (size_t)rows_cap);

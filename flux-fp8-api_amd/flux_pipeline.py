@@ -26,7 +26,7 @@ import torch
 
 import lora_loading  # noqa: F401  (same import side as the reference)
 from fluxmi import dist as fdist
-from util import ModelSpec, ModelVersion, into_device, into_dtype, load_config_from_path, load_models_from_config
+from util import ModelSpec, ModelVersion, engine_flow_dtype, into_device, into_dtype, load_config_from_path, load_models_from_config
 
 MAX_RAND = 2**32 - 1
 
@@ -327,15 +327,14 @@ class FluxPipeline:
                                              t5_kwargs=t5_kwargs)
             config = models.config
             flux_device = into_device(config.flux_device)
+            # every shipped reference JSON says flow_dtype float16: accepted -- the engine computes in bf16 and the pipeline keeps the
+            # configured dtype for what crosses its boundary (util.engine_flow_dtype; warned once)
             flux_dtype = into_dtype(config.flow_dtype)
-            if flux_dtype != torch.bfloat16:
-                raise ValueError("fluxmi implements the bf16 flow path (north star / README.md:92 of the reference); "
-                                 f"override flow_dtype='bfloat16' (got {config.flow_dtype})")
             flow_model = models.flow
             if not config.prequantized_flow:
                 flow_model = quantize_flow_transformer_and_dispatch_float8(
                     flow_model, flux_device, offload_flow=config.offload_flow, swap_linears_with_cublaslinear=False,
-                    flow_dtype=flux_dtype, quantize_modulation=config.quantize_modulation,
+                    flow_dtype=engine_flow_dtype(config.flow_dtype), quantize_modulation=config.quantize_modulation,
                     quantize_flow_embedder_layers=config.quantize_flow_embedder_layers)
             else:
                 flow_model.eval().requires_grad_(False)

@@ -156,6 +156,8 @@ class LastLayer(nn.Module):  # reference flux_model.py:488-503
 class Flux(nn.Module):
     """Transformer model for flow matching on sequences (reference flux_model.py:506-734)."""
 
+    MAX_ENGINE_BATCH = 32  # samples per engine pass (csrc/engine.hip FLUXMI_ENGINE_MAX_BATCH)
+
     def __init__(self, config: "ModelSpec", dtype: torch.dtype = torch.float16):
         super().__init__()
         self.dtype = dtype
@@ -454,14 +456,24 @@ class Flux(nn.Module):
         """The Euler loop of FluxPipeline.generate (reference flux_pipeline.py:619-651) run natively: calibrating
         steps unfused, every later step one replay of a captured hipGraph.  Returns the final latent tokens."""
         bf = lambda t: t.to(torch.bfloat16).contiguous()
-        if img.shape[0] > 8:
-            # the engine takes at most 8 samples per pass (modulation GEMV staging); the reference has no num_images limit, so
-            # larger batches run as consecutive passes (samples never interact).  Only frozen models: a calibrating pass per chunk
-            # would advance the F8Linear trial counters once per chunk instead of once per step.
+        if img.shape[0] > self.MAX_ENGINE_BATCH:
+            # the engine takes at most 32 samples per pass (workspace / modulation-table size); the reference has no num_images limit, so
+            # larger batches run as consecutive passes (samples never interact).  EQUAL passes: the engine re-allocates its workspace and
+            # re-captures its graph whenever the batch size changes, so 40 = 20 + 20, not 32 + 8.  Only frozen models: a calibrating pass
+            # per chunk would advance the F8Linear trial counters once per chunk instead of once per step.
             if self.calibration_state()[0] is False:
-                raise ValueError("fluxmi: batches larger than 8 need frozen F8Linear input scales (run the calibration warm-up first)")
-            return torch.cat([self.denoise(img[i:i + 8], img_ids[i:i + 8], txt[i:i + 8], txt_ids[i:i + 8], y[i:i + 8], timesteps,
-                                           guidance=guidance, use_graph=use_graph) for i in range(0, img.shape[0], 8)], 0)
+                raise ValueError(f"fluxmi: batches larger than {self.MAX_ENGINE_BATCH} need frozen F8Linear input scales (run the calibration warm-up first)")
+            B = img.shape[0]
+            n_pass = -(-B // self.MAX_ENGINE_BATCH)
+            per = -(-B // n_pass)
+            outs = []
+            for i in range(0, B, per):
+                sl = slice(i, min(i + per, B))
+                pad = per - (sl.stop - sl.start)  # a short last pass is padded with copies of its last sample (same B -> same graph)
+                pick = lambda t: torch.cat([t[sl], t[sl.stop - 1:sl.stop].expand(pad, *t.shape[1:])], 0) if pad else t[sl]
+                o = self.denoise(pick(img), pick(img_ids), pick(txt), pick(txt_ids), pick(y), timesteps, guidance=guidance, use_graph=use_graph)
+                outs.append(o[:per - pad])
+            return torch.cat(outs, 0)
         img = bf(img).clone()
         txt, y = bf(txt), bf(y)
         self._ensure_engine(img.device)

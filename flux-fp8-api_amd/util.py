@@ -88,6 +88,26 @@ def into_dtype(dtype) -> torch.dtype:
         raise ValueError(f"Invalid dtype: {dtype}")
 
 
+_warned_fp16 = False
+
+
+def engine_flow_dtype(flow_dtype) -> torch.dtype:
+    """The dtype the flow transformer COMPUTES in.  Every JSON the reference ships says `flow_dtype: float16` (configs/*.json:47): its
+    fp16 flow is the CublasLinear + fp16-accumulate path for consumer GPUs (float8_quantize.py:372-392, the fp16 clamp of
+    flux_model.py:397-399), and its README (:92) recommends bfloat16 wherever the hardware has it.  libfluxmi implements the bf16 flow
+    only, so a float16 (or float32) config is accepted as is: parameters are held and every kernel runs in bf16, and tensors that cross the
+    model boundary (`Flux.forward` output, the pipeline's noise / latents) are cast to the configured dtype.  Logged once."""
+    global _warned_fp16
+    dt = into_dtype(flow_dtype)
+    if dt != torch.bfloat16 and not _warned_fp16:
+        import warnings
+
+        warnings.warn(f"fluxmi: flow_dtype={str(dt).replace('torch.', '')} requested; the MI355X engine computes the flow in bfloat16 "
+                      "(inputs / outputs are cast to the requested dtype)", stacklevel=3)
+        _warned_fp16 = True
+    return torch.bfloat16
+
+
 def into_device(device) -> torch.device:
     if isinstance(device, int):
         return torch.device(f"cuda:{device}")
@@ -164,11 +184,12 @@ def load_config_from_path(path: str) -> ModelSpec:
 
 def load_flow_model(config: ModelSpec, state_dict=None) -> Flux:
     """reference util.py:240-256.  `state_dict` lets tests / the bench inject a synthetic BFL checkpoint."""
-    dtype = into_dtype(config.flow_dtype)
+    dtype = into_dtype(config.flow_dtype)          # what callers see (Flux.dtype: forward() returns this)
+    pdtype = engine_flow_dtype(config.flow_dtype)  # what the parameters are held in: bf16, whatever the config asks for
     with torch.device("meta"):
         model = Flux(config, dtype=dtype)
         if not config.prequantized_flow:
-            model.type(dtype)
+            model.type(pdtype)
     if state_dict is None and config.ckpt_path is not None:
         from safetensors.torch import load_file as load_sft
 
@@ -176,7 +197,7 @@ def load_flow_model(config: ModelSpec, state_dict=None) -> Flux:
     if state_dict is not None:
         model.load_state_dict(state_dict, strict=False, assign=True)
         if not config.prequantized_flow:
-            model.type(dtype)
+            model.type(pdtype)
     model.requires_grad_(False)
     return model
 
