@@ -64,18 +64,6 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
   for (int i = 0; i < n; ++i) p.g[i] = gs[i];
   p.N = N; p.K = K; p.epi = epi;
   int cfg = force_cfg >= 0 && fluxmi_gemm_tile_ok(N, K, is_fp8, force_cfg) ? force_cfg : fluxmi_gemm_auto_cfg(p, is_fp8);
-  // stream-K (config 17) instead of config 16 when whole 256x256 tiles would leave the last round of the 256 CUs thinly filled
-  // (mlp.2 / linear2: 216 tiles -> 84 %): every CU then gets the same number of K-steps.  FLUXMI_GEMM_SK=0 turns it off.
-  static int sk = -1;
-  if (sk < 0) { const char* e = getenv("FLUXMI_GEMM_SK"); sk = e ? atoi(e) : 1; }
-  if (sk && cfg == 16 && force_cfg < 0 && getenv("FLUXMI_GEMM_CFG") == nullptr && is_fp8 && act_fmt == FLUXMI_E5M2 && (epi == FLUXMI_EPI_GATE_RESID || epi == FLUXMI_EPI_BF16)) {
-    long long tiles = 0;
-    bool fused_out = false;
-    for (int i = 0; i < n; ++i) { tiles += (gs[i].M + 255) / 256; fused_out |= (gs[i].vt_out || gs[i].k_out); }
-    tiles *= N / 256;
-    // one round, thin: between half and ~92 % of the CUs (every XCD then has at least as many tiles as idle CUs to help with their tails)
-    if (!fused_out && tiles >= 128 && tiles <= 236) cfg = 17;
-  }
   const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0);
   if (cfg < 0 || !split_ok) return fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, s);
   return fluxmi_launch_gemm(p, is_fp8, act_fmt, cfg, s);

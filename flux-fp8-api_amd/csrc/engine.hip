@@ -862,7 +862,6 @@ int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void*
       off += (it.bytes + 255) & ~(size_t)255;
     }
     FLUXMI_TRY(build_gemv_table(e, s));
-    FLUXMI_TRY(fluxmi_gemm_sk_prepare());  // stream-K scratch of this device (allocated once; never inside a forward pass)
     // step-ahead modulation table: MODS_STEPS steps x B rows (59 MB per 28 steps at Flux-dev); engine_denoise never allocates
     const int rows_cap = MODS_STEPS * B;
     const size_t need = mods_table_bytes(e, (size_t)rows_cap);

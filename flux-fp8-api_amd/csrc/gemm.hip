@@ -309,12 +309,11 @@ int launch_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
 }  // namespace
 
 // tile configs: 0..3 = double-buffered kernels of this file, 4..6 = ring kernels of gemm_ring.hip
-static const int kTileBN[18] = {256, 128, 128, 256, 256, 128, 128, 256, 128, 256, 128, 256, 256, 256, 256, 64, 256, 256};
-static const int kTileBM[18] = {256, 256, 128, 128, 256, 256, 128, 256, 256, 128, 256, 256, 256, 256, 256, 128, 256, 256};
-#define FLUXMI_N_CFG 18
+static const int kTileBN[17] = {256, 128, 128, 256, 256, 128, 128, 256, 128, 256, 128, 256, 256, 256, 256, 64, 256};
+static const int kTileBM[17] = {256, 256, 128, 128, 256, 256, 128, 256, 256, 128, 256, 256, 256, 256, 256, 128, 256};
+#define FLUXMI_N_CFG 17
 int fluxmi_launch_gemm_ring(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s);
 int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
-int fluxmi_launch_gemm_w1_sk(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
 
 int fluxmi_gemm_tile_bn(int cfg) { return (cfg >= 0 && cfg < FLUXMI_N_CFG) ? kTileBN[cfg] : 0; }
 int fluxmi_gemm_tile_bm(int cfg) { return (cfg >= 0 && cfg < FLUXMI_N_CFG) ? kTileBM[cfg] : 0; }
@@ -327,7 +326,7 @@ int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg) {
 #endif
   if (cfg < 0 || cfg >= FLUXMI_N_CFG) return 0;
   const int kb = K * (is_fp8 ? 1 : 2);
-  const int kstep = (cfg == 16 || cfg == 17) ? 256 : (cfg >= 4 && cfg != 15) ? 64 : 128;
+  const int kstep = cfg == 16 ? 256 : (cfg >= 4 && cfg != 15) ? 64 : 128;
   return (N % kTileBN[cfg] == 0) && (kb % kstep == 0) && kb >= kstep;
 }
 
@@ -340,7 +339,6 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
     if (p.g[i].vt_out || p.g[i].k_out)
       FLUXMI_REQUIRE((cfg >= 11 && cfg <= 14) || cfg == 16, "gemm: fused K / V^T outputs exist only in tile configs 13 and 16 (got %d)", cfg);
   if (cfg == 16) return fluxmi_launch_gemm_w1(p, is_fp8, act_fmt, s);
-  if (cfg == 17) return fluxmi_launch_gemm_w1_sk(p, is_fp8, act_fmt, s);
   if (cfg >= 4 && cfg != 15) return fluxmi_launch_gemm_ring(p, is_fp8, act_fmt, cfg, s);
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) return launch_cfg<true, FLUXMI_FMT_E5M2>(p, cfg, s);

@@ -55,8 +55,6 @@ class ModelDesc(C.Structure):
 _SIGS = {
     "fluxmi_abi_version": ([], i32),
     "fluxmi_gemm_grouped": ([C.POINTER(GemmGroup), i32, i32, i32, i32, i32, i32, i32, vp], i32),
-    "fluxmi_gemm_sk_prepare": ([], i32),
-    "fluxmi_gemm_sk_status": ([C.POINTER(C.c_uint)], i32),
     "fluxmi_f8_gemm": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "fluxmi_gemv": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_quantize_act": ([vp, vp, vp, i32, i32, i64, i64, i32, vp], i32),
@@ -107,8 +105,8 @@ for _name, (_args, _res) in _SIGS.items():
     _fn.argtypes = _args
     _fn.restype = _res
 
-if lib.fluxmi_abi_version() != 3:
-    raise ImportError(f"fluxmi: ABI version mismatch ({lib.fluxmi_abi_version()} != 3)")
+if lib.fluxmi_abi_version() != 2:
+    raise ImportError(f"fluxmi: ABI version mismatch ({lib.fluxmi_abi_version()} != 2)")
 
 
 def check(rc: int) -> None:

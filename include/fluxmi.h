@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FLUXMI_ABI_VERSION 3
+#define FLUXMI_ABI_VERSION 2
 
 /* fp8 format codes (torch.float8_e4m3fn / torch.float8_e5m2, float8_quantize.py:39,43) */
 #define FLUXMI_E4M3 0
@@ -92,20 +92,10 @@ int fluxmi_abi_version(void);
 /* Grouped linear.  is_fp8=1: A is `act_fmt` fp8, W is e4m3fn (torch._scaled_mm, float8_quantize.py:284-292);
  * is_fp8=0: A, W bf16 (F.linear).  tile_cfg: -1 auto (cost model + split of a thin last round, what the engine uses);
  * 0..3, 15 double-buffered MFMA tile kernels (256x256, 256x128, 128x128, 128x256, 128x64); 4, 5, 6, 8 LDS-ring kernels;
- * 13 = ping-pong 256x256; 16 = 256x256 with one wave per SIMD (K*bytes % 256 == 0); 17 = config 16 as a STREAM-K launch (fp8 x e5m2,
- * bf16 / gate*y+x epilogues): a persistent grid of one workgroup per CU, the launch's K-steps cut into equal contiguous ranges, a
- * tile whose K range spans two or three workgroups is summed from fp32 partials by the workgroup holding its first range -- what the
- * auto dispatch picks when the 256x256 tiling would leave the last round of CUs thinly filled (mlp.2 / linear2: 216 tiles on 256 CUs);
- * 100 = generic any-shape kernel.  Configs 0-16 and 100 compute the same bits; config 17 adds the fp32 partial sums of a split tile in
- * ascending K order (deterministic for a given shape, <= 1 bf16 ulp of fp64 like the others).  Stream-K launches of one device share a
- * scratch area and must be stream-ordered with each other. */
+ * 13 = ping-pong 256x256; 16 = 256x256 with one wave per SIMD (K*bytes % 256 == 0);
+ * 100 = generic any-shape kernel.  Every config computes the same bits. */
 int fluxmi_gemm_grouped(const fluxmi_gemm_group_t* groups, int n_groups, int N, int K, int is_fp8, int act_fmt,
                         int epilogue, int tile_cfg, void* stream);
-/* Stream-K scratch (64 MiB of fp32 partial tiles + flags per device): allocated by the first call, or by fluxmi_engine_prepare, never
- * inside a forward pass.  fluxmi_gemm_sk_status copies the give-up word to *err_word and clears it: non-zero = a workgroup stopped
- * waiting for a partial tile (bounded spin, so that a lost workgroup cannot hang the device); host-synchronising, diagnostics only. */
-int fluxmi_gemm_sk_prepare(void);
-int fluxmi_gemm_sk_status(unsigned* err_word);
 /* single-problem convenience form of the above (F8Linear.forward after quantisation) */
 int fluxmi_f8_gemm(const void* a_fp8, const void* w_e4m3, const float* sa_recip, const float* sb_recip, const void* bias,
                    void* out, int M, int N, int K, int act_fmt, int epilogue, const void* gate, const void* resid,

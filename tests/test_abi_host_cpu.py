@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), f"libfluxmi.so does not export {s}"
     assert set(_lib.EXPORTS) == set(syms), f"ctypes table out of sync with the header: {set(_lib.EXPORTS) ^ set(syms)}"
-    assert _lib.lib.fluxmi_abi_version() == 3
+    assert _lib.lib.fluxmi_abi_version() == 2
 
 
 def test_errors_are_returned_not_thrown():
