@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Headline benchmark: denoise it/s of the Flux hot path on MI355X (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W [--config {1,2,3,5}]     (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--config {1,2,3,5}]
+      N > 1: one rank per GPU over RCCL.  Either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+      (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or plainly as `python bench.py --gpus N`: the script then re-launches
+      itself under torch.distributed.run on 127.0.0.1 and passes rank 0's JSON line through.
 
 One "step" = one pass of the hot path = one Flux.forward + Euler update of the denoise loop (reference flux_pipeline.py:641-651)
 on one latent per GPU, inputs resident in HBM, replayed from the captured hipGraph.  Synthetic seeded request + random-init weights
@@ -22,7 +25,10 @@ the bf16 GEMM's weight stream) from HIP-event timings taken live in this process
 reference's CPU flow path on the host cores for a bounded sample: the UNMODIFIED reference when /root/reference is present
 (build container), otherwise the oracle port that is pinned bit-for-bit to it (oracle/gen_golden*.py).
   python bench.py --cpu-baseline-only [--config C]      runs only that leg (no GPU needed)
-  python bench.py --pmc                                  additionally collects the rocprofv3 PMC counters (HBM traffic, MFMA busy) live
+  python bench.py --no-pmc                               skips the live rocprofv3 PMC passes (HBM traffic, MFMA busy; default at N = 1 when
+                                                         rocprofv3 is on PATH, ~2 min); `roofline.source` says where each number came from
+  python bench.py --gpus 2 --backend gloo --dry-run      no GPU: the multi-rank control flow (rendezvous, broadcast, sharding, in-step amax
+                                                         exchange, barriers, max-over-ranks timing, one JSON line) on a stub engine
 """
 import argparse
 import hashlib
@@ -181,7 +187,7 @@ def measure_attention(torch, ops, dev, L, iters=10, H=24):
 
 
 def pmc_file(kind, cfg_id):
-    return os.path.join(ROOT, "profiles", f"r02_{kind}_config{cfg_id}.json")
+    return os.path.join(ROOT, "profiles", f"r03_{kind}_config{cfg_id}.json")
 
 
 def read_pmc(kind, cfg_id):
@@ -219,7 +225,7 @@ def collect_pmc(cfg_id, Li, Lt):
 
 
 def summarize_pmc(cfg_id, Li, Lt):
-    """raw CSVs -> profiles/r02_{traffic,mfma}_config<id>.json, keyed by the kernel-source hash.  HBM bytes per launch =
+    """raw CSVs -> profiles/r03_{traffic,mfma}_config<id>.json, keyed by the kernel-source hash.  HBM bytes per launch =
     (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 tallies a 128-B fabric read at 64 B: MI355X_MICROARCH.md 'HBM'); matrix-pipe busy fraction =
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs).  The first dispatch of every kernel (cold caches, lazy init) is
     dropped; the 256x256 kernels of a launch are summed with its 128x128 peel."""
@@ -270,7 +276,7 @@ def cpu_baseline(cfg_id):
     unmodified reference's `modules` / `util` packages shadow this repo's same-named host modules, so the two cannot share a process)."""
     C = CONFIGS[cfg_id]
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--height", str(C["height"]), "--width", str(C["width"]),
-           "--txt-len", str(C["txt_len"])] + (["--schnell", "--full-step"] if C["schnell"] else [])
+           "--txt-len", str(C["txt_len"]), "--full-step"] + (["--schnell"] if C["schnell"] else [])
     out = subprocess.run(cmd, check=True, capture_output=True, text=True, timeout=900).stdout.strip().splitlines()[-1]
     return json.loads(out)
 
@@ -300,6 +306,61 @@ def synthetic_lora(p, rank=16, seed=5):
     return lora
 
 
+class _StubFlux:
+    """--dry-run: CPU stand-in with the surface of modules.flux_model.Flux that this script drives (denoise, calibration state, amax
+    exchange).  Per-sample arithmetic only, like the real model, so sharded == whole-batch; every calibrating step issues one
+    reduction through the installed exchange, like the engine's per-layer hook does."""
+
+    def __init__(self, has_f8=True):
+        self._xchg, self._frozen, self._trial, self._has_f8 = None, not has_f8, 0, has_f8
+        self._engine, self.exchanges = None, 0
+
+    def enable_amax_exchange(self, reduce_fn=None):
+        import torch.distributed as td
+
+        self._xchg = None if reduce_fn is False else (reduce_fn or (lambda t: td.all_reduce(t, op=td.ReduceOp.MAX)))
+
+    def calibration_state(self):
+        return (self._frozen, self._trial) if self._has_f8 else (None, 0)
+
+    def f8_modules(self):
+        return []
+
+    def load_lora(self, *a, **k):
+        pass
+
+    def denoise(self, img, img_ids, txt, txt_ids, vec, ts, guidance=3.5, use_graph=True):
+        import torch
+
+        x = img.float().clone()
+        ctx = txt.float().mean(dim=(1, 2)).reshape(-1, 1, 1) + vec.float().mean(dim=1).reshape(-1, 1, 1)
+        for t0, t1 in zip(ts[:-1], ts[1:]):
+            if not self._frozen:
+                if self._xchg is not None:
+                    a = x.abs().amax().reshape(1)
+                    self._xchg(a)
+                    self.exchanges += 1
+                self._trial += 1
+                self._frozen = self._trial > 12
+            x = x + (t1 - t0) * (0.1 * x + ctx)
+        return x.to(img.dtype)
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: re-launch under torch.distributed.run (one rank per GPU, rendezvous on
+    127.0.0.1) and pass rank 0's JSON line through."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, FLUXMI_BENCH_CHILD="1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,14 +369,15 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
-    ap.add_argument("--pmc", action="store_true", help="collect the rocprofv3 PMC counters live (adds ~2 min)")
-    ap.add_argument("--pmc-summarize", action="store_true", help="no GPU: rebuild profiles/r02_*_config<id>.json from gpurun_out/pmc_config<id>/")
+    ap.add_argument("--pmc", action="store_true", help="force the live rocprofv3 PMC passes (default: on at N = 1 when rocprofv3 is on PATH)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (~2 min)")
+    ap.add_argument("--pmc-summarize", action="store_true", help="no GPU: rebuild profiles/r03_*_config<id>.json from gpurun_out/pmc_config<id>/")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL over xGMI)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: run the multi-rank control flow on a stub engine (CPU tensors)")
     ap.add_argument("--depth", type=int, default=None, help="debug only: fewer blocks (the result is then flagged invalid)")
     args = ap.parse_args()
     C = CONFIGS[args.config]
-
-    import torch
 
     if args.pmc_summarize:
         Li, Lt = (C["height"] // 16) * (C["width"] // 16), C["txt_len"]
@@ -324,43 +386,66 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps({"config": args.config, "workload": C["name"], "cpu_baseline": cpu_baseline(args.config)}), flush=True)
         return
+    if args.gpus > 1 and "RANK" not in os.environ:
+        _self_launch(args)
 
+    import torch
     import torch.distributed as td
 
     from fluxmi import dist as fdist
 
-    rank, world, local = fdist.init_from_env("nccl")
+    rank, world, local = fdist.init_from_env("gloo" if args.dry_run and args.backend != "nccl" else args.backend)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         "(or without a torchrun environment: the script then launches its own ranks)")
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        sync = torch.cuda.synchronize
 
-    import util
-    from float8_quantize import quantize_flow_transformer_and_dispatch_float8
-    from fluxmi import _lib, ops, synth
+    from fluxmi import synth
 
-    cfg = util.load_config(util.ModelVersion.flux_schnell if C["schnell"] else util.ModelVersion.flux_dev, flow_dtype="bfloat16",
-                           quantize_modulation=bool(C["quant"] and C["quant"]["modulation"]),
-                           quantize_flow_embedder_layers=bool(C["quant"] and C["quant"]["embedders"]))
-    if args.depth is not None:
-        cfg.params.depth, cfg.params.depth_single_blocks = args.depth, 2 * args.depth
-    p = cfg.params
+    if dry:
+        from types import SimpleNamespace
+
+        p = SimpleNamespace(in_channels=64, vec_in_dim=64, context_in_dim=128, hidden_size=256, mlp_ratio=4.0, num_heads=2, depth=2,
+                            depth_single_blocks=2, guidance_embed=not C["schnell"], qkv_bias=True)
+        _lib = ops = None
+    else:
+        import util
+        from float8_quantize import quantize_flow_transformer_and_dispatch_float8
+        from fluxmi import _lib, ops
+
+        cfg = util.load_config(util.ModelVersion.flux_schnell if C["schnell"] else util.ModelVersion.flux_dev, flow_dtype="bfloat16",
+                               quantize_modulation=bool(C["quant"] and C["quant"]["modulation"]),
+                               quantize_flow_embedder_layers=bool(C["quant"] and C["quant"]["embedders"]))
+        if args.depth is not None:
+            cfg.params.depth, cfg.params.depth_single_blocks = args.depth, 2 * args.depth
+        p = cfg.params
     spr = C["steps_per_request"] or args.steps          # steps per denoise request (config 1: 1-step requests)
-    n_req = args.steps // spr
+    n_req = max(1, args.steps // spr)
     t_setup = time.time()
     with torch.inference_mode():
-        sd = synth.make_state_dict(p, seed=0, device=dev)
-        model = util.load_flow_model(cfg, sd)
-        del sd
-        if C["quant"] is not None:
-            quantize_flow_transformer_and_dispatch_float8(model, dev, flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
-                                                          quantize_modulation=C["quant"]["modulation"],
-                                                          quantize_flow_embedder_layers=C["quant"]["embedders"])
+        if dry:
+            model = _StubFlux(has_f8=C["quant"] is not None)
         else:
-            model.to(dev)
-        torch.cuda.empty_cache()
+            sd = synth.make_state_dict(p, seed=0, device=dev)
+            model = util.load_flow_model(cfg, sd)
+            del sd
+            if C["quant"] is not None:
+                quantize_flow_transformer_and_dispatch_float8(model, dev, flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
+                                                              quantize_modulation=C["quant"]["modulation"],
+                                                              quantize_flow_embedder_layers=C["quant"]["embedders"])
+            else:
+                model.to(dev)
+            torch.cuda.empty_cache()
         # request: rank 0 plays the text-encoder rank; ONE RCCL broadcast of embeddings + noise
-        inp = synth.make_inputs(p, C["height"], C["width"], C["txt_len"], batch=world, seed=0)
+        hw = (64, 64, 32) if dry else (C["height"], C["width"], C["txt_len"])
+        inp = synth.make_inputs(p, hw[0], hw[1], hw[2], batch=world, seed=0)
         txt, vec, img = (inp[k].to(dev) for k in ("txt", "y", "img"))
         if world > 1:
             if rank != 0:
@@ -373,30 +458,36 @@ def main():
         sched = lambda n: util_schedule(n, Li, shift=not C["schnell"])
         nranks = td.get_world_size() if world > 1 else 1
         backend = td.get_backend() if world > 1 else None
+        calibration = None
         if C["quant"] is not None:
-            # calibration (untimed): 13 unfused steps freeze every F8Linear input scale.  Batch-sharded replicas MAX-reduce each
-            # layer's amax inside every calibrating step (float8_quantize.py:227 takes it over the whole batch)
+            # calibration (untimed): 13 unfused steps freeze every F8Linear input scale.  Batch-sharded replicas MAX-reduce each layer's
+            # amax inside every calibrating step (float8_quantize.py:227 takes it over the whole batch).  A rank whose exchange fails
+            # cannot rejoin the others' collectives: it reports and exits non-zero (torch.distributed.run then tears the job down) --
+            # there is no silent per-rank fallback.  FLUXMI_BENCH_AMAX_XCHG=0 selects the coarser scheme on purpose: per-rank
+            # calibration, then ONE all-reduce of the running-amax trials (fluxmi.dist.sync_calibration).
             xchg = world > 1 and os.environ.get("FLUXMI_BENCH_AMAX_XCHG", "1") != "0"
+            calibration = "in-step per-layer amax all-reduce(MAX)" if xchg else ("per-rank + one all-reduce of the trials" if world > 1 else "single rank")
             try:
                 if xchg:
                     model.enable_amax_exchange()
+                if dry and os.environ.get("FLUXMI_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank whose exchange breaks
+                    raise RuntimeError("injected exchange failure")
                 model.denoise(img, img_ids, txt, txt_ids, vec, sched(13), guidance=3.5, use_graph=False)
-            except Exception as e:  # the timed region does not depend on the scales: finish the warm-up without the in-step exchange
-                if not xchg:
-                    raise
-                print(f"bench: in-step amax exchange failed on rank {rank} ({e}); calibrating per rank + one all-reduce of the trials", file=sys.stderr)
-                model.enable_amax_exchange(False)
-                while not model.calibration_state()[0]:
-                    model.denoise(img, img_ids, txt, txt_ids, vec, sched(2), guidance=3.5, use_graph=False)
-                fdist.sync_calibration(model.f8_modules(), model)
+                sync()
+            except Exception as e:
+                print(json.dumps({"error": f"rank {rank}: calibration failed ({type(e).__name__}: {e})", "calibration": calibration,
+                                  "n_gpus": world, "backend": backend}), file=sys.stderr, flush=True)
+                os._exit(3)
             if xchg:
                 model.enable_amax_exchange(False)
+            elif world > 1 and not dry:
+                fdist.sync_calibration(model.f8_modules(), model)
             assert model.calibration_state()[0]
         lora_s = None
-        if C["lora"]:
+        if C["lora"] and not dry:
             t0 = time.time()
             model.load_lora(synthetic_lora(p), 1.0, name="bench-rank16")
-            torch.cuda.synchronize()
+            sync()
             lora_s = time.time() - t0
         if args.warmup > 0:
             model.denoise(img, img_ids, txt, txt_ids, vec, sched(max(min(args.warmup, spr), 2) if spr > 1 else 1), guidance=3.5,
@@ -404,63 +495,44 @@ def main():
             if spr == 1:
                 for _ in range(max(args.warmup - 1, 1)):
                     model.denoise(img, img_ids, txt, txt_ids, vec, sched(1), guidance=3.5, use_graph=not args.no_graph)
-        torch.cuda.synchronize()
+        sync()
         setup_s = time.time() - t_setup
 
         ts = sched(spr)
         if world > 1:
             td.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
-        ev_ms = 0.0
         for _ in range(n_req):
             out = model.denoise(img, img_ids, txt, txt_ids, vec, ts, guidance=3.5, use_graph=not args.no_graph)
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             td.barrier()
         elapsed = time.perf_counter() - t0
-        finite = bool(torch.isfinite(out).all())
-        # engine-side meter: hipEvents recorded on the stream around the table build + graph replays of the LAST request
-        ms_ev, n_ev = _lib.C.c_float(0), _lib.C.c_int(0)
-        _lib.call("fluxmi_engine_last_timing", model._engine, _lib.C.byref(ms_ev), _lib.C.byref(n_ev))
+        finite = bool(torch.isfinite(out.float()).all())
+        ms_ev_v, n_ev_v = 0.0, 0
+        if not dry:
+            # engine-side meter: hipEvents recorded on the launch stream around the graph replays of the LAST request
+            ms_ev, n_ev = _lib.C.c_float(0), _lib.C.c_int(0)
+            _lib.call("fluxmi_engine_last_timing", model._engine, _lib.C.byref(ms_ev), _lib.C.byref(n_ev))
+            ms_ev_v, n_ev_v = ms_ev.value, n_ev.value
         if world > 1:
-            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            tt = torch.tensor([elapsed, 0.0 if finite else 1.0], device=dev, dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
-            elapsed = float(tt.item())
+            elapsed, finite = float(tt[0].item()), float(tt[1].item()) == 0.0
 
         result = None
         if rank == 0:
             steps_done = n_req * spr
             ms_per_step = elapsed / steps_done * 1e3
             its = world * steps_done / elapsed
-            lin_flops = linear_flops_per_step(Li, Lt)
             fp8 = C["quant"] is not None
-            fl, by, sec, gemm_table = measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=fp8)
-            attn_row = measure_attention(torch, ops, dev, Li + Lt)
-            if args.pmc and world == 1 and fp8:
-                collect_pmc(args.config, Li, Lt)
-                summarize_pmc(args.config, Li, Lt)
-            traffic, busy = read_pmc("traffic", args.config), read_pmc("mfma", args.config)
-            busy_w = None
-            if busy:
-                num = den = 0.0
-                for row in gemm_table:
-                    if row["launch"] in busy["per_launch"]:
-                        w = row["us"] * row["per_step"]
-                        num, den = num + w * busy["per_launch"][row["launch"]], den + w
-                busy_w = round(num / den, 4) if den else None
-            if fp8:
-                roof = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_w1_kernel <fp8 MX-MFMA 32x32x64, 256x256 tiles> (the 152 grouped "
-                                                    "F8Linear GEMM launches of a step, fused epilogues included)",
-                        "achieved": round(fl / sec / 1e12, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / FP8_PEAK_TFLOPS, 4)}
-            else:
-                roof = {"bound": "hbm", "kernel": "bf16 MFMA GEMM at M = 512 (weight-stream bound: 23.8 GB of bf16 weights per step)",
-                        "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4)}
-            roof.update({"traffic": traffic["bytes_per_launch"] if traffic else None,
-                         "traffic_note": None if traffic else "no PMC file for the current kernel sources (run bench.py --pmc)",
-                         "flops_per_launch": fl, "algorithmic_bytes_per_launch": by, "avg_launch_us": round(sec * 1e6, 2),
-                         "mfma_busy_frac_pmc": busy_w, "launches": gemm_table,
-                         "attention": attn_row})
+            cfg_block = {"workload": f"BASELINE.json configs[{args.config - 1}]: {C['name']}; batch 1 per GPU, Li={Li}+Lt={Lt} tokens, "
+                                     f"{p.depth} double + {p.depth_single_blocks} single blocks, {spr} step(s) per request x {n_req} request(s), "
+                                     "hipGraph denoise loop",
+                         "baseline_config": args.config, "images_per_gpu": 1, "parallelism": f"batch-sharded replicas x{world}",
+                         "nranks": nranks, "backend": backend, "calibration": calibration, "finite_output": finite,
+                         "depth_override": args.depth, "lora_fuse_s": None if lora_s is None else round(lora_s, 2)}
             result = {
                 "metric": "denoise it/s, " + C["name"],
                 "value": round(its, 4), "unit": "it/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup,
@@ -468,21 +540,63 @@ def main():
                 "vs_baseline": None,
                 "dtype": ("fp8_e4m3 weights x fp8_e5m2 activations (fp32 accumulate), bf16 flow" if fp8 else "bf16 (nn.Linear weights and flow)"),
                 "data": "synthetic seeded request + random-init Flux weights (no checkpoint available offline)",
-                "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: {C['name']}; batch 1 per GPU, Li={Li}+Lt={Lt} tokens, "
-                                       f"{p.depth} double + {p.depth_single_blocks} single blocks, {spr} step(s) per request x {n_req} request(s), "
-                                       "hipGraph denoise loop",
-                           "baseline_config": args.config, "images_per_gpu": 1, "parallelism": f"batch-sharded replicas x{world}",
-                           "nranks": nranks, "backend": backend, "finite_output": finite, "depth_override": args.depth,
-                           "lora_fuse_s": None if lora_s is None else round(lora_s, 2)},
-                "reference_h100_compiled_its": H100_COMPILED.get(args.config),
-                "vs_h100_compiled": round(its / world / H100_COMPILED[args.config], 3) if args.config in H100_COMPILED else None,
-                "fp8_mfma_fraction_whole_step": round(lin_flops / (ms_per_step * 1e-3) / (FP8_PEAK_TFLOPS * 1e12), 4) if fp8 else None,
-                "ms_per_step_hipevent": round(ms_ev.value / n_ev.value, 3) if n_ev.value else None,
-                "setup_s": round(setup_s, 1),
-                "roofline": roof,
+                "config": cfg_block,
             }
+            if dry:
+                result.update({"dry_run": True, "data": "DRY RUN on a stub engine (CPU tensors): control flow only, not a measurement",
+                               "amax_exchanges": model.exchanges})
+            else:
+                lin_flops = linear_flops_per_step(Li, Lt)
+                fl, by, sec, gemm_table = measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=fp8)
+                attn_row = measure_attention(torch, ops, dev, Li + Lt)
+                src = {"achieved": "live (HIP events on the launch stream, this process)", "traffic": None, "mfma_busy": None}
+                have_prof = subprocess.run(["which", "rocprofv3"], capture_output=True).returncode == 0
+                if world == 1 and fp8 and (args.pmc or (have_prof and not args.no_pmc)):
+                    try:
+                        collect_pmc(args.config, Li, Lt)
+                        per_t, per_b = summarize_pmc(args.config, Li, Lt)
+                        if per_t:
+                            src["traffic"] = "live (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this command)"
+                        if per_b:
+                            src["mfma_busy"] = "live (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass run by this command)"
+                    except Exception as ex:  # the counters must never take the measurement down
+                        print(f"bench: PMC collection failed: {ex}", file=sys.stderr)
+                traffic, busy = read_pmc("traffic", args.config), read_pmc("mfma", args.config)
+                if traffic and src["traffic"] is None:
+                    src["traffic"] = "committed file profiles/" + os.path.basename(pmc_file("traffic", args.config)) + " (same kernel sources, earlier run)"
+                if busy and src["mfma_busy"] is None:
+                    src["mfma_busy"] = "committed file profiles/" + os.path.basename(pmc_file("mfma", args.config)) + " (same kernel sources, earlier run)"
+                busy_w = None
+                if busy:
+                    num = den = 0.0
+                    for row in gemm_table:
+                        if row["launch"] in busy["per_launch"]:
+                            w = row["us"] * row["per_step"]
+                            num, den = num + w * busy["per_launch"][row["launch"]], den + w
+                    busy_w = round(num / den, 4) if den else None
+                if fp8:
+                    roof = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_w1_kernel <fp8 MX-MFMA 32x32x64, 256x256 tiles> (the 152 grouped "
+                                                        "F8Linear GEMM launches of a step, fused epilogues included)",
+                            "achieved": round(fl / sec / 1e12, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / FP8_PEAK_TFLOPS, 4)}
+                else:
+                    roof = {"bound": "hbm", "kernel": "bf16 MFMA GEMM at M = 512 (weight-stream bound: 23.8 GB of bf16 weights per step)",
+                            "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4)}
+                roof.update({"traffic": traffic["bytes_per_launch"] if traffic else None,
+                             "traffic_note": None if traffic else "no PMC values for the current kernel sources (rocprofv3 not on PATH, or --no-pmc)",
+                             "source": src,
+                             "flops_per_launch": fl, "algorithmic_bytes_per_launch": by, "avg_launch_us": round(sec * 1e6, 2),
+                             "mfma_busy_frac_pmc": busy_w, "launches": gemm_table,
+                             "attention": attn_row})
+                result.update({
+                    "reference_h100_compiled_its": H100_COMPILED.get(args.config),
+                    "vs_h100_compiled": round(its / world / H100_COMPILED[args.config], 3) if args.config in H100_COMPILED else None,
+                    "fp8_mfma_fraction_whole_step": round(lin_flops / (ms_per_step * 1e-3) / (FP8_PEAK_TFLOPS * 1e12), 4) if fp8 else None,
+                    "ms_per_step_hipevent": round(ms_ev_v / n_ev_v, 3) if n_ev_v else None,
+                    "setup_s": round(setup_s, 1),
+                    "roofline": roof,
+                })
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dry:
             try:
                 result["cpu_baseline"] = cpu_baseline(args.config)
             except Exception as ex:  # the baseline must never take the measurement down

@@ -113,7 +113,11 @@ int fuse_kv_level() {
 // (FLUXMI_FUSE_KV=2) writes bf16 K and therefore switches it off.
 int attn_f16k() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("FLUXMI_ATTN_F16K"); v = (e ? atoi(e) : 1) && fuse_kv_level() < 2; }
+  if (v < 0) {
+    const char* e = getenv("FLUXMI_ATTN_F16K");
+    const char* av = getenv("FLUXMI_ATTN_V");  // FLUXMI_ATTN_V=1: the round-1 cross-check kernel, bf16 K only
+    v = (e ? atoi(e) : 1) && fuse_kv_level() < 2 && !(av && atoi(av) == 1);
+  }
   return v;
 }
 
@@ -966,8 +970,10 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
       FLUXMI_TRY(fluxmi_k_euler(img_s, pred_s, e->d_dts, e->d_step, n_img, st));
       return fluxmi_k_advance_step(e->d_step, st);
     };
-    FLUXMI_CHECK_HIP(hipEventRecord(e->ev_t0, s));
-    const int first_frozen = step;
+    // ev_t0 .. ev_t1 (fluxmi_engine_last_timing) brackets frozen STEPS only: recorded behind the first window's modulation table, the eager
+    // warm step and the graph capture of a new shape (a request longer than MODS_STEPS steps includes its later table builds)
+    bool t0_recorded = false;
+    int first_timed = step;
     // the modulation vectors of up to MODS_STEPS steps are produced ahead (one pass over the 3.2 GB of modulation weights per window);
     // the table address and the device-side window origin never change, so ONE captured graph serves every step of every request
     while (step < n_steps) {
@@ -1006,6 +1012,11 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
         }
       }
       Range r("frozen steps (hipGraph replay)");
+      if (!t0_recorded) {
+        FLUXMI_CHECK_HIP(hipEventRecord(e->ev_t0, s));
+        first_timed = step;
+        t0_recorded = true;
+      }
       if (use_graph && e->graph_ok) {
         for (; step < win_end; ++step) FLUXMI_CHECK_HIP(hipGraphLaunch(e->exec, s));
       } else {
@@ -1013,7 +1024,7 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
       }
     }
     FLUXMI_CHECK_HIP(hipEventRecord(e->ev_t1, s));
-    e->timed_steps = n_steps - first_frozen;
+    e->timed_steps = t0_recorded ? n_steps - first_timed : 0;
   }
   FLUXMI_CHECK_HIP(hipMemcpyAsync(img, img_s, n_img * 2, hipMemcpyDeviceToDevice, s));
   *trial_index_inout = trial;

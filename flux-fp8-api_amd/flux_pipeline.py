@@ -185,6 +185,21 @@ class FluxPipeline:
         bs, c, h, w = img.shape
         tokens = self.pack(img)
         assert tokens.shape == (bs, (h // 2) * (w // 2), c * 4), f"{tokens.shape} != {(bs, (h // 2) * (w // 2), c * 4)}"
+        prompts = None
+        if isinstance(prompt, (list, tuple)):
+            # reference flux_pipeline.py:267-278: a list with num_images == 1 sizes the batch by its length (the one noise sample is
+            # repeated).  The reference then hands the LIST to parse_prompt_attention, whose regex scan raises TypeError; here every
+            # prompt of the list is embedded on its own, which is what the batch sizing implies.
+            if not prompt or not all(isinstance(q, str) for q in prompt):
+                raise TypeError("fluxmi: a prompt list must be a non-empty list of str")
+            prompts = list(prompt)
+            if bs == 1 and len(prompts) > 1:
+                bs = len(prompts)
+                tokens = tokens.repeat_interleave(bs, dim=0)
+            elif len(prompts) == 1:
+                prompts = prompts * bs
+            elif len(prompts) != bs:
+                raise ValueError(f"fluxmi: {len(prompts)} prompts for a batch of {bs} images")
         img_ids = self.make_img_ids(bs, h // 2, w // 2, target_device, target_dtype)
         if isinstance(prompt, dict):
             txt = prompt["txt"].to(device=target_device, dtype=target_dtype)
@@ -194,10 +209,14 @@ class FluxPipeline:
         elif self.t5 is not None and self.clip is not None:
             from flux_emphasis import get_weighted_text_embeddings_flux
 
-            if not isinstance(prompt, str):  # the reference sizes the batch by len(prompt) but embeds the list as one prompt; be explicit
-                raise TypeError("fluxmi: prompt must be a str (one prompt, `num_images` copies) or a dict of pre-computed embeddings")
-            vec, txt, txt_ids = get_weighted_text_embeddings_flux(self, prompt, num_images_per_prompt=bs, device=self.device_clip,
-                                                                  target_device=target_device, target_dtype=target_dtype, debug=self.debug)
+            kw = dict(device=self.device_clip, target_device=target_device, target_dtype=target_dtype, debug=self.debug)
+            if prompts is not None:
+                parts = [get_weighted_text_embeddings_flux(self, q, num_images_per_prompt=1, **kw) for q in prompts]
+                vec, txt, txt_ids = (torch.cat([pt[i] for pt in parts], 0) for i in range(3))
+                return tokens, img_ids, vec, txt, txt_ids
+            if not isinstance(prompt, str):
+                raise TypeError("fluxmi: prompt must be a str, a list of str, or a dict of pre-computed embeddings")
+            vec, txt, txt_ids = get_weighted_text_embeddings_flux(self, prompt, num_images_per_prompt=bs, **kw)
             return tokens, img_ids, vec, txt, txt_ids
         else:
             raise RuntimeError("fluxmi: no text encoders attached (config.text_enc_path / clip_path not found). Pass "
@@ -256,22 +275,26 @@ class FluxPipeline:
         height, width = 16 * (height // 16), 16 * (width // 16)
         generator, seed = self.set_seed(seed)
         world, rank = fdist.world_size(), fdist.rank()
+        cal = getattr(self.model, "calibration_state", None)
+        if world > 1 and num_images < world and cal is not None and cal()[0] is False:
+            # every rank sees the same (num_images, world, calibration state), so every rank raises -- before any collective.  A rank
+            # with an empty shard would skip the calibrating steps: its trial counters would not advance and (with or without the in-step
+            # amax exchange) the replicas would freeze different input scales, silently.
+            raise RuntimeError(f"fluxmi: calibrating with fewer images ({num_images}) than ranks ({world}); use num_images >= world_size "
+                               "until the F8Linear input scales are frozen (FluxPipeline.compile() does)")
         # batch-sharded replicas: every rank denoises its own slice of the batch (rank 0's noise / init latent is
         # what the broadcast below distributes)
         noise, timesteps = self.preprocess_latent(init_image=init_image, height=height, width=width, num_steps=num_steps, strength=strength,
                                                   generator=generator, num_images=num_images, noise=noise)
         img, img_ids, vec, txt, txt_ids = map(lambda x: x.contiguous(), self.prepare(noise, prompt))
+        num_images = img.shape[0]  # a list prompt with num_images == 1 sizes the batch (prepare)
         if world > 1:
             txt, vec, img = fdist.broadcast_request(txt, vec, img, src=0)
             lo, hi = fdist.shard_bounds(img.shape[0], rank, world)
             img, img_ids, vec, txt, txt_ids = (t[lo:hi].contiguous() for t in (img, img_ids, vec, txt, txt_ids))
         if img.shape[0] == 0:
-            # more ranks than images: this rank has nothing to denoise but still takes part in the gather below (an exception or an
-            # early return here would leave the other ranks blocked in the collective).  A calibrating model must not run like this:
-            # its per-layer amax exchange is a collective too.
-            cal = getattr(self.model, "calibration_state", None)
-            if cal is not None and cal()[0] is False and getattr(self.model, "_amax_xchg", None) is not None:
-                raise RuntimeError("fluxmi: calibrating with fewer images than ranks (use num_images >= world_size for the warm-up)")
+            # more ranks than images (frozen scales only, see above): this rank has nothing to denoise but still takes part in the gather
+            # below (an exception or an early return here would leave the other ranks blocked in the collective)
             latents = img.new_empty((0,) + tuple(img.shape[1:]))
         else:
             latents = self.model.denoise(img, img_ids, txt, txt_ids, vec, timesteps, guidance=guidance, use_graph=use_graph)

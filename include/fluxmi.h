@@ -249,9 +249,11 @@ int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, 
  * Steps with trial_index <= num_trials run unfused; the remainder replays ONE captured hipGraph per step. */
 int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const void* y, float guidance,
                           const double* timesteps_host, int n_steps, int* trial_index_inout, int use_graph, void* stream);
-/* hipEvent timing of the frozen (table + graph-replayed) part of the last fluxmi_engine_denoise call: the events are recorded on the
- * caller's stream around the replays (the reference's only meter is tqdm's it/s, flux_pipeline.py:628-630).  Blocks until the
- * second event has completed.  steps = number of steps between the events (0: nothing was timed, ms = 0).
+/* hipEvent timing of the frozen STEPS of the last fluxmi_engine_denoise call: the first event is recorded on the caller's stream behind
+ * the step-ahead modulation table, the eager warm step and the graph capture of a new shape (none of them is inside the window), the
+ * second behind the last step (the reference's only meter is tqdm's it/s, flux_pipeline.py:628-630).  A request longer than 64 steps
+ * includes the table builds of its later windows.  Blocks until the second event has completed.  steps = number of steps between the
+ * events (0: nothing was timed, ms = 0).
  * FLUXMI_ROCTX=1 additionally emits roctx ranges (calibrating steps / modulation table / graph replays) for rocprofv3 --marker-trace. */
 int fluxmi_engine_last_timing(fluxmi_engine_t* e, float* ms, int* steps);
 /* Batch-sharded calibration: F8Linear.quantize_input takes amax over the WHOLE batch (float8_quantize.py:227).

@@ -4,9 +4,10 @@ TEST / BENCH INFRASTRUCTURE (never on the product path).  Prints one JSON object
 
 kind "reference": the UNMODIFIED /root/reference modules (through oracle/ref_shims.py) when that tree exists (build container);
 kind "port": oracle/flux_oracle.py, which oracle/gen_golden*.py pin bit-for-bit to the reference (the GPU box has no /root/reference).
-Default sample: one DoubleStreamBlock + one SingleStreamBlock at the configuration's sequence length, extrapolated x19 / x38.
---full-step (config 1, schnell 256x256): the whole 19+38-block step executed in full, one block's weights reused for every block of
-its kind (synthesising 24 GB of distinct random weights would take minutes; the arithmetic and the streamed bytes are the same).
+--full-step (what bench.py asks for): the whole 19+38-block step executed in full, one block's weights reused for every block of its kind
+(synthesising 24 GB of distinct random weights would take minutes; the arithmetic and the streamed bytes are the same: a block's
+0.6 GB of bf16 weights do not fit any host cache) -- provided one DoubleStreamBlock + one SingleStreamBlock predict a step of at most
+--full-budget seconds (75); otherwise, and without --full-step: those two blocks timed and extrapolated x19 / x38.
 """
 import argparse
 import json
@@ -36,6 +37,7 @@ def main():
     ap.add_argument("--schnell", action="store_true")
     ap.add_argument("--full-step", action="store_true")
     ap.add_argument("--budget", type=float, default=25.0)
+    ap.add_argument("--full-budget", type=float, default=75.0)
     ap.add_argument("--port", action="store_true", help="force the oracle port even when /root/reference exists")
     a = ap.parse_args()
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -85,7 +87,7 @@ def main():
         t0 = time.time()
         dbl(); sgl()
         warm = time.time() - t0
-        if a.full_step:
+        if a.full_step and 0.5 * (19 + 38) * warm <= a.full_budget:
             t0 = time.time()
             for _ in range(19):
                 dbl()

@@ -161,3 +161,50 @@ def test_two_rank_pipeline_generate_matches_single_process(batch):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+# ---- bench.py: the launch paths the driver uses for N > 1, on CPU (gloo, stub engine) ---------------------------------------------------
+def _run_bench(extra, env=None, launcher=False, timeout=240):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    args = ["--backend", "gloo", "--dry-run", "--steps", "6", "--warmup", "2"] + extra
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), bench] + args
+    else:
+        cmd = [sys.executable, bench] + args
+    e = dict(os.environ, OMP_NUM_THREADS="2")
+    e.pop("RANK", None); e.pop("WORLD_SIZE", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+@pytest.mark.parametrize("launcher", [False, True], ids=["python bench.py --gpus 2", "torch.distributed.run ... bench.py --gpus 2"])
+def test_bench_multi_rank_launch_paths(launcher):
+    """`python bench.py --gpus 2` must launch its own ranks (what the round-2 driver ran: it exited with `launch with torch.distributed.run`),
+    and the documented torchrun form must keep working.  Stub engine over gloo: rendezvous on 127.0.0.1, ONE broadcast of the request, batch
+    sharding, 13 calibrating steps with the in-step amax exchange, barrier + max-over-ranks timing, exactly ONE JSON line from rank 0 with
+    the world size and backend the process group reports."""
+    r, out = _run_bench(["--gpus", "2"], launcher=launcher)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1, r.stdout
+    d = out[0]
+    assert d["n_gpus"] == 2 and d["config"]["nranks"] == 2 and d["config"]["backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["dry_run"] and d["amax_exchanges"] == 13 and d["config"]["calibration"].startswith("in-step")
+    assert d["steps"] == 6 and d["warmup"] == 2 and d["config"]["finite_output"] and d["value"] > 0
+    assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) / d["value"] < 1e-2  # whole-job aggregate
+
+
+def test_bench_single_rank_dry_run_and_failed_exchange():
+    r, out = _run_bench(["--gpus", "1"])
+    assert r.returncode == 0 and len(out) == 1 and out[0]["n_gpus"] == 1 and out[0]["config"]["backend"] is None, r.stderr[-2000:]
+    # a rank whose calibration exchange breaks must take the whole job down with a non-zero status (no silent per-rank fallback)
+    r, out = _run_bench(["--gpus", "2"], env={"FLUXMI_BENCH_FAIL_RANK": "1"}, timeout=400)
+    assert r.returncode != 0 and not out, (r.returncode, r.stdout[-500:])
+    assert "injected exchange failure" in r.stderr
