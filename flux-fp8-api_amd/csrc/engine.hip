@@ -635,6 +635,26 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
   return 0;
 }
 
+// LastLayer.forward (flux_model.py:499-503) on the img rows of x: stage 0 = (1 + scale) * LayerNorm(x) + shift -> fin (bf16; the adaLN
+// vectors are the last 2H entries of `mod`, shift first), stage 1 = the bf16 Linear hidden -> patch channels -> pred.  Never fp8
+// (float8_quantize.py:476).
+int final_layer(E* e, u16* pred, int s0, int s1, hipStream_t s) {
+  const int H = e->d.hidden, B = e->B, L = e->L, Lt = e->Lt, Li = e->Li;
+  const long long XB = (long long)L * H, MC = e->mod_cols;
+  u16 *x = buf<u16>(e, "x"), *mod = buf<u16>(e, "mod"), *fin = buf<u16>(e, "fin");
+  const u16* mf = mod + (long long)e->d.depth * 12 * H + (long long)e->d.depth_single * 3 * H;  // shift | scale
+  if (s0 <= 0 && s1 >= 0)
+    FLUXMI_TRY(fluxmi_k_ln_modulate(x + (long long)Lt * H, H, XB, fin, H, (long long)Li * H, mf, mf + H, mf, mf + H, MC, nullptr, nullptr, B,
+                                    Li, Li, H, 0, 0, s));
+  if (s0 <= 1 && s1 >= 1) {
+    const fluxmi_linear_t& l = e->lin[e->i_final_lin];
+    std::vector<FluxmiGemmGroup> gs;
+    gs.push_back(mk_group(l, fin, H, pred, l.N, B * Li));
+    FLUXMI_TRY(run_gemm(gs, l.N, H, 0, 0, FLUXMI_EPI_BF16, s));
+  }
+  return 0;
+}
+
 int require_all_f8(E* e) {
   for (int i = 0; i < e->d.depth; ++i)
     for (int sl : {D_IMG_QKV, D_IMG_PROJ, D_IMG_MLP0, D_IMG_MLP2, D_TXT_QKV, D_TXT_PROJ, D_TXT_MLP0, D_TXT_MLP2})
@@ -687,15 +707,7 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
   for (int i = 0; i < e->d.depth_single; ++i) FLUXMI_TRY(single_block(e, ctx, i, mode, trial, 0, SINGLE_STAGES - 1, s));
 
   // ---- final layer                                                                flux_model.py:499-503, 714-715
-  {
-    const u16* mf = mod + (long long)e->d.depth * 12 * H + (long long)e->d.depth_single * 3 * H;  // shift | scale
-    FLUXMI_TRY(fluxmi_k_ln_modulate(x + (long long)Lt * H, H, XB, fin, H, (long long)Li * H, mf, mf + H, mf, mf + H, MC, nullptr, nullptr, B,
-                                    Li, Li, H, 0, 0, s));
-    const fluxmi_linear_t& l = e->lin[e->i_final_lin];
-    std::vector<FluxmiGemmGroup> gs;
-    gs.push_back(mk_group(l, fin, H, pred, l.N, B * Li));
-    FLUXMI_TRY(run_gemm(gs, l.N, H, 0, 0, FLUXMI_EPI_BF16, s));
-  }
+  FLUXMI_TRY(final_layer(e, pred, 0, 1, s));
   return 0;
 }
 
@@ -1053,12 +1065,16 @@ int fluxmi_engine_set_amax_exchange(fluxmi_engine_t* e, float* amax_dev, int n, 
   return 0;
 }
 
-// One block (kind 0 = DoubleStreamBlock `index`, 1 = SingleStreamBlock `index`), stages [stage_from, stage_to], on the engine's own
+// One block (kind 0 = DoubleStreamBlock `index`, 1 = SingleStreamBlock `index`, 2 = LastLayer), stages [stage_from, stage_to], on the engine's own
 // buffers: x (and the stage's input buffer) hold whatever the caller put there with fluxmi_engine_copy_buffer, the modulation vectors
 // are read from `mod`.  Test hook for teacher-forced per-layer parity; mode as in fluxmi_engine_forward (1 fused, 2 unfused-frozen).
 int fluxmi_engine_run_block(fluxmi_engine_t* e, int kind, int index, int mode, int stage_from, int stage_to, void* stream) {
   FLUXMI_REQUIRE(e && e->ws, "engine_run_block: call fluxmi_engine_prepare first");
   FLUXMI_REQUIRE(mode == 1 || mode == 2, "engine_run_block: mode must be 1 (fused) or 2 (unfused, frozen scales)");
+  if (kind == 2) {  // LastLayer: x (img rows) + the last 2H entries of `mod` -> the engine's own `pred_s` buffer
+    FLUXMI_REQUIRE(index == 0 && stage_from >= 0 && stage_to <= 1 && stage_from <= stage_to, "engine_run_block: LastLayer has stages 0..1, index 0");
+    return final_layer(e, buf<u16>(e, "pred_s"), stage_from, stage_to, (hipStream_t)stream);
+  }
   const int nst = kind == 0 ? DOUBLE_STAGES : SINGLE_STAGES, nb = kind == 0 ? e->d.depth : e->d.depth_single;
   FLUXMI_REQUIRE((kind == 0 || kind == 1) && index >= 0 && index < nb, "engine_run_block: no block %d of kind %d", index, kind);
   FLUXMI_REQUIRE(stage_from >= 0 && stage_to < nst && stage_from <= stage_to, "engine_run_block: stages [%d, %d] out of range (0..%d)",

@@ -272,7 +272,9 @@ int fluxmi_engine_get_buffer(fluxmi_engine_t* e, const char* name, void** ptr, l
  * 1 linear1->qkv(+V^T)|cat8[:,H:], 2 K relayout, 3 attention->cat8[:,:H], 4 linear2+gate+resid->x; flux_model.py:467-485) `index`
  * on the engine's own workspace: the residual stream is buffer "x" ([B, Lt+Li, H], txt rows first), the modulation vectors are read
  * from buffer "mod" (per batch row: double block i at [i*12H, +12H) = img shift1|scale1|gate1|shift2|scale2|gate2 then txt, single
- * block i at depth*12H + i*3H = shift|scale|gate).  mode 1 = fused kernels, 2 = unfused with frozen scales.
+ * block i at depth*12H + i*3H = shift|scale|gate, LastLayer.adaLN at depth*12H + single*3H = shift|scale).  kind 2 = LastLayer (index 0;
+ * stages 0 LN+modulate of the img rows of x -> "fin", 1 bf16 Linear -> buffer "pred_s" [B, Li, in_channels]; flux_model.py:499-503).
+ * mode 1 = fused kernels, 2 = unfused with frozen scales.
  * copy_buffer: device-to-device copy between a named workspace buffer and a caller buffer (to_engine != 0 writes the workspace). */
 int fluxmi_engine_run_block(fluxmi_engine_t* e, int kind, int index, int mode, int stage_from, int stage_to, void* stream);
 int fluxmi_engine_copy_buffer(fluxmi_engine_t* e, const char* name, long long offset, void* dev_ptr, long long bytes, int to_engine,

@@ -4,10 +4,16 @@ Shared by oracle/gen_golden_full.py (build container: runs the UNMODIFIED refere
 tests/golden/g10_full_*.safetensors) and tests/test_full_geometry_gpu.py (GPU box: re-runs the oracle on the host cores, checks
 it against the committed reference samples, then checks the HIP engine against the oracle layer by layer, teacher-forced).
 
-Cases (BASELINE.json configs[1], configs[2] and the full depth):
-  c2_2p2_L4608   2 double + 2 single blocks, 1024x1024 (Li 4096) + Lt 512, quantize_modulation, embedders in bf16
-  c3_2p2_L2816   2 + 2 blocks, 768x768 (Li 2304) + Lt 512, quantize_modulation + quantize_flow_embedder_layers
+Cases (one per BASELINE.json config, plus the full depth and the loop):
+  c2_2p2_L4608   2 double + 2 single blocks, 1024x1024 (Li 4096) + Lt 512, quantize_modulation, embedders in bf16       configs[1]
+  c3_2p2_L2816   2 + 2 blocks, 768x768 (Li 2304) + Lt 512, quantize_modulation + quantize_flow_embedder_layers           configs[2]
   c2_19p38_L320  the whole 19 + 38-block model, 256x256 (Li 256) + Lt 64 (fp8 error accumulation through 57 residual blocks)
+  c1_schnell_bf16_19p38_L512  Flux-schnell (no guidance embedder), ALL 19 + 38 blocks, 256x256 (Li 256) + Lt 256, bf16 nn.Linear everywhere
+                 (no fp8): configs[0] at its real geometry and depth; the checkpoint is c2_19p38_L320's minus guidance_in
+  c4_B2_1p1_L4608  1 + 1 blocks of c2_2p2_L4608's model on a batch of TWO different samples in one call (batch strides at L = 4608)  configs[3]
+  c5_lora_2p2_L4608  c2_2p2_L4608's model with a rank-16 LoRA on every attention / MLP linear (fused-qkv layers in the reference's "uneven
+                 rank" form) fused into the fp8 weights at scale 1.0 AFTER calibration (lora_loading.py:509-577,635-693)  configs[4]
+  c2_loop4_2p2_L4608  c2_2p2_L4608's model: one calibrating call, then a 4-step frozen Euler loop (flux_pipeline.py:619-651)
 Protocol per case: call 1 calibrates (every F8Linear takes its first amax trial, float8_quantize.py:220-238), the input scales are
 then frozen (`input_scale_initialized = True`, what the reference does after its 13th call, :239-246) and call 2 runs frozen with
 every intermediate recorded.  A full tensor at L = 4608 is tens of MB, so fixtures hold SAMPLES (first 256 + 768 evenly strided
@@ -29,7 +35,23 @@ CASES = {
                          w_seed=12, in_seed=22, trace="all"),
     "c2_19p38_L320": dict(depth=19, single=38, height=256, width=256, txt_len=64, quant=dict(modulation=True, embedders=False),
                           w_seed=13, in_seed=23, trace="blocks"),
-    # harness check only (no fixture): the same test code on a model that runs in a second
+    "c1_schnell_bf16_19p38_L512": dict(depth=19, single=38, height=256, width=256, txt_len=256, quant=None, w_seed=13, in_seed=25, trace="blocks",
+                                       params=dict(guidance_embed=False), schnell=True, sd_from="c2_19p38_L320"),
+    "c4_B2_1p1_L4608": dict(depth=1, single=1, height=1024, width=1024, txt_len=512, quant=dict(modulation=True, embedders=False),
+                            w_seed=11, in_seed=26, trace="blocks", batch=2),
+    "c5_lora_2p2_L4608": dict(depth=2, single=2, height=1024, width=1024, txt_len=512, quant=dict(modulation=True, embedders=False),
+                              w_seed=11, in_seed=21, trace="blocks", lora=dict(rank=16, seed=5)),
+    "c2_loop4_2p2_L4608": dict(depth=2, single=2, height=1024, width=1024, txt_len=512, quant=dict(modulation=True, embedders=False),
+                               w_seed=11, in_seed=21, trace="none", loop_steps=4),
+    # harness checks only (no fixture): the same test code on models that run in a second
+    "tiny_schnell_bf16_L48": dict(depth=2, single=2, height=64, width=64, txt_len=32, quant=None, w_seed=15, in_seed=27, trace="blocks", schnell=True,
+                                  params=dict(hidden_size=256, num_heads=2, context_in_dim=128, vec_in_dim=64, guidance_embed=False)),
+    "tiny_B2_L96": dict(depth=2, single=2, height=128, width=128, txt_len=32, quant=dict(modulation=True, embedders=False), w_seed=14, in_seed=28,
+                        trace="blocks", batch=2, params=dict(hidden_size=256, num_heads=2, context_in_dim=128, vec_in_dim=64)),
+    "tiny_lora_L96": dict(depth=2, single=2, height=128, width=128, txt_len=32, quant=dict(modulation=True, embedders=False), w_seed=14, in_seed=24,
+                          trace="blocks", lora=dict(rank=4, seed=6), params=dict(hidden_size=256, num_heads=2, context_in_dim=128, vec_in_dim=64)),
+    "tiny_loop4_L96": dict(depth=2, single=2, height=128, width=128, txt_len=32, quant=dict(modulation=True, embedders=False), w_seed=14, in_seed=24,
+                           trace="none", loop_steps=4, params=dict(hidden_size=256, num_heads=2, context_in_dim=128, vec_in_dim=64)),
     "tiny_2p2_L96": dict(depth=2, single=2, height=128, width=128, txt_len=32, quant=dict(modulation=True, embedders=False),
                          w_seed=14, in_seed=24, trace="all",
                          params=dict(hidden_size=256, num_heads=2, context_in_dim=128, vec_in_dim=64)),
@@ -42,13 +64,74 @@ def params_for(case: dict) -> fo.FluxParams:
     return fo.FluxParams(depth=case["depth"], depth_single_blocks=case["single"], **case.get("params", {}))
 
 
+_SD_CACHE: Dict[tuple, Dict[str, torch.Tensor]] = {}  # full-depth checkpoints take minutes to synthesise: shared between cases of one process
+
+
+def drop_sd_cache():
+    _SD_CACHE.clear()
+
+
 def make_case(name: str, synth):
-    """-> (case dict, FluxParams, state dict (CPU bf16), inputs dict).  `synth` = the fluxmi.synth module."""
+    """-> (case dict, FluxParams, state dict (CPU bf16), inputs dict).  `synth` = the fluxmi.synth module.  Nobody may modify the
+    returned tensors in place (cases share checkpoints)."""
     case = CASES[name]
     p = params_for(case)
-    sd = synth.make_state_dict(p, seed=case["w_seed"])
-    inp = synth.make_inputs(p, case["height"], case["width"], case["txt_len"], batch=1, seed=case["in_seed"], real_tokens=32)
+    if case.get("sd_from"):
+        base = CASES[case["sd_from"]]
+        bp = params_for(base)
+        assert (bp.depth, bp.depth_single_blocks, bp.hidden_size) == (p.depth, p.depth_single_blocks, p.hidden_size) and base["w_seed"] == case["w_seed"]
+        key = (case["sd_from"], base["w_seed"])
+        if key not in _SD_CACHE:
+            _SD_CACHE[key] = synth.make_state_dict(bp, seed=base["w_seed"])
+        sd = {k: v for k, v in _SD_CACHE[key].items() if p.guidance_embed or not k.startswith("guidance_in.")}
+    else:
+        key = (name if p.depth >= 19 else None, case["w_seed"])
+        if key[0] is not None:
+            if key not in _SD_CACHE:
+                _SD_CACHE[key] = synth.make_state_dict(p, seed=case["w_seed"])
+            sd = dict(_SD_CACHE[key])
+        else:
+            sd = synth.make_state_dict(p, seed=case["w_seed"])
+    inp = synth.make_inputs(p, case["height"], case["width"], case["txt_len"], batch=case.get("batch", 1), seed=case["in_seed"], real_tokens=32)
     return case, p, sd, inp
+
+
+def make_lora(p, rank: int, seed: int) -> Dict[str, torch.Tensor]:
+    """rank-`rank` LoRA on every attention / MLP linear (BFL-dotted keys = what Flux.load_lora takes as a dict, lora_loading.py:608-612):
+    the fused qkv layers get the reference's "uneven rank" form A [3r, K], B [3N', r] (lora_loading.py:533-541)."""
+    g = torch.Generator().manual_seed(seed)
+    H, Hm = p.hidden_size, int(p.hidden_size * p.mlp_ratio)
+    lora = {}
+
+    def add(name, N, K, uneven=False):
+        lora[name + ".lora_A.weight"] = torch.randn((3 if uneven else 1) * rank, K, generator=g) * 0.02
+        lora[name + ".lora_B.weight"] = torch.randn(N, rank, generator=g) * 0.02
+
+    for i in range(p.depth):
+        for s in ("img", "txt"):
+            add(f"double_blocks.{i}.{s}_attn.qkv", 3 * H, H, True)
+            add(f"double_blocks.{i}.{s}_attn.proj", H, H)
+            add(f"double_blocks.{i}.{s}_mlp.0", Hm, H)
+            add(f"double_blocks.{i}.{s}_mlp.2", H, Hm)
+    for i in range(p.depth_single_blocks):
+        add(f"single_blocks.{i}.linear1", 3 * H + Hm, H)
+        add(f"single_blocks.{i}.linear2", H, H + Hm)
+    return lora
+
+
+def add_lora_weight_entries(tr: dict, orc, p, case) -> None:
+    """LoRA cases: the fused + re-quantised fp8 weights themselves become part of the digest ("w8:<layer>")."""
+    if not case.get("lora"):
+        return
+    keys = make_lora(p, **case["lora"])
+    for nm, st in orc.lin.items():
+        if isinstance(st, fo.F8LinearState) and (nm + ".lora_A.weight") in keys:
+            dict.__setitem__(tr, "w8:" + nm, st.float8_data)
+
+
+def loop_schedule(case) -> list:
+    Li = (case["height"] // 16) * (case["width"] // 16)
+    return fo.get_schedule(case["loop_steps"], Li, shift=not case.get("schnell", False))
 
 
 def call_args(inp, t: float):
@@ -65,13 +148,16 @@ class FilteredTrace(dict):
         self.mode = mode
 
     def __setitem__(self, k, v):
+        if self.mode == "none":
+            return
         if self.mode == "all" or k in ("vec", "pe", "img_in.out", "txt_in.out") or k.endswith((".img_out", ".txt_out")) or (
                 k.startswith("single_blocks") and k.endswith(".out") and k.count(".") == 2):
             super().__setitem__(k, v)
 
 
 def run_oracle(name: str, p, sd, inp, log=print):
-    """calibrating call, freeze, traced frozen call.  -> (oracle, pred_calib, pred_frozen, trace)"""
+    """calibrating call, freeze, [fuse the case's LoRA], traced frozen call, [the case's frozen Euler loop].
+    -> (oracle, pred_calib, pred_frozen, trace); the loop's final latents are trace["loop_latents"]."""
     case = CASES[name]
     t0 = time.time()
     orc = fo.FluxOracle(sd, p, quantize=case["quant"])
@@ -80,11 +166,21 @@ def run_oracle(name: str, p, sd, inp, log=print):
     with torch.inference_mode():
         pred0 = orc.forward(*call_args(inp, T_CALIB))
         log(f"[{name}] oracle calibrating call {time.time() - t0:.1f} s")
-        orc.freeze_input_scales()
+        if case["quant"] is not None:
+            orc.freeze_input_scales()
+        if case.get("lora"):
+            t0 = time.time()
+            orc.fuse_lora(make_lora(p, **case["lora"]), 1.0)  # no input-scale recalibration after fusing, as in the reference
+            log(f"[{name}] oracle LoRA fuse {time.time() - t0:.1f} s")
         tr = FilteredTrace(case["trace"])
         t0 = time.time()
         pred1 = orc.forward(*call_args(inp, T_FROZEN), trace=tr)
         log(f"[{name}] oracle frozen call {time.time() - t0:.1f} s, {len(tr)} tensors recorded")
+        if case.get("loop_steps"):
+            t0 = time.time()
+            lat = fo.denoise(orc, inp["img"], inp["img_ids"], inp["txt"], inp["txt_ids"], inp["y"], loop_schedule(case), guidance=GUIDANCE)
+            dict.__setitem__(tr, "loop_latents", lat)
+            log(f"[{name}] oracle {case['loop_steps']}-step frozen Euler loop {time.time() - t0:.1f} s")
     return orc, pred0, pred1, tr
 
 

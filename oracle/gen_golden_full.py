@@ -33,18 +33,36 @@ import synth
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
-def build_ref(p, sd, quant):
-    cfg = rutil.load_config(rutil.ModelVersion.flux_dev, flow_dtype="bfloat16")
+def build_ref(p, sd, quant, schnell=False):
+    cfg = rutil.load_config(rutil.ModelVersion.flux_schnell if schnell else rutil.ModelVersion.flux_dev, flow_dtype="bfloat16")
     cfg.params.depth, cfg.params.depth_single_blocks = p.depth, p.depth_single_blocks
+    assert cfg.params.guidance_embed == p.guidance_embed
     with torch.device("meta"):
         m = fm.Flux(cfg, dtype=torch.bfloat16)
         m.type(torch.bfloat16)
     m.load_state_dict(sd, strict=True, assign=True)
     m.eval()
-    f8q.quantize_flow_transformer_and_dispatch_float8(
-        m, torch.device("cpu"), flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
-        quantize_modulation=quant["modulation"], quantize_flow_embedder_layers=quant["embedders"])
+    if quant is not None:  # (quant None = the reference's bf16 flow: plain nn.Linear everywhere)
+        f8q.quantize_flow_transformer_and_dispatch_float8(
+            m, torch.device("cpu"), flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
+            quantize_modulation=quant["modulation"], quantize_flow_embedder_layers=quant["embedders"])
     return m
+
+
+def ref_loop(ref, inp, timesteps, guidance):
+    """the denoise loop of FluxPipeline.generate, flux_pipeline.py:619-651, around the unmodified model"""
+    img = inp["img"]
+    guidance_vec = torch.full((img.shape[0],), guidance, dtype=torch.bfloat16)
+    t_vec = None
+    for t_curr, t_prev in zip(timesteps[:-1], timesteps[1:]):
+        if t_vec is None:
+            t_vec = torch.full((img.shape[0],), t_curr, dtype=torch.bfloat16)
+        else:
+            t_vec = t_vec.reshape((img.shape[0],)).fill_(t_curr)
+        pred = ref.forward(img=img, img_ids=inp["img_ids"], txt=inp["txt"], txt_ids=inp["txt_ids"], y=inp["y"], timesteps=t_vec,
+                           guidance=guidance_vec)
+        img = img + (t_prev - t_curr) * pred
+    return img
 
 
 @torch.inference_mode()
@@ -52,7 +70,7 @@ def run_case(name):
     t_all = time.time()
     case, p, sd, inp = fg.make_case(name, synth)
     print(f"[{name}] synthetic checkpoint: {sum(v.numel() for v in sd.values()) / 1e9:.2f} B parameters ({time.time() - t_all:.0f} s)", flush=True)
-    ref = build_ref(p, sd, case["quant"])
+    ref = build_ref(p, {k: v for k, v in sd.items()}, case["quant"], schnell=case.get("schnell", False))
     print(f"[{name}] reference built + quantised ({time.time() - t_all:.0f} s)", flush=True)
     got = {}
 
@@ -87,10 +105,20 @@ def run_case(name):
     for mod in ref.modules():
         if isinstance(mod, f8q.F8Linear):
             mod.input_scale_initialized = True  # freeze after one trial (float8_quantize.py:273: forward now bypasses quantize_input)
-    recording[0] = True
+    if case.get("lora"):
+        t0 = time.time()
+        ref.load_lora({k: v.clone() for k, v in fg.make_lora(p, **case["lora"]).items()}, 1.0, name="c5")  # Flux.load_lora -> apply_lora_to_model
+        print(f"[{name}] reference LoRA fused into the fp8 weights ({time.time() - t0:.0f} s)", flush=True)
+    recording[0] = case["trace"] != "none"
     t0 = time.time()
     r1 = ref(*fg.call_args(inp, fg.T_FROZEN))
     print(f"[{name}] reference frozen call {time.time() - t0:.0f} s, {len(got)} intermediates hooked", flush=True)
+    recording[0] = False
+    r_loop = None
+    if case.get("loop_steps"):
+        t0 = time.time()
+        r_loop = ref_loop(ref, inp, fg.loop_schedule(case), fg.GUIDANCE)
+        print(f"[{name}] reference {case['loop_steps']}-step Euler loop {time.time() - t0:.0f} s", flush=True)
 
     orc, o0, o1, tr = fg.run_oracle(name, p, sd, inp, log=lambda m: print(m, flush=True))
     assert torch.equal(r0, o0), f"{name}: calibrating prediction differs"
@@ -106,8 +134,14 @@ def run_case(name):
     assert not missing, missing[:5]
     for k, v in got.items():
         assert torch.equal(v.reshape(tr[k].shape), tr[k]), f"{name}: {k} differs from the reference"
-    print(f"[{name}] oracle == reference bit for bit: 2 predictions, {len(got)} intermediates, {n_lin} F8Linear states", flush=True)
+    if r_loop is not None:
+        assert torch.equal(r_loop, tr["loop_latents"]), f"{name}: loop latents differ from the reference"
+    print(f"[{name}] oracle == reference bit for bit: 2 predictions, {len(got)} intermediates, {n_lin} F8Linear states"
+          + (" (fp8 weight bytes + scales AFTER the LoRA fuse)" if case.get("lora") else "") + (f", the latents after {case['loop_steps']} Euler steps" if r_loop is not None else ""),
+          flush=True)
+    tr = dict(tr)
     tr["pred_calib"], tr["pred_frozen"] = o0, o1
+    fg.add_lora_weight_entries(tr, orc, p, case)  # the fused + re-quantised weights themselves go into the fixture (samples + checksums)
     names = sorted(n for n, m in orc.lin.items() if isinstance(m, fo.F8LinearState))
     dg = fg.digest(tr)
     dg["input_scales"] = torch.tensor([orc.lin[n].input_scale.item() for n in names], dtype=torch.float32)

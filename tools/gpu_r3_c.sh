@@ -1,8 +1,9 @@
 #!/bin/bash
-# round 3, GPU batch C: new host-surface tests (reference configs, engine batch > 8) + engine timing window
+# round 3, GPU batch C: real-geometry parity additions (selected by $1, default: the tiny harness twins)
 cd "$GRAFT_REPO_ROOT" || exit 1
-rm -rf gpurun_out/r3c; mkdir -p gpurun_out/r3c
+mkdir -p gpurun_out/r3c
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_engine_gpu.py -x -q -k "reference_config or pipeline_generate_latents or prequantized or denoise_loop or batch_sharded" > gpurun_out/r3c/pytest.log 2>&1
-echo "rc=$?" >> gpurun_out/r3c/pytest.log
-tail -15 gpurun_out/r3c/pytest.log
+SEL=${1:-tiny}
+timeout 3000 python -m pytest tests/test_full_geometry_gpu.py -x -q -s -k "$SEL" > gpurun_out/r3c/pytest_$2.log 2>&1
+echo "rc=$?" >> gpurun_out/r3c/pytest_$2.log
+grep -E "^\[|  ok |  BAD|  -- |passed|failed|rc=|Error|error" gpurun_out/r3c/pytest_$2.log | tail -70
