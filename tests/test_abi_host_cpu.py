@@ -405,3 +405,36 @@ def test_list_prompt_sizes_the_batch():
         assert calls[-1] == ("one prompt", 3) and vec.shape[0] == 3
     finally:
         flux_emphasis.get_weighted_text_embeddings_flux = old
+
+
+def test_diffusers_lora_key_conversion_matches_reference_fixture():
+    """lora_loading.convert_diffusers_to_flux_transformer_checkpoint / resolve_lora_state_dict against the outputs of the UNMODIFIED reference
+    functions (lora_loading.py:62-432,580-606) on synthetic diffusers-format LoRA dicts (oracle/gen_golden_lora_diffusers.py): same key set,
+    same tensors, same row order of the fused qkv / linear1 concatenations, zero-filled missing members, untouched `.alpha` leftovers, and the
+    guidance embedder left unconverted for flux-schnell.  Missing single-block members raise KeyError like the reference."""
+    import torch
+    from safetensors.torch import load_file
+
+    import lora_loading as ll
+
+    fx = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_lora_diffusers.safetensors"))
+    for name, has_guidance, src in (("full", True, "full"), ("sparse", True, "sparse"), ("noguidance", False, "full")):
+        inp = {k[len(src) + 4:]: v for k, v in fx.items() if k.startswith(src + ":in:")}
+        want = {k[len(name) + 5:]: v for k, v in fx.items() if k.startswith(name + ":out:")}
+        assert inp and want
+        keys, got = ll.resolve_lora_state_dict({k: v.clone() for k, v in inp.items()}, has_guidance=has_guidance)
+        assert set(got) == set(want), (name, sorted(set(got) ^ set(want))[:6])
+        for k in want:
+            assert got[k].shape == want[k].shape and torch.equal(got[k], want[k]), (name, k)
+        if name != "noguidance":
+            assert len(keys) == int(fx[f"{name}:n_keys_without_ab"])
+        # what apply_lora_to_model will see: fused qkv in the uneven-rank form, linear1 with four chunks
+        a, b = got["double_blocks.0.img_attn.qkv.lora_A.weight"], got["double_blocks.0.img_attn.qkv.lora_B.weight"]
+        assert a.shape[0] == 3 * b.shape[1] and got["single_blocks.0.linear1.lora_A.weight"].shape[0] == 4 * got["single_blocks.0.linear1.lora_B.weight"].shape[1]
+    broken = {k[8:]: v for k, v in fx.items() if k.startswith("full:in:") and "single_transformer_blocks.3.attn.to_k" not in k}
+    with pytest.raises(KeyError):
+        ll.resolve_lora_state_dict(broken, has_guidance=True)
+    # kohya files keep working through the same entry point
+    _, k2 = ll.resolve_lora_state_dict({"lora_unet_double_blocks_0_img_attn_qkv.lora_down.weight": torch.zeros(2, 4),
+                                        "lora_unet_single_blocks_1_linear2.lora_up.weight": torch.zeros(4, 2), "not_a_lo_ra_key": torch.zeros(1)})
+    assert set(k2) == {"double_blocks.0.img_attn.qkv.lora_A.weight", "single_blocks.1.linear2.lora_B.weight"}

@@ -627,7 +627,7 @@ def test_lora_fuse(ops, dev):
     torch.manual_seed(12)
     N, K, R = 384, 256, 16
     w = (torch.randn(N, K) * 0.05).bfloat16()
-    for chunks in (1, 3):
+    for chunks in (1, 3, 4):  # 1 = plain, 3 = fused qkv ("uneven rank"), 4 = single-block linear1 from a diffusers-format file (q|k|v|mlp)
         st = fo.F8LinearState(w, None)
         A = torch.randn(chunks * R, K) * 0.1
         Bm = torch.randn(N, R) * 0.1
