@@ -29,17 +29,18 @@ int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8) {
   }
   if (forced >= 0 && fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, forced)) return forced;
   // candidates, in order of preference at equal cost; eff = measured relative rate per flop on MI355X at full occupancy
-  // (profiles/r01_kernel_sweep.txt): 13 = 256x256 ping-pong ring (1 block/CU), 2 = 128x128 double-buffered (2 blocks/CU),
-  // 1 = 256x128, 3 = 128x256, 0 = 256x256 double-buffered, 15 = 128x64 (narrow N).  Cost = (number of block waves) x (time of one wave of blocks).
+  // (profiles/r01_kernel_sweep.txt): 13 = 256x256 ping-pong ring (1 block/CU), 2 = 128x128 double-buffered (2 blocks/CU), 15 = 128x64
+  // (narrow N).  Cost = (number of block waves) x (time of one wave of blocks).
   // 16 = 256x256 with ONE wave per SIMD (128x128 wave tiles): the leaner main loop wins once K is long enough to amortise its
   // twice-as-long per-wave epilogue (measured +6 % at K = 15360, -5 % at K = 3072)
   const bool long_k = (long long)p.K * (is_fp8 ? 1 : 2) >= 8192;
-  static const int cand[7] = {13, 16, 2, 1, 3, 0, 15};
-  const double eff[7] = {1.00, long_k ? 1.06 : 0.94, 0.84, 0.78, 0.78, 0.80, 0.30};
-  static const int occ[7] = {1, 1, 2, 1, 1, 1, 3};
+  constexpr int NC = 4;
+  static const int cand[NC] = {13, 16, 2, 15};
+  const double eff[NC] = {1.00, long_k ? 1.06 : 0.94, 0.84, 0.30};
+  static const int occ[NC] = {1, 1, 2, 3};
   int best = -1;
   double best_cost = 1e300;
-  for (int ci = 0; ci < 7; ++ci) {
+  for (int ci = 0; ci < NC; ++ci) {
     const int c = cand[ci];
     if (!fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, c)) continue;
     const int bm = fluxmi_gemm_tile_bm(c), bn = fluxmi_gemm_tile_bn(c);

@@ -297,10 +297,7 @@ int launch_tile(FluxmiGemmParams& p, hipStream_t s) {
 template <bool FP8, int ACT>
 int launch_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
   switch (cfg) {
-    case 0: return launch_tile<256, 256, 2, 4, FP8, ACT>(p, s);
-    case 1: return launch_tile<256, 128, 4, 2, FP8, ACT>(p, s);
-    case 2: return launch_tile<128, 128, 2, 2, FP8, ACT>(p, s);
-    case 3: return launch_tile<128, 256, 2, 4, FP8, ACT>(p, s);
+    case 2: return launch_tile<128, 128, 2, 2, FP8, ACT>(p, s);  // two workgroups per CU: thin launches, N % 256 != 0
     case 15: return launch_tile<128, 64, 4, 1, FP8, ACT>(p, s);  // narrow outputs (LastLayer.linear: N = 64)
     default: fluxmi_set_error("gemm: unknown tile config %d", cfg); return 1;
   }
@@ -308,26 +305,21 @@ int launch_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
 
 }  // namespace
 
-// tile configs: 0..3 = double-buffered kernels of this file, 4..6 = ring kernels of gemm_ring.hip
-static const int kTileBN[17] = {256, 128, 128, 256, 256, 128, 128, 256, 128, 256, 128, 256, 256, 256, 256, 64, 256};
-static const int kTileBM[17] = {256, 256, 128, 128, 256, 256, 128, 256, 256, 128, 256, 256, 256, 256, 256, 128, 256};
-#define FLUXMI_N_CFG 17
+// tile configs (the numbers are part of the C ABI, fluxmi_gemm_grouped): 2 = 128x128 and 15 = 128x64 double-buffered kernels of this
+// file, 13 = 256x256 ping-pong ring (gemm_ring.hip), 16 = 256x256 one wave per SIMD (gemm_w1.hip), 100 = generic.  The other numbers
+// belonged to kernel generations that were measured slower and removed in round 3 (profiles/r01_kernel_sweep.txt, r02_gemm_ab.txt).
 int fluxmi_launch_gemm_ring(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s);
 int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
 
-int fluxmi_gemm_tile_bn(int cfg) { return (cfg >= 0 && cfg < FLUXMI_N_CFG) ? kTileBN[cfg] : 0; }
-int fluxmi_gemm_tile_bm(int cfg) { return (cfg >= 0 && cfg < FLUXMI_N_CFG) ? kTileBM[cfg] : 0; }
+int fluxmi_gemm_tile_bn(int cfg) { return cfg == 2 ? 128 : cfg == 15 ? 64 : (cfg == 13 || cfg == 16) ? 256 : 0; }
+int fluxmi_gemm_tile_bm(int cfg) { return (cfg == 2 || cfg == 15) ? 128 : (cfg == 13 || cfg == 16) ? 256 : 0; }
 
 int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg) {
-#ifdef FLUXMI_EXPERIMENTS
-  if (cfg >= 20 && cfg < 36) cfg = 4;  // ablation variants of the 256x256 ring
-#else
-  if (cfg == 7 || cfg == 9 || cfg == 10 || cfg == 11 || cfg == 14) return 0;  // experimental variants, not built
-#endif
-  if (cfg < 0 || cfg >= FLUXMI_N_CFG) return 0;
+  const int bn = fluxmi_gemm_tile_bn(cfg);
+  if (!bn) return 0;
   const int kb = K * (is_fp8 ? 1 : 2);
-  const int kstep = cfg == 16 ? 256 : (cfg >= 4 && cfg != 15) ? 64 : 128;
-  return (N % kTileBN[cfg] == 0) && (kb % kstep == 0) && kb >= kstep;
+  const int kstep = cfg == 16 ? 256 : cfg == 13 ? 64 : 128;
+  return (N % bn == 0) && (kb % kstep == 0) && kb >= kstep;
 }
 
 int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s) {
@@ -337,9 +329,9 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
     FLUXMI_REQUIRE(p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0, "gemm: split_n=%d must be a multiple of the N tile", p.g[0].split_n);
   for (int i = 0; i < p.n_groups; ++i)
     if (p.g[i].vt_out || p.g[i].k_out)
-      FLUXMI_REQUIRE((cfg >= 11 && cfg <= 14) || cfg == 16, "gemm: fused K / V^T outputs exist only in tile configs 13 and 16 (got %d)", cfg);
+      FLUXMI_REQUIRE(cfg == 13 || cfg == 16, "gemm: fused K / V^T outputs exist only in tile configs 13 and 16 (got %d)", cfg);
   if (cfg == 16) return fluxmi_launch_gemm_w1(p, is_fp8, act_fmt, s);
-  if (cfg >= 4 && cfg != 15) return fluxmi_launch_gemm_ring(p, is_fp8, act_fmt, cfg, s);
+  if (cfg == 13) return fluxmi_launch_gemm_ring(p, is_fp8, act_fmt, cfg, s);
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) return launch_cfg<true, FLUXMI_FMT_E5M2>(p, cfg, s);
     return launch_cfg<true, FLUXMI_FMT_E4M3>(p, cfg, s);

@@ -1,211 +1,19 @@
-// fluxmi -- "ring" GEMM: the deep-pipelined tile kernel for the big F8Linear GEMMs (gfx950).
+// fluxmi -- "ping-pong" GEMM: the deep-pipelined 256x256 tile kernel for the F8Linear GEMMs with K < 8192 bytes (gfx950).
 //
 // Same math, operands, grouping and epilogues as gemm.hip; different pipeline:
-//  * K-step = 64 BYTES of every row (one v_mfma_scale_f32_32x32x64_f8f6f4 deep), 4-stage LDS ring
-//    (256x256 tile: 4 x 32 KiB = 128 KiB), filled by LDS-DMA three K-steps ahead;
-//  * counted `s_waitcnt vmcnt(N)` + raw s_barrier: the loads of the NEXT-next tile stay in flight across
-//    every barrier (hipcc's __syncthreads would drain them), nothing but the tile needed next is waited for;
-//  * fragments of K-step k+1 are read from LDS into a second register set while the MFMAs of K-step k run,
-//    so the only latency left after a barrier is hidden behind 8-16 MFMAs;
-//  * epilogue through LDS: each wave parks its bf16 tile in the (now idle) ring, then every lane handles
-//    8 consecutive columns of one row: residual / gate / bias vectors are 16 B coalesced loads and the
-//    output leaves as full 128 B lines (the direct accumulator layout gives 8 B pieces at a 6 KB stride).
-// LDS rows are 64 B (4 x 16 B slots); bank-conflict-free ds_read_b128 needs slot ^= (row >> 2) & 3, applied on
-// the DMA source address and on the read address.
+//  * K-step = 64 BYTES of every row (one v_mfma_scale_f32_32x32x64_f8f6f4 deep), 4-stage LDS ring (4 x 32 KiB = 128 KiB), filled by
+//    LDS-DMA three K-steps ahead;
+//  * counted `s_waitcnt vmcnt(N)` + raw s_barrier: the loads of the NEXT-next tile stay in flight across every barrier (hipcc's
+//    __syncthreads would drain them), nothing but the tile needed next is waited for;
+//  * epilogue through LDS: each wave parks its bf16 tile in the (now idle) ring, then every lane handles 8 consecutive columns of one
+//    row: residual / gate / bias vectors are 16 B coalesced loads and the output leaves as full 128 B lines (the direct accumulator
+//    layout gives 8 B pieces at a 6 KB stride).
+// LDS rows are 64 B (4 x 16 B slots); bank-conflict-free ds_read_b128 needs slot ^= (row >> 2) & 3, applied on the DMA source address
+// and on the read address.  (Rounds 1-2 also carried a lock-step ring kernel in five tile shapes, a two-workgroups-per-CU variant and
+// timing-only ablations of it: measured slower everywhere -- profiles/r01_gemm_ablation*.txt, r02_gemm_ab.txt -- and removed in round 3.)
 #include "gemm_epilogue.h"
 
 namespace {
-
-template <int BM, int BN, int WM, int WN, int NS, bool SPREAD, bool FP8, int ACT_FMT, int ABL = 0>
-__global__ void __launch_bounds__(WM* WN * 64, (NS == 3 ? 2 : 1) * WM * WN / 4) gemm_ring_kernel(const FluxmiGemmParams P) {
-  constexpr int NT = WM * WN * 64;
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int D = NS - 1;                               // prefetch distance (K-steps in flight)
-  constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
-  constexpr int IA = (BM * 4) / NT, IW = (BN * 4) / NT;   // 16-B slots per thread per K-step
-  constexpr int LPT = IA + IW;                            // LDS-DMA loads per thread per K-step
-  constexpr int EB = FP8 ? 1 : 2;
-  static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0, "tile/threads mismatch");
-  static_assert(NS * STAGE >= WM * WN * WTM * WTN * 2, "ring too small for the epilogue tile");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int l31 = lane & 31, hi = lane >> 5;
-
-  const int tiles_n = P.N / BN;
-  const int nblk = P.tiles_m_total * tiles_n;
-  const int lid = xcd_remap(blockIdx.x, nblk);
-  const int width = P.group_m * tiles_n;
-  const int first_m = (lid / width) * P.group_m;
-  const int gsz = min(P.tiles_m_total - first_m, P.group_m);
-  const int tm = first_m + (lid % width) % gsz;
-  const int tn = (lid % width) / gsz;
-  int gi = 0;
-  for (int i = 1; i < P.n_groups; ++i) gi = (tm >= P.g[i].m_tile_start) ? i : gi;
-  const FluxmiGemmGroup& G = P.g[gi];
-  const int M = G.M;
-  const int m0 = (tm - G.m_tile_start) * BM;
-  const int n0 = tn * BN;
-  const int nk = (P.K * EB) / 64;
-
-  const unsigned char* srcA[IA];
-  const unsigned char* srcW[IW];
-#pragma unroll
-  for (int i = 0; i < IA; ++i) {
-    const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-    const int gr = min(m0 + row, M - 1);
-    srcA[i] = (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16;
-  }
-#pragma unroll
-  for (int i = 0; i < IW; ++i) {
-    const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-    srcW[i] = (const unsigned char*)G.W + ((long long)(n0 + row) * P.K) * EB + slot * 16;
-  }
-  // LDS-DMA loads [from, to) of the LPT loads that bring K-step kt into ring slot kt % NS
-  auto stage_part = [&](int kt, int slot, int from, int to) {
-    unsigned char* dA = smem + slot * STAGE + wave * 1024;
-    unsigned char* dW = dA + A_BYTES;
-    const long long koff = (long long)kt * 64;
-#pragma unroll
-    for (int i = 0; i < IA; ++i)
-      if (i >= from && i < to) glds16(srcA[i] + koff, dA + NT * 16 * i);
-#pragma unroll
-    for (int i = 0; i < IW; ++i)
-      if (IA + i >= from && IA + i < to) glds16(srcW[i] + koff, dW + NT * 16 * i);
-  };
-  auto stage = [&](int kt) { stage_part(kt, kt % NS, 0, LPT); };
-
-  v16f acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // Fragment addresses inside a stage: row*64 + swizzled 16-B slot.  Rows of successive 32-row MFMA tiles are 2048 B
-  // apart and share the swizzle key ((row>>2)&3 is unchanged by +32), so ONE base per operand and half suffices; the tile
-  // index goes into the ds_read immediate offset.
-  int a_lo, a_hi, w_lo, w_hi;
-  {
-    const int ra = wm * WTM + l31, ka = (ra >> 2) & 3;
-    a_lo = ra * 64 + (((hi * 2) ^ ka) << 4);
-    a_hi = ra * 64 + (((hi * 2 + 1) ^ ka) << 4);
-    const int rw = wn * WTN + l31, kw = (rw >> 2) & 3;
-    w_lo = A_BYTES + rw * 64 + (((hi * 2) ^ kw) << 4);
-    w_hi = A_BYTES + rw * 64 + (((hi * 2 + 1) ^ kw) << 4);
-  }
-  auto read_a = [&](int slot, int i) -> v8i {
-    const unsigned char* sb = smem + slot * STAGE + i * 2048;
-    const v4i lo = *(const v4i*)(sb + a_lo), h4 = *(const v4i*)(sb + a_hi);
-    return (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
-  };
-  auto read_w = [&](int slot, int j) -> v8i {
-    const unsigned char* sb = smem + slot * STAGE + j * 2048;
-    const v4i lo = *(const v4i*)(sb + w_lo), h4 = *(const v4i*)(sb + w_hi);
-    return (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
-  };
-  // one row of MFMA tiles: acc[i][*] += W frags x A frag.  bf16: the 32 B operand is two K=16 operands (lo/hi halves);
-  // any consistent k -> (lane-half, slot) assignment is valid because A and W use the same one.
-  auto mma_row = [&](int i, const v8i& fa, const v8i (&fw)[TN]) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      if constexpr (FP8) {
-        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[j], fa, acc[i][j], FLUXMI_FMT_E4M3, ACT_FMT, 0, 0x7f7f7f7f, 0,
-                                                                  0x7f7f7f7f);
-      } else {
-        const v4i alo = (v4i){fa[0], fa[1], fa[2], fa[3]}, ahi = (v4i){fa[4], fa[5], fa[6], fa[7]};
-        const v4i wlo = (v4i){fw[j][0], fw[j][1], fw[j][2], fw[j][3]}, whi = (v4i){fw[j][4], fw[j][5], fw[j][6], fw[j][7]};
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, wlo), __builtin_bit_cast(v8bf, alo), acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, whi), __builtin_bit_cast(v8bf, ahi), acc[i][j], 0, 0, 0);
-      }
-    }
-  };
-
-  // ---- prologue: three K-steps in flight; W fragments + first A fragment of step 0 in registers ------------------------
-  stage(0);
-  if (nk > 1) stage(1);
-  if (D > 2 && nk > 2) stage(2);
-  if (D > 2 && nk > 2) wait_vmcnt<2 * LPT>(); else if (nk > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  struct Head { v8i fw[TN]; v8i fa0; };
-  Head h0, h1;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) h0.fw[j] = read_w(0, j);
-  h0.fa0 = read_a(0, 0);
-
-  // One K-step.  Entry: `cur` = W fragments + A fragment 0 of step kt (LDS reads possibly still in flight); LDS-DMA of
-  // steps kt+1, kt+2 in flight.  Wait ONLY for step kt+1, barrier, refill the slot step kt-1 vacated with step kt+3.
-  // A fragments stream one MFMA row ahead; the head of step kt+1 is fetched under the last row.
-  // `slot` = kt % NS is carried incrementally (no integer division in the loop).
-  auto kstep = [&](Head& cur, Head& nxt, int kt, int slot) {
-    if (!(ABL & 8)) { if (D > 2 && kt + 2 < nk) wait_vmcnt<(D - 2) * LPT>(); else wait_vmcnt<0>(); }
-    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
-    const bool refill = (kt + D < nk) && !(ABL & 1);  // wave-uniform
-    const int rslot = slot == 0 ? NS - 1 : slot - 1;  // the slot K-step kt-1 vacated == (kt + D) % NS
-    if (!SPREAD && refill) stage_part(kt + D, rslot, 0, LPT);
-    // branch-free from here on (a conditional around the head reads makes LLVM sink every MFMA below it): on the last
-    // step the "next head" is simply re-read from the last tile and never used
-    const int nslot = kt + 1 < nk ? (slot + 1 == NS ? 0 : slot + 1) : slot;
-    v8i fa = cur.fa0;
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      v8i fn = fa;
-      if constexpr (ABL & 2) {
-        // ablation: no LDS reads in the main loop (fragments are recycled; results are garbage, timing only)
-        if (i + 1 == TM) { nxt = cur; }
-        asm volatile("" : "+v"(fn));
-      } else if (i + 1 < TM) {
-        fn = read_a(slot, i + 1);
-      } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) nxt.fw[j] = read_w(nslot, j);
-        nxt.fa0 = read_a(nslot, 0);
-      }
-      // pin the software pipeline: [LDS reads for the next row] | [this row's MFMAs]; without the fences hipcc hoists every
-      // read of the K-step above one lgkmcnt(0) and the MFMAs start only after the slowest of them
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      mma_row(i, fa, cur.fw);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("" ::: "memory");
-      // SPREAD: the refill of the vacated slot is issued in TM pieces, one behind each MFMA row, so that the two waves of a
-      // SIMD never sit in a burst of LDS-DMA issue (~60 cycles each) at the same time with the matrix pipe idle
-      if (SPREAD && refill) stage_part(kt + D, rslot, (i * LPT) / TM, ((i + 1) * LPT) / TM);
-      if (SPREAD) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-      fa = fn;
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  {
-    int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      kstep(h0, h1, kt, slot);
-      h0 = h1;  // 24 register moves per K-step: cheaper than the address/unroll state a 2x-unrolled ping-pong keeps live
-      slot = slot + 1 == NS ? 0 : slot + 1;
-    }
-  }
-
-  // ---- epilogue ----------------------------------------------------------------------------------------------------
-  const float s = load_scale_u(G.sa_recip) * load_scale_u(G.sb_recip);
-  const float qs = load_scale_u(G.q_scale);
-  __builtin_amdgcn_s_barrier();  // every wave is done reading the ring before it is reused as epilogue scratch
-  unsigned char* wbuf = smem + wave * (WTM * WTN * 2);
-  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
-  switch (P.epi) {
-    case FLUXMI_EPI_BF16: lds_epilogue<FLUXMI_EPI_BF16, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_GELU_QUANT: lds_epilogue<FLUXMI_EPI_GELU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_GATE_RESID: lds_epilogue<FLUXMI_EPI_GATE_RESID, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_SPLIT: lds_epilogue<FLUXMI_EPI_SPLIT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_QUANT: lds_epilogue<FLUXMI_EPI_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    case FLUXMI_EPI_SILU_QUANT: lds_epilogue<FLUXMI_EPI_SILU_QUANT, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane); break;
-    default: break;
-  }
-}
 
 // -------------------------------------------------------------------------------------------------------------------
 // "ping-pong" kernel: 256x256 tile, 8 waves (2 x 4), 4-slot ring, ONE barrier per 64-byte K-step -- and the two waves
@@ -445,85 +253,32 @@ int launch_pp(FluxmiGemmParams& p, hipStream_t s) {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool SPREAD, bool FP8, int ACT, int ABL = 0>
-int launch_ring(FluxmiGemmParams& p, hipStream_t s) {
-  int t = 0;
-  for (int i = 0; i < p.n_groups; ++i) {
-    p.g[i].m_tile_start = t;
-    t += (p.g[i].M + BM - 1) / BM;
-  }
-  p.tiles_m_total = t;
-  p.group_m = 8;
-  constexpr int SMEM = NS * (BM + BN) * 64;
-  auto kern = gemm_ring_kernel<BM, BN, WM, WN, NS, SPREAD, FP8, ACT, ABL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_set = true;
-  }
-  const int nblk = t * (p.N / BN);
-  if (nblk == 0) return 0;
-  hipLaunchKernelGGL(kern, dim3(nblk), dim3(WM * WN * 64), SMEM, s, p);
-  FLUXMI_LAUNCH_CHECK();
-  return 0;
-}
-
 template <bool FP8, int ACT>
-int launch_ring_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
-  switch (cfg) {
-    case 4: return launch_ring<256, 256, 2, 4, 4, false, FP8, ACT>(p, s);
-    case 5: return launch_ring<256, 128, 4, 2, 4, false, FP8, ACT>(p, s);
-    case 6: return launch_ring<128, 128, 2, 2, 4, false, FP8, ACT>(p, s);
-    case 8: return launch_ring<256, 128, 2, 2, 3, true, FP8, ACT>(p, s);   // 72 KiB LDS, 4 waves: 2 blocks per CU
-    case 13:
-      // the hot epilogues get a kernel compiled for them alone (fp8 x e5m2: the calibrated step; bf16: VAE / text encoders / bf16 flow)
-      if constexpr (ACT == FLUXMI_FMT_E5M2) {
-        static int esel = -1;  // FLUXMI_GEMM_ESEL=0: the run-time-switch kernel for every epilogue (A/B)
-        if (esel < 0) { const char* e = getenv("FLUXMI_GEMM_ESEL"); esel = e ? atoi(e) : 1; }
-        if (esel) switch (p.epi) {
-          case FLUXMI_EPI_BF16: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_BF16>(p, s);
-          case FLUXMI_EPI_GATE_RESID: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GATE_RESID>(p, s);
-          case FLUXMI_EPI_SPLIT: if constexpr (FP8) return launch_pp<FP8, ACT, 2, FLUXMI_EPI_SPLIT>(p, s); else break;
-          case FLUXMI_EPI_GELU_QUANT: if constexpr (FP8) return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GELU_QUANT>(p, s); else break;
-          default: break;
-        }
-      }
-      return launch_pp<FP8, ACT, 2>(p, s);
-    case 12: return launch_pp<FP8, ACT, 10>(p, s);  // 13 with the second wave group's refill behind its MFMA block
-#ifdef FLUXMI_EXPERIMENTS  // variants measured and rejected in round 1 (profiles/r01_gemm_ablation*.txt); not built by default
-    case 7: return launch_ring<256, 256, 2, 4, 4, true, FP8, ACT>(p, s);
-    case 9: return launch_ring<128, 256, 2, 2, 3, true, FP8, ACT>(p, s);
-    case 10: return launch_ring<256, 128, 2, 2, 3, false, FP8, ACT>(p, s);
-    case 11: return launch_pp<FP8, ACT, 0>(p, s);
-    case 14: return launch_pp<FP8, ACT, 3>(p, s);
-#endif
-    default: break;
-  }
-  // timing-only ablations of the 256x256 ring (tools/gemm_probe.py): cfg = 20 + mask, 1 = no LDS-DMA refill, 2 = no LDS reads,
-  // 4 = no barrier, 8 = no vmcnt wait.  Results are wrong by construction.
-#ifdef FLUXMI_EXPERIMENTS
-  if constexpr (FP8 && ACT == FLUXMI_FMT_E5M2) {
-    switch (cfg) {
-#define ABL_CASE(m) case 20 + m: return launch_ring<256, 256, 2, 4, 4, false, FP8, ACT, m>(p, s);
-      ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(7) ABL_CASE(9) ABL_CASE(13) ABL_CASE(15)
-#undef ABL_CASE
+int launch_pp_cfg(FluxmiGemmParams& p, hipStream_t s) {
+  // the hot epilogues get a kernel compiled for them alone (fp8 x e5m2: the calibrated step; bf16: VAE / text encoders / bf16 flow)
+  if constexpr (ACT == FLUXMI_FMT_E5M2) {
+    static int esel = -1;  // FLUXMI_GEMM_ESEL=0: the run-time-switch kernel for every epilogue (A/B)
+    if (esel < 0) { const char* e = getenv("FLUXMI_GEMM_ESEL"); esel = e ? atoi(e) : 1; }
+    if (esel) switch (p.epi) {
+      case FLUXMI_EPI_BF16: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_BF16>(p, s);
+      case FLUXMI_EPI_GATE_RESID: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GATE_RESID>(p, s);
+      case FLUXMI_EPI_SPLIT: if constexpr (FP8) return launch_pp<FP8, ACT, 2, FLUXMI_EPI_SPLIT>(p, s); else break;
+      case FLUXMI_EPI_GELU_QUANT: if constexpr (FP8) return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GELU_QUANT>(p, s); else break;
       default: break;
     }
   }
-#endif
-  switch (cfg) {
-    default: fluxmi_set_error("gemm_ring: unknown tile config %d", cfg); return 1;
-  }
+  return launch_pp<FP8, ACT, 2>(p, s);
 }
 
 }  // namespace
 
-// ring configs: 4 = 256x256 (8 waves), 5 = 256x128 (8 waves), 6 = 128x128 (4 waves)
+// config 13 = 256x256 ping-pong ring (8 waves)
 int fluxmi_launch_gemm_ring(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s) {
+  FLUXMI_REQUIRE(cfg == 13, "gemm_ring: unknown tile config %d", cfg);
   if (is_fp8) {
-    if (act_fmt == FLUXMI_FMT_E5M2) return launch_ring_cfg<true, FLUXMI_FMT_E5M2>(p, cfg, s);
-    return launch_ring_cfg<true, FLUXMI_FMT_E4M3>(p, cfg, s);
+    if (act_fmt == FLUXMI_FMT_E5M2) return launch_pp_cfg<true, FLUXMI_FMT_E5M2>(p, s);
+    return launch_pp_cfg<true, FLUXMI_FMT_E4M3>(p, s);
   }
-  if (act_fmt == FLUXMI_FMT_E5M2) return launch_ring_cfg<false, FLUXMI_FMT_E5M2>(p, cfg, s);
-  return launch_ring_cfg<false, FLUXMI_FMT_E4M3>(p, cfg, s);
+  if (act_fmt == FLUXMI_FMT_E5M2) return launch_pp_cfg<false, FLUXMI_FMT_E5M2>(p, s);
+  return launch_pp_cfg<false, FLUXMI_FMT_E4M3>(p, s);
 }

@@ -26,7 +26,7 @@ struct W1Frags { v8i fw[4]; v8i fa[4]; };
 // ESEL >= 0: the kernel is compiled for ONE epilogue (the hot ones get their own instantiation: with the run-time switch over six inlined
 // epilogues hipcc allocates registers for all of them at once and spilled ~110 ACCUMULATOR pairs to scratch right after the K loop -- on every
 // path, each reload behind an s_waitcnt vmcnt(0)); ESEL = -1 keeps the switch (cold epilogues)
-template <bool FP8, int ACT_FMT, int ABL, int ESEL>
+template <bool FP8, int ACT_FMT, int ESEL>
 __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams P) {
   constexpr int BM = 256, BN = 256, NT = 256, TM = 4, TN = 4, NS = 4;
   constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
@@ -54,7 +54,6 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   const int m0 = (tm - G.m_tile_start) * BM;
   const int n0 = tn * BN;
   const int nk = (P.K * EB) / 64;
-  constexpr int abl = ABL;  // timing-only ablations (1 = no LDS-DMA refill, 2 = no LDS reads, 4 = no barrier); 0 in production
 
   // ---- LDS-DMA: descriptors (SGPRs), per-lane offsets (VGPRs, loop-invariant), tile offsets (SGPRs) ----------------------------
   const long long a_row_b = (long long)G.lda * EB, w_row_b = (long long)P.K * EB;
@@ -142,15 +141,15 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   auto step = [&](auto SLOT, W1Frags& cur, W1Frags& nxt, int kt) {
     constexpr int S = decltype(SLOT)::value, SN = (S + 1) & 3, SR = (S + 3) & 3;
     wait_vmcnt<LPT>();  // step kt+1 landed (own pieces); step kt+2 stays in flight
-    if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     fence();
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       mma(cur, s >> 2, s & 3);
       fence();
       // next fragments: W halves first (needed by every MFMA row), then A
-      if (!(abl & 2)) read_half(nxt, SN, s >> 1, s & 1);
-      if ((s & 1) == 0 && !(abl & 1)) dma_piece(s >> 1, SR, kt + 3);
+      read_half(nxt, SN, s >> 1, s & 1);
+      if ((s & 1) == 0) dma_piece(s >> 1, SR, kt + 3);
       fence();
     }
   };
@@ -183,7 +182,7 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   }
 }
 
-template <bool FP8, int ACT, int ABL = 0, int ESEL = -1>
+template <bool FP8, int ACT, int ESEL = -1>
 int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
   constexpr int BM = 256, BN = 256;
   int t = 0;
@@ -194,7 +193,7 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
   p.tiles_m_total = t;
   p.group_m = 8;
   constexpr int SMEM = 4 * (BM + BN) * 64;
-  auto kern = gemm_w1_kernel<FP8, ACT, ABL, ESEL>;
+  auto kern = gemm_w1_kernel<FP8, ACT, ESEL>;
   static bool attr_set = false;
   if (!attr_set) {
     FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -217,29 +216,17 @@ int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStrea
                    "gemm_w1: operand larger than 4 GiB");
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) {
-#ifdef FLUXMI_EXPERIMENTS
-      static int abl = -1;  // FLUXMI_GEMM_ABL: timing-only ablations for tools/gemm_probe.py
-      if (abl < 0) { const char* e = getenv("FLUXMI_GEMM_ABL"); abl = e ? atoi(e) : 0; }
-      switch (abl) {
-        case 1: return launch_w1<true, FLUXMI_FMT_E5M2, 1>(p, s);
-        case 2: return launch_w1<true, FLUXMI_FMT_E5M2, 2>(p, s);
-        case 3: return launch_w1<true, FLUXMI_FMT_E5M2, 3>(p, s);
-        case 4: return launch_w1<true, FLUXMI_FMT_E5M2, 4>(p, s);
-        case 7: return launch_w1<true, FLUXMI_FMT_E5M2, 7>(p, s);
-        default: break;
-      }
-#endif
       // the step's K >= 8192 launches (mlp.2, linear2) all end in gate*y + x
       static int esel = -1;  // FLUXMI_GEMM_ESEL=0: the run-time-switch kernel for every epilogue (A/B)
       if (esel < 0) { const char* e = getenv("FLUXMI_GEMM_ESEL"); esel = e ? atoi(e) : 1; }
-      if (esel && p.epi == FLUXMI_EPI_GATE_RESID) return launch_w1<true, FLUXMI_FMT_E5M2, 0, FLUXMI_EPI_GATE_RESID>(p, s);
+      if (esel && p.epi == FLUXMI_EPI_GATE_RESID) return launch_w1<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID>(p, s);
       return launch_w1<true, FLUXMI_FMT_E5M2>(p, s);
     }
     return launch_w1<true, FLUXMI_FMT_E4M3>(p, s);
   }
   if (act_fmt == FLUXMI_FMT_E5M2) {  // bf16 operands (VAE convolutions, text encoders, bf16 flow): plain and residual epilogues specialised
-    if (p.epi == FLUXMI_EPI_GATE_RESID) return launch_w1<false, FLUXMI_FMT_E5M2, 0, FLUXMI_EPI_GATE_RESID>(p, s);
-    if (p.epi == FLUXMI_EPI_BF16) return launch_w1<false, FLUXMI_FMT_E5M2, 0, FLUXMI_EPI_BF16>(p, s);
+    if (p.epi == FLUXMI_EPI_GATE_RESID) return launch_w1<false, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID>(p, s);
+    if (p.epi == FLUXMI_EPI_BF16) return launch_w1<false, FLUXMI_FMT_E5M2, FLUXMI_EPI_BF16>(p, s);
     return launch_w1<false, FLUXMI_FMT_E5M2>(p, s);
   }
   return launch_w1<false, FLUXMI_FMT_E4M3>(p, s);

@@ -91,9 +91,9 @@ int fluxmi_abi_version(void);
 /* ---- F8Linear / Linear ------------------------------------------------------------------------- */
 /* Grouped linear.  is_fp8=1: A is `act_fmt` fp8, W is e4m3fn (torch._scaled_mm, float8_quantize.py:284-292);
  * is_fp8=0: A, W bf16 (F.linear).  tile_cfg: -1 auto (cost model + split of a thin last round, what the engine uses);
- * 0..3, 15 double-buffered MFMA tile kernels (256x256, 256x128, 128x128, 128x256, 128x64); 4, 5, 6, 8 LDS-ring kernels;
- * 13 = ping-pong 256x256; 16 = 256x256 with one wave per SIMD (K*bytes % 256 == 0);
- * 100 = generic any-shape kernel.  Every config computes the same bits. */
+ * 13 = 256x256 ping-pong LDS ring (K*bytes % 64 == 0); 16 = 256x256 with one wave per SIMD (K*bytes % 256 == 0); 2 = 128x128 and 15 = 128x64
+ * double-buffered tiles (K*bytes % 128 == 0); 100 = generic any-shape kernel.  Every config computes the same bits.  (Other numbers
+ * named kernel generations that were removed: they are rejected.) */
 int fluxmi_gemm_grouped(const fluxmi_gemm_group_t* groups, int n_groups, int N, int K, int is_fp8, int act_fmt,
                         int epilogue, int tile_cfg, void* stream);
 /* single-problem convenience form of the above (F8Linear.forward after quantisation) */

@@ -110,15 +110,15 @@ def make_f8_problem(M, N, K, fmt, seed):
     return a8, w8, sa.reciprocal(), sbr, bias
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 15, 16, 100])
+@pytest.mark.parametrize("cfg", [2, 13, 15, 16, 100])
 @pytest.mark.parametrize("shape", [(256, 256, 64), (256, 256, 128), (512, 768, 256), (300, 512, 384), (37, 256, 3072), (1024, 1024, 1024)])
 @pytest.mark.parametrize("fmt", [E5M2, E4M3])
 def test_f8_gemm(ops, dev, cfg, shape, fmt):
     """K1: fp8 GEMM on identical quantised operands vs fp64 (float8_quantize.py:284-292): <= 1 bf16 ulp."""
     M, N, K = shape
-    if fmt == E4M3 and (cfg not in (0, 4, 8, 12, 13, 16, 100) or shape != (512, 768, 256)):
+    if fmt == E4M3 and (cfg == 15 or shape != (512, 768, 256)):
         pytest.skip("e4m3 activations: one representative case per kernel")
-    if K % 128 and cfg in (0, 1, 2, 3, 15):
+    if K % 128 and cfg in (2, 15):
         pytest.skip("double-buffered kernels step K by 128 bytes")
     if K % 256 and cfg == 16:
         pytest.skip("the one-wave-per-SIMD kernel steps K by 256 bytes")
@@ -188,7 +188,7 @@ def accum_noise(a, w, s):
     return 16.0 * math.sqrt(max(a.shape[1], 256)) * 2.0 ** -24 * S * 2.0 ** 7
 
 
-@pytest.mark.parametrize("cfg", [0, 2, 4, 6, 8, 13, 15, 100])
+@pytest.mark.parametrize("cfg", [2, 13, 15, 100])
 def test_bf16_gemm(ops, dev, cfg):
     torch.manual_seed(5)
     M, N, K = 320, 512, 192
@@ -201,7 +201,7 @@ def test_bf16_gemm(ops, dev, cfg):
     assert_close_mag(out, ref, mag=accum_noise(a, w, 1.0), ulps=1, min_exact=0.99, what=f"bf16 gemm cfg={cfg}")
 
 
-@pytest.mark.parametrize("cfg", [0, 2, 4, 5, 6, 8, 12, 13, 16, 100])
+@pytest.mark.parametrize("cfg", [2, 13, 16, 100])
 def test_gemm_epilogues(ops, dev, cfg):
     """K8/K9/K2 fused epilogues == the reference's eager chain applied to the GEMM's own bf16 output."""
     from fluxmi import _lib
@@ -251,7 +251,7 @@ def test_gemm_grouped(ops, dev):
         outs.append(o)
         groups.append(ops.make_group(t[0].data_ptr(), t[1].data_ptr(), t[4].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
                                      o.data_ptr(), a8.shape[0], K, N))
-    for cfg in (0, 1, 2, 3, 4, 5, 6):
+    for cfg in (2, 13):
         for o in outs:
             o.zero_()
         ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_BF16, cfg)

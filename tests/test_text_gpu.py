@@ -115,8 +115,14 @@ def test_pipeline_generate_from_a_prompt_string(embedders, dev):
     a = pipe.generate(prompt, width=64, height=64, num_steps=4, seed=11, silent=True)
     b = pipe.generate({"txt": txt, "vec": vec}, width=64, height=64, num_steps=4, seed=11, silent=True)
     assert a.shape == (1, 16, 8, 8) and torch.isfinite(a).all() and torch.equal(a, b)
+    # a list prompt with one noise sample sizes the batch (reference flux_pipeline.py:267-278); every prompt is embedded on its own
+    tok2, ids2, vec2, txt2, tids2 = pipe.prepare(noise, [prompt, "a dog"])
+    assert tok2.shape[0] == 2 and vec2.shape == (2, 128) and txt2.shape == (2, 512, 128) and torch.equal(tok2[0], tok2[1])
+    assert torch.equal(vec2[0], vec[0]) and torch.equal(txt2[0], txt[0]) and not torch.equal(txt2[1], txt2[0])
+    c = pipe.generate([prompt, "a dog"], width=64, height=64, num_steps=4, seed=11, silent=True)
+    assert c.shape == (2, 16, 8, 8) and torch.equal(c[0], a[0])
     with pytest.raises(TypeError):
-        pipe.prepare(noise, ["a", "b"])
+        pipe.prepare(noise, ["a", 3])
 
 
 def test_full_width_text_encoders_match_oracle(dev):

@@ -1,5 +1,5 @@
 """One GEMM shape / tile config / epilogue, launched `iters` times -- the target for rocprofv3 PMC passes and A/B timing:
-    python tools/gemm_probe.py --shape 4608,21504,3072 --cfg 4 --epi bf16 --iters 10 [--fill zero] [--ab 4,7]
+    python tools/gemm_probe.py --shape 4608,21504,3072 --cfg 13 --epi bf16 --iters 10 [--fill zero] [--ab 13,16]
 With --ab a,b the two configs are timed interleaved over several rounds (median / min per config)."""
 import argparse
 import os
@@ -21,7 +21,7 @@ SHAPES = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="lin1")
-    ap.add_argument("--cfg", type=int, default=4)
+    ap.add_argument("--cfg", type=int, default=13)
     ap.add_argument("--epi", default="bf16", choices=["bf16", "gelu", "gate", "quant"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fill", default="rand", choices=["rand", "zero"])
