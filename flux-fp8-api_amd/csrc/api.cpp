@@ -58,6 +58,11 @@ int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8) {
   return best;
 }
 
+// mods_gemm (engine.hip) needs results that do not depend on how many rows share a launch (the step-ahead table of R = steps x B rows
+// must equal the per-step R = B launches bit for bit): it switches the M-dependent split-K choice off around its launches
+static thread_local int g_splitk_block = 0;
+void fluxmi_gemm_block_splitk(int on) { g_splitk_block += on ? 1 : -1; }
+
 static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is_fp8, int act_fmt, int epi, int force_cfg, hipStream_t s) {
   FluxmiGemmParams p;
   memset(&p, 0, sizeof(p));
@@ -65,6 +70,35 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
   for (int i = 0; i < n; ++i) p.g[i] = gs[i];
   p.N = N; p.K = K; p.epi = epi;
   int cfg = force_cfg >= 0 && fluxmi_gemm_tile_ok(N, K, is_fp8, force_cfg) ? force_cfg : fluxmi_gemm_auto_cfg(p, is_fp8);
+  // small-M launches (M <= 512: schnell 256x256, the text encoders, the modulation GEMMs): 24-96 tiles of 256x256 for 256 CUs, weight-stream
+  // bound -> split K over several workgroups per tile (fp32 partials + a reduce / epilogue pass).  FLUXMI_GEMM_SPLITK=0 turns it off;
+  // fluxmi_gemm_grouped(tile_cfg = 113 + S) forces S splits (tests).
+  {
+    static int sk_on = -1;
+    if (sk_on < 0) { const char* e = getenv("FLUXMI_GEMM_SPLITK"); sk_on = e ? atoi(e) : 1; }
+    int S = 0;
+    const int nk = K * (is_fp8 ? 1 : 2) / 64;
+    bool fused_out = false;
+    long long tiles = 0, rows = 0;
+    for (int i = 0; i < n; ++i) { tiles += (gs[i].M + 255) / 256; rows += (long long)((gs[i].M + 255) / 256) * 256; fused_out |= (gs[i].vt_out || gs[i].k_out); }
+    tiles *= N / 256;
+    const bool can = !fused_out && (epi == FLUXMI_EPI_BF16 || epi == FLUXMI_EPI_GATE_RESID) && fluxmi_gemm_tile_ok(N, K, is_fp8, 13) && tiles > 0;
+    // measured on M = 512 bf16 launches (tools/bf16_gemm_probe.py, profiles/r03_small_m.txt): below ~190 K-steps per tile the 128x128 tiles at two
+    // workgroups per CU are as fast as any split; above, ~40-50 K-steps per workgroup is the sweet spot (K = 15360: 72 us vs 158 us unsplit)
+    if (force_cfg < 0 && sk_on && !g_splitk_block && can && !is_fp8 && getenv("FLUXMI_GEMM_CFG") == nullptr && tiles <= 128 && nk >= 192)
+      S = (int)std::max<long long>(2, std::min<long long>(std::min<long long>(256 / tiles, (nk + 24) / 48), 16));
+    while (S >= 2 && (size_t)S * rows * N * 4 > ((size_t)256 << 20)) --S;
+    if (S >= 2) return fluxmi_launch_gemm_splitk(p, is_fp8, act_fmt, S, s);
+  }
+  // bf16 operands, one thin round of 256x256 tiles (Flux-schnell linear1 at M = 512: 168 tiles): the one-wave-per-SIMD kernel runs the
+  // single tile per CU fastest (74 us vs 95 / 98 us for configs 13 / 2, profiles/r03_small_m.txt)
+  if (!is_fp8 && force_cfg < 0 && getenv("FLUXMI_GEMM_CFG") == nullptr && fluxmi_gemm_tile_ok(N, K, is_fp8, 16)) {
+    long long t256 = 0;
+    bool fused_out = false;
+    for (int i = 0; i < n; ++i) { t256 += (gs[i].M + 255) / 256; fused_out |= (gs[i].vt_out || gs[i].k_out); }
+    t256 *= N / 256;
+    if (t256 > 128 && t256 <= 256 && (!fused_out || cfg == 13)) cfg = 16;
+  }
   const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0);
   if (cfg < 0 || !split_ok) return fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, s);
   return fluxmi_launch_gemm(p, is_fp8, act_fmt, cfg, s);
@@ -144,6 +178,7 @@ int fluxmi_gemm_grouped(const fluxmi_gemm_group_t* groups, int n_groups, int N, 
   }
   p.n_groups = n_groups; p.N = N; p.K = K; p.epi = epilogue;
   if (tile_cfg == 100) return fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, (hipStream_t)stream);
+  if (tile_cfg >= 115 && tile_cfg <= 113 + 32) return fluxmi_launch_gemm_splitk(p, is_fp8, act_fmt, tile_cfg - 113, (hipStream_t)stream);
   if (tile_cfg < 0) return fluxmi_gemm_dispatch(p.g, p.n_groups, N, K, is_fp8, act_fmt, epilogue, (hipStream_t)stream);
   return fluxmi_launch_gemm(p, is_fp8, act_fmt, tile_cfg, (hipStream_t)stream);
 }

@@ -267,7 +267,10 @@ int mods_gemm(E* e, const u16* sv, int R, u16* out, uint8_t* a8, size_t a8_strid
       gg.C = out + ((u16*)g.out - mod0); gg.ldc = MC; gg.M = R;
       gs.push_back(gg);
     }
-    FLUXMI_TRY(run_gemm(gs, g0.N, g0.K, g0.w_fp8, g0.act_fmt, FLUXMI_EPI_BF16, s));
+    fluxmi_gemm_block_splitk(1);  // row-count-independent K order: table rows == per-step rows, bit for bit
+    const int rc = run_gemm(gs, g0.N, g0.K, g0.w_fp8, g0.act_fmt, FLUXMI_EPI_BF16, s);
+    fluxmi_gemm_block_splitk(0);
+    FLUXMI_TRY(rc);
     i = j;
   }
   return 0;
@@ -460,7 +463,9 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
   const int roff[2] = {0, Lt}, rows[2] = {Lt, Li};
   const void* const* ns = &e->norm[i * 4];  // img q, img k, txt q, txt k
   // V^T leaves the qkv GEMM's epilogue directly in the attention kernel's layout when the 256x256 kernels apply
-  const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H, H, e->lin[li_q[0]].kind, 13) && Lt % 16 == 0;
+  // (short sequences -- Flux-schnell 256x256: 72 tiles -- leave V^T to the relayout kernel: the fused output exists only in the 256x256
+  // kernels, and a launch that small runs 1.7x faster on 128x128 tiles at two workgroups per CU, profiles/r03_small_m.txt)
+  const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H, H, e->lin[li_q[0]].kind, 13) && Lt % 16 == 0 && (long long)B * L >= 2048;
   const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;  // a 256-column tile must not straddle the q|k|v boundaries
 
   for (int half = 0; half < 2; ++half) {

@@ -10,6 +10,10 @@ typedef fluxmi_gemm_group_t FluxmiGemmGroup;
 struct FluxmiGemmParams {
   FluxmiGemmGroup g[FLUXMI_MAX_GROUPS];
   int n_groups, N, K, epi, tiles_m_total, group_m;
+  // split-K (small-M launches, gemm_ring.hip): `split_k` workgroups per tile, each over its own K range, fp32 partial tiles in
+  // partial[split][tiles_m_total * 256][N]; fluxmi_launch_splitk_reduce sums them in split order and applies the epilogue
+  int split_k;
+  float* partial;
 };
 
 // ---- batched skinny GEMV (modulations + embedders, M = batch <= 8) ----------------------------
@@ -62,6 +66,9 @@ int fluxmi_gemm_tile_bm(int cfg);
 int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int tile_cfg, hipStream_t s);
 int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
 int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8);
+// 256x256 ping-pong tiles with `split_k` K ranges per tile + the reduce / epilogue pass (BF16 and GATE_RESID epilogues)
+void fluxmi_gemm_block_splitk(int on);  // +1 / -1: no M-dependent split-K choice while > 0 (thread-local)
+int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int split_k, hipStream_t s);
 // tile choice + (when it pays) the split of a grouped launch into a 256x256 and a 128x128 launch; any number of groups
 int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs, int n, int N, int K, int is_fp8, int act_fmt, int epi, hipStream_t s);
 int fluxmi_launch_gemv(const FluxmiGemvLayer* layers_dev, FluxmiGemvLayer* layers_host, int n_layers, int B, int total_blocks,

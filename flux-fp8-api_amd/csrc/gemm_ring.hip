@@ -28,7 +28,10 @@ namespace {
 // before that barrier.
 // -------------------------------------------------------------------------------------------------------------------
 // ESEL >= 0: compiled for ONE epilogue (see gemm_w1.hip), -1: run-time switch
-template <bool FP8, int ACT_FMT, int VAR, int ESEL>
+// SPLITK: blockIdx.x = split * tiles + tile; the workgroup accumulates K-steps [split * nk / S, (split + 1) * nk / S) of its tile and
+// stores the raw fp32 accumulators (no scale, no bias) into P.partial -- the small-M launches (M <= 512: schnell 256x256, the text
+// encoders) have 24-96 tiles for 256 CUs and are weight-stream bound: a tile per workgroup leaves the stream to a tenth of the chip.
+template <bool FP8, int ACT_FMT, int VAR, int ESEL, bool SPLITK = false>
 __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams P) {
   constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NT = 512, TM = 4, TN = 2, NS = 4, D = 3;
   constexpr int WTM = 128, WTN = 64;
@@ -44,7 +47,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
 
   const int tiles_n = P.N / BN;
   const int nblk = P.tiles_m_total * tiles_n;
-  const int lid = xcd_remap(blockIdx.x, nblk);
+  const int split = SPLITK ? (int)blockIdx.x / nblk : 0;
+  const int lid = xcd_remap(SPLITK ? (int)blockIdx.x % nblk : (int)blockIdx.x, nblk);
   const int width = P.group_m * tiles_n;
   const int first_m = (lid / width) * P.group_m;
   const int gsz = min(P.tiles_m_total - first_m, P.group_m);
@@ -56,7 +60,9 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
   const int M = G.M;
   const int m0 = (tm - G.m_tile_start) * BM;
   const int n0 = tn * BN;
-  const int nk = (P.K * EB) / 64;
+  const int nk_all = (P.K * EB) / 64;
+  const int k_begin = SPLITK ? (int)(((long long)split * nk_all) / P.split_k) : 0;
+  const int nk = SPLITK ? (int)(((long long)(split + 1) * nk_all) / P.split_k) - k_begin : nk_all;
 
   // VAR & 4: LDS-DMA through buffer descriptors (SGPR tile / K offsets, rows past M read as zero) instead of per-lane 64-bit
   // addresses (4 v_lshl_add_u64 per K-step and a clamped row index)
@@ -69,13 +75,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
   for (int i = 0; i < IA; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
     const int gr = min(m0 + row, M - 1);
-    srcA[i] = (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16;
+    srcA[i] = (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16 + (long long)k_begin * 64;
     a_voff[i] = (unsigned)(row * a_row_b + slot * 16);
   }
 #pragma unroll
   for (int i = 0; i < IW; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-    srcW[i] = (const unsigned char*)G.W + ((long long)(n0 + row) * P.K) * EB + slot * 16;
+    srcW[i] = (const unsigned char*)G.W + ((long long)(n0 + row) * P.K) * EB + slot * 16 + (long long)k_begin * 64;
     w_voff[i] = (unsigned)(row * w_row_b + slot * 16);
   }
   const __amdgpu_buffer_rsrc_t ars = make_rsrc(G.A, (unsigned)min((long long)M * a_row_b, 0xffffffffLL));
@@ -206,6 +212,23 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
     }
   }
 
+  if constexpr (SPLITK) {
+    // raw fp32 partial tile: lane = one row, 4 consecutive columns per register group (16-byte stores)
+    float* base = P.partial + ((size_t)split * P.tiles_m_total * BM + (size_t)tm * BM) * P.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ml = wm * WTM + i * 32 + l31;
+      if (m0 + ml < M) {
+        float* rowp = base + (size_t)ml * P.N + n0 + wn * WTN + hi * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            *(v4f*)(rowp + j * 32 + g4 * 8) = (v4f){acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
+      }
+    }
+    return;
+  }
   // ---- epilogue ----------------------------------------------------------------------------------------------------
   const float s = load_scale_u(G.sa_recip) * load_scale_u(G.sb_recip);
   const float qs = load_scale_u(G.q_scale);
@@ -253,6 +276,86 @@ int launch_pp(FluxmiGemmParams& p, hipStream_t s) {
   return 0;
 }
 
+// ---- split-K: reduce + epilogue pass ---------------------------------------------------------------------------------
+// one thread = 8 consecutive columns of one row: sum of the splits in ascending order (deterministic), h = bf16(acc * sa*sb + bias), then
+// C = h (FLUXMI_EPI_BF16) or resid + bf16(gate * h) (FLUXMI_EPI_GATE_RESID) -- the same rounding points as lds_epilogue.
+template <int EPI>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const FluxmiGemmParams P) {
+  const int prow = blockIdx.x;  // padded row: tile row * 256 + local row
+  const int tm = prow >> 8;
+  int gi = 0;
+  for (int i = 1; i < P.n_groups; ++i) gi = (tm >= P.g[i].m_tile_start) ? i : gi;
+  const FluxmiGemmGroup& G = P.g[gi];
+  const int m = prow - G.m_tile_start * 256;
+  if (m >= G.M) return;
+  const float s = load_scale(G.sa_recip) * load_scale(G.sb_recip);
+  const size_t split_stride = (size_t)P.tiles_m_total * 256 * P.N;
+  for (int c = threadIdx.x; c < P.N / 8; c += 256) {
+    const int n = c * 8;
+    const float* src = P.partial + (size_t)prow * P.N + n;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < P.split_k; ++sp) {
+      const v4f a = *(const v4f*)(src + sp * split_stride), b = *(const v4f*)(src + sp * split_stride + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[e] += a[e]; acc[4 + e] += b[e]; }
+    }
+    float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, h[8];
+    if (G.bias) unpack8(*(const uint4*)((const u16*)G.bias + n), bias);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = rbf(fmaf(acc[e], s, bias[e]));
+    if constexpr (EPI == FLUXMI_EPI_GATE_RESID) {
+      float r[8], g[8], o[8];
+      unpack8(*(const uint4*)((const u16*)G.resid + (long long)m * G.ldr + n), r);
+      unpack8(*(const uint4*)((const u16*)G.gate + n), g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = r[e] + rbf(g[e] * h[e]);
+      *(uint4*)((u16*)G.C + (long long)m * G.ldc + n) = pack8(o);
+    } else {
+      *(uint4*)((u16*)G.C + (long long)m * G.ldc + n) = pack8(h);
+    }
+  }
+}
+
+float* g_splitk_ws[16] = {nullptr};
+constexpr size_t SPLITK_WS_BYTES = (size_t)256 << 20;
+
+template <bool FP8, int ACT>
+int launch_pp_splitk(FluxmiGemmParams& p, int split_k, hipStream_t s) {
+  constexpr int BM = 256, BN = 256;
+  int t = 0;
+  for (int i = 0; i < p.n_groups; ++i) {
+    p.g[i].m_tile_start = t;
+    t += (p.g[i].M + BM - 1) / BM;
+  }
+  p.tiles_m_total = t;
+  p.group_m = 8;
+  const int nblk = t * (p.N / BN);
+  if (nblk == 0) return 0;
+  FLUXMI_REQUIRE(p.epi == FLUXMI_EPI_BF16 || p.epi == FLUXMI_EPI_GATE_RESID, "gemm split-K: bf16 / gate*y+x epilogues only (got %d)", p.epi);
+  const size_t need = (size_t)split_k * t * BM * p.N * sizeof(float);
+  FLUXMI_REQUIRE(split_k >= 2 && need <= SPLITK_WS_BYTES, "gemm split-K: %d splits of %d x %d need %zu bytes of scratch (have %zu)", split_k, t * BM, p.N,
+                 need, SPLITK_WS_BYTES);
+  int dev = 0;
+  FLUXMI_CHECK_HIP(hipGetDevice(&dev));
+  FLUXMI_REQUIRE(dev >= 0 && dev < 16, "gemm split-K: device ordinal %d out of range", dev);
+  if (!g_splitk_ws[dev]) FLUXMI_CHECK_HIP(hipMalloc((void**)&g_splitk_ws[dev], SPLITK_WS_BYTES));  // once per device, on the first (eager) use
+  p.split_k = split_k;
+  p.partial = g_splitk_ws[dev];
+  constexpr int SMEM = 4 * (BM + BN) * 64 + 8 * 128 * 4;
+  auto kern = gemm_pp_kernel<FP8, ACT, 2, -1, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblk * split_k), dim3(512), SMEM, s, p);
+  FLUXMI_LAUNCH_CHECK();
+  if (p.epi == FLUXMI_EPI_GATE_RESID) hipLaunchKernelGGL(splitk_reduce_kernel<FLUXMI_EPI_GATE_RESID>, dim3(t * BM), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<FLUXMI_EPI_BF16>, dim3(t * BM), dim3(256), 0, s, p);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
 template <bool FP8, int ACT>
 int launch_pp_cfg(FluxmiGemmParams& p, hipStream_t s) {
   // the hot epilogues get a kernel compiled for them alone (fp8 x e5m2: the calibrated step; bf16: VAE / text encoders / bf16 flow)
@@ -271,6 +374,16 @@ int launch_pp_cfg(FluxmiGemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int split_k, hipStream_t s) {
+  FLUXMI_REQUIRE(fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, 13), "gemm split-K: shape N=%d K=%d not tileable", p.N, p.K);
+  for (int i = 0; i < p.n_groups; ++i) FLUXMI_REQUIRE(!p.g[i].vt_out && !p.g[i].k_out, "gemm split-K: no fused K / V^T outputs");
+  if (is_fp8) {
+    if (act_fmt == FLUXMI_FMT_E5M2) return launch_pp_splitk<true, FLUXMI_FMT_E5M2>(p, split_k, s);
+    return launch_pp_splitk<true, FLUXMI_FMT_E4M3>(p, split_k, s);
+  }
+  return launch_pp_splitk<false, FLUXMI_FMT_E5M2>(p, split_k, s);
+}
 
 // config 13 = 256x256 ping-pong ring (8 waves)
 int fluxmi_launch_gemm_ring(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s) {

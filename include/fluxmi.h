@@ -92,8 +92,12 @@ int fluxmi_abi_version(void);
 /* Grouped linear.  is_fp8=1: A is `act_fmt` fp8, W is e4m3fn (torch._scaled_mm, float8_quantize.py:284-292);
  * is_fp8=0: A, W bf16 (F.linear).  tile_cfg: -1 auto (cost model + split of a thin last round, what the engine uses);
  * 13 = 256x256 ping-pong LDS ring (K*bytes % 64 == 0); 16 = 256x256 with one wave per SIMD (K*bytes % 256 == 0); 2 = 128x128 and 15 = 128x64
- * double-buffered tiles (K*bytes % 128 == 0); 100 = generic any-shape kernel.  Every config computes the same bits.  (Other numbers
- * named kernel generations that were removed: they are rejected.) */
+ * double-buffered tiles (K*bytes % 128 == 0); 100 = generic any-shape kernel.  Every one of these computes the same bits.  (Other numbers
+ * named kernel generations that were removed: they are rejected.)  113 + S (S = 2..32): config 13 with SPLIT-K -- S workgroups per tile, each
+ * over its own K range, fp32 partial tiles in a 256 MiB per-device scratch (allocated by the first such launch) summed in ascending K
+ * order by a second pass that applies the epilogue (FLUXMI_EPI_BF16 / FLUXMI_EPI_GATE_RESID only).  The auto dispatch uses it for bf16
+ * launches of <= 128 tiles (M <= 512: Flux-schnell at 256x256, the text encoders): deterministic, <= 1 bf16 ulp of fp64 like the others, but
+ * not bit-identical to the unsplit kernels (the fp32 sum is associated differently). */
 int fluxmi_gemm_grouped(const fluxmi_gemm_group_t* groups, int n_groups, int N, int K, int is_fp8, int act_fmt,
                         int epilogue, int tile_cfg, void* stream);
 /* single-problem convenience form of the above (F8Linear.forward after quantisation) */

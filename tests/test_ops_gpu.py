@@ -177,6 +177,71 @@ def test_f8_gemm_production_shapes_auto_dispatch(ops, dev, which):
         print(f"{which} group {gi}: {len(rows)} rows x {N} columns within 1 bf16 ulp of fp64, bit-exact {ex:.5f}")
 
 
+@pytest.mark.parametrize("case", ["bf16 linear2 M=512", "bf16 mlp2 txt+img", "bf16 mlp2 ragged M", "fp8 forced S=5"])
+def test_gemm_split_k(ops, dev, case):
+    """Small-M launches: `S` workgroups per 256x256 tile, each over its own K range, fp32 partial tiles + a reduce pass that applies the
+    epilogue (gemm_ring.hip).  The shapes the auto dispatch splits (bf16, <= 128 tiles: Flux-schnell 256x256 = BASELINE configs[0], the
+    text encoders) with both epilogues, grouped txt + img launches, a ragged M, and a forced split of an fp8 problem (the per-tensor scales
+    are then applied by the reduce pass): every row within 1 bf16 ulp of fp64; 5 launches bit-identical; the auto dispatch == the forced
+    split it is expected to choose."""
+    from fluxmi import _lib
+
+    g = torch.Generator().manual_seed(len(case))
+    cases = {"bf16 linear2 M=512": ((512,), 3072, 15360, False, _lib.EPI_GATE_RESID, 10), "bf16 mlp2 txt+img": ((256, 256), 3072, 12288, False, _lib.EPI_GATE_RESID, 8),
+             "bf16 mlp2 ragged M": ((300, 77), 3072, 12288, False, _lib.EPI_BF16, 7), "fp8 forced S=5": ((512,), 1024, 4096, True, _lib.EPI_BF16, 5)}
+    Ms, N, K, fp8, epi, S = cases[case]
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    bias, gate = torch.randn(N, generator=g).bfloat16(), torch.randn(N, generator=g).bfloat16()
+    if fp8:
+        w8, sb, sbr = fo.quantize_weight(w)
+        dw, dsbr = w8.to(dev), sbr.to(dev)
+    else:
+        dw, dsbr = w.to(dev), None
+    dbias, dgate = bias.to(dev), gate.to(dev)
+    groups, keep, checks = [], [], []
+    for M in Ms:
+        a = torch.randn(M, K, generator=g).bfloat16()
+        a[:, 3] += 1.5
+        x = torch.randn(M, N, generator=g).bfloat16()
+        if fp8:
+            sa = fo.amax_to_scale(a.abs().max().float(), 57344.0)
+            a_op = fo.to_fp8_saturated(a, sa, 57344.0).to(torch.float8_e5m2)
+            sar = sa.reciprocal()
+            dsar = sar.to(dev)
+        else:
+            a_op, sar, dsar = a, None, None
+        da, dx = a_op.to(dev), x.to(dev)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        keep += [da, dx, out, dsar]
+        kw = dict(gate=ops._p(dgate), resid=ops._p(dx), ldr=N) if epi == _lib.EPI_GATE_RESID else {}
+        groups.append(ops.make_group(ops._p(da), ops._p(dw), ops._p(dbias), ops._p(dsar) if fp8 else None, ops._p(dsbr) if fp8 else None, ops._p(out), M, K, N, **kw))
+        checks.append((out, a_op, sar, x))
+    runs = []
+    for cfg in [113 + S] * 5 + ([-1] if not fp8 else []):
+        for c in checks:
+            c[0].fill_(float("nan"))
+        ops.gemm_grouped(groups, N, K, fp8, E5M2, epi, cfg)
+        torch.cuda.synchronize()
+        runs.append([c[0].clone() for c in checks])
+    for r in runs[1:]:
+        for a_, b_ in zip(runs[0], r):
+            assert torch.equal(a_.view(torch.int16), b_.view(torch.int16)), f"{case}: split-K launches differ (the last one is the auto dispatch)"
+    for gi, (out, a_op, sar, x) in enumerate(checks):
+        wref = w8 if fp8 else w
+        acc = a_op.double() @ wref.double().T
+        sc = float(sar * sbr) if fp8 else 1.0
+        h = round_fp64_to_bf16(acc * sc + bias.double())
+        noise = accum_noise(a_op, wref, sc)
+        if epi == _lib.EPI_GATE_RESID:
+            ref = (x.float() + (gate.float() * h.float()).bfloat16().float()).bfloat16()
+            gh = (gate.float() * h.float()).abs().double()
+            mag = torch.maximum(torch.maximum(noise * gate.float().abs()[None, :].double(), gh), x.double().abs())
+            ex = assert_close_mag(runs[0][gi], ref, mag=mag, ulps=2.05, min_exact=0.95, what=f"split-K {case} group {gi}")
+        else:
+            ex = assert_close_mag(runs[0][gi], h, mag=noise, ulps=1.05, min_exact=0.98, what=f"split-K {case} group {gi}")
+        print(f"split-K {case} group {gi} (M={out.shape[0]}): bit-exact vs fp64 {ex:.5f}")
+
+
 def accum_noise(a, w, s):
     """Magnitude (already in 'bf16-ulp units', i.e. multiplied by 2^7) of fp32 accumulation-order noise:
     16*sqrt(K)*2^-24 * sum_k|a||w| * s  (worst case is K*2^-24; the MX MFMA also aligns the 64 products of a block to
