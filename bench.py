@@ -211,15 +211,19 @@ def collect_pmc(cfg_id, Li, Lt):
     out_dir = pmc_dir(cfg_id)
     os.makedirs(out_dir, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
+    t_start, budget_s = time.time(), float(os.environ.get("FLUXMI_BENCH_PMC_BUDGET_S", "480"))  # the counters must not eat the driver's time limit
     for name, Ms, N, K, cnt, epi in gemm_shapes(Li, Lt):
         tag = name.split("(")[0].replace(".", "_")
         for pi, counters in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"])):
             d = os.path.join(out_dir, f"{tag}_p{pi}")
+            left = budget_s - (time.time() - t_start)
+            if left < 20:
+                return
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
                    sys.executable, os.path.join(ROOT, "tools", "gemm_probe.py"), "--shape", f"{sum(Ms)},{N},{K}", "--cfg", "-1", "--iters", "4",
                    "--epi", {"bf16": "bf16", "gate_resid": "gate", "gelu_quant": "gelu", "split": "bf16"}[epi]]
             try:
-                subprocess.run(cmd, env=env, cwd="/tmp", check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+                subprocess.run(cmd, env=env, cwd="/tmp", check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=min(150.0, left))
             except Exception:  # noqa
                 pass
 

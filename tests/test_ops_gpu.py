@@ -110,18 +110,26 @@ def make_f8_problem(M, N, K, fmt, seed):
     return a8, w8, sa.reciprocal(), sbr, bias
 
 
-@pytest.mark.parametrize("cfg", [2, 13, 15, 16, 100])
-@pytest.mark.parametrize("shape", [(256, 256, 64), (256, 256, 128), (512, 768, 256), (300, 512, 384), (37, 256, 3072), (1024, 1024, 1024)])
-@pytest.mark.parametrize("fmt", [E5M2, E4M3])
+def _f8_gemm_cases():
+    """(tile config, shape, activation format): every shape a kernel can tile (config 2 / 15 step K by 128 bytes, 16 by 256), e4m3
+    activations on one representative shape per kernel"""
+    shapes = [(256, 256, 64), (256, 256, 128), (512, 768, 256), (300, 512, 384), (37, 256, 3072), (1024, 1024, 1024)]
+    out = []
+    for cfg in (2, 13, 15, 16, 100):
+        for shape in shapes:
+            K = shape[2]
+            if (K % 128 and cfg in (2, 15)) or (K % 256 and cfg == 16):
+                continue
+            out.append((cfg, shape, E5M2))
+            if shape == (512, 768, 256) and cfg != 15:
+                out.append((cfg, shape, E4M3))
+    return out
+
+
+@pytest.mark.parametrize("cfg,shape,fmt", _f8_gemm_cases(), ids=lambda v: str(v).replace(" ", ""))
 def test_f8_gemm(ops, dev, cfg, shape, fmt):
     """K1: fp8 GEMM on identical quantised operands vs fp64 (float8_quantize.py:284-292): <= 1 bf16 ulp."""
     M, N, K = shape
-    if fmt == E4M3 and (cfg == 15 or shape != (512, 768, 256)):
-        pytest.skip("e4m3 activations: one representative case per kernel")
-    if K % 128 and cfg in (2, 15):
-        pytest.skip("double-buffered kernels step K by 128 bytes")
-    if K % 256 and cfg == 16:
-        pytest.skip("the one-wave-per-SIMD kernel steps K by 256 bytes")
     a8, w8, sar, sbr, bias = make_f8_problem(M, N, K, fmt, seed=M + N + K)
     ref = round_fp64_to_bf16(fo.scaled_mm_fp64(a8, w8, sar, sbr, bias))
     out = ops.linear(a8.to(dev), w8.to(dev), bias.to(dev), sar.to(dev), sbr.to(dev), tile_cfg=cfg)
