@@ -616,3 +616,38 @@ def test_reference_config_jsons_load_and_generate(dev, path, tmp_path):
     pred = pipe.model(d["img"].half(), d["img_ids"].half(), d["txt"].half(), d["txt_ids"].half(), torch.full((1,), 0.5, device=dev).half(),
                       d["y"].half(), torch.full((1,), 3.5, device=dev).half() if tiny.params.guidance_embed else None)
     assert pred.dtype == torch.float16 and torch.isfinite(pred).all()
+
+
+def test_large_batches_in_one_pass_and_in_equal_passes(dev):
+    """The reference has no num_images limit.  The engine takes up to 32 samples per pass (round 2: 8): a batch of 10 in ONE pass must give every
+    sample exactly what it gets alone (samples never interact; the embedder GEMV runs in row chunks of 8), and a batch above the limit
+    runs as EQUAL consecutive passes (35 -> 12 + 12 + 11 padded to 12, one workspace / one graph) with the same bits.
+    A calibrating model refuses the multi-pass form (its trial counters advance once per step, not once per pass)."""
+    from fluxmi import synth
+
+    cfg = tiny_config()
+    model, _, _ = build(cfg, QUANTS["fp8"], dev)
+    H, W, Lt = 64, 64, 32
+    ts = fo.get_schedule(3, (H // 16) * (W // 16))
+    inp = to_dev(synth.make_inputs(cfg.params, H, W, Lt, batch=35, seed=9, real_tokens=8), dev)
+    sl = lambda n: tuple(inp[k][:n].contiguous() for k in ("img", "img_ids", "txt", "txt_ids", "y"))
+    model.denoise(*sl(1), fo.get_schedule(13, (H // 16) * (W // 16)), guidance=3.5)  # calibration on sample 0
+    assert model.calibration_state()[0]
+    ten = model.denoise(*sl(10), ts, guidance=3.5)
+    assert ten.shape[0] == 10 and torch.isfinite(ten).all()
+    alone = [model.denoise(*(t[i:i + 1].contiguous() for t in sl(10)), ts, guidance=3.5) for i in (0, 7, 8, 9)]
+    for i, a in zip((0, 7, 8, 9), alone):
+        assert torch.equal(ten[i].view(torch.int16), a[0].view(torch.int16)), f"sample {i} of a 10-batch differs from the same sample alone"
+    model.MAX_ENGINE_BATCH = 12  # instance override: 35 samples -> three passes of 12 (the last one padded by one copy)
+    try:
+        big = model.denoise(*sl(35), ts, guidance=3.5)
+    finally:
+        del model.MAX_ENGINE_BATCH
+    assert big.shape[0] == 35 and torch.equal(big[:10].view(torch.int16), ten.view(torch.int16))
+    for i in (11, 12, 23, 24, 34):
+        one = model.denoise(*(t[i:i + 1].contiguous() for t in sl(35)), ts, guidance=3.5)
+        assert torch.equal(big[i].view(torch.int16), one[0].view(torch.int16)), f"sample {i} of the 3-pass batch"
+    fresh, _, _ = build(cfg, QUANTS["fp8"], dev)
+    fresh.MAX_ENGINE_BATCH = 12
+    with pytest.raises(ValueError, match="frozen"):
+        fresh.denoise(*sl(35), ts, guidance=3.5)
