@@ -380,6 +380,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: run the multi-rank control flow on a stub engine (CPU tensors)")
     ap.add_argument("--depth", type=int, default=None, help="debug only: fewer blocks (the result is then flagged invalid)")
+    ap.add_argument("--single-rank-group", action="store_true",
+                    help="N = 1 only: create a one-rank process group anyway and run every collective of the N > 1 path through it (broadcast, "
+                         "in-step amax all-reduce from the engine's hook, barriers): exercises the RCCL plumbing on a one-GPU box")
     args = ap.parse_args()
     C = CONFIGS[args.config]
 
@@ -392,6 +395,12 @@ def main():
         return
     if args.gpus > 1 and "RANK" not in os.environ:
         _self_launch(args)
+    # stdout carries exactly ONE line, the JSON: everything else any library writes to fd 1 (RCCL prints a version banner there when a
+    # communicator is created or destroyed) goes to stderr; rank 0 writes the line to the saved descriptor at the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    emit = lambda line: os.write(real_stdout, (line + "\n").encode())
 
     import torch
     import torch.distributed as td
@@ -399,6 +408,13 @@ def main():
     from fluxmi import dist as fdist
 
     rank, world, local = fdist.init_from_env("gloo" if args.dry_run and args.backend != "nccl" else args.backend)
+    group1 = args.single_rank_group and world == 1
+    if group1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if args.backend == "nccl" and not args.dry_run:
+            torch.cuda.set_device(0)
+        td.init_process_group(backend=args.backend, rank=0, world_size=1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
                          "(or without a torchrun environment: the script then launches its own ranks)")
@@ -451,7 +467,7 @@ def main():
         hw = (64, 64, 32) if dry else (C["height"], C["width"], C["txt_len"])
         inp = synth.make_inputs(p, hw[0], hw[1], hw[2], batch=world, seed=0)
         txt, vec, img = (inp[k].to(dev) for k in ("txt", "y", "img"))
-        if world > 1:
+        if world > 1 or group1:
             if rank != 0:
                 txt, vec, img = torch.zeros_like(txt), torch.zeros_like(vec), torch.zeros_like(img)
             txt, vec, img = fdist.broadcast_request(txt, vec, img, src=0)
@@ -460,8 +476,8 @@ def main():
         img_ids, txt_ids = inp["img_ids"][lo:hi].to(dev), inp["txt_ids"][lo:hi].to(dev)
         Li, Lt = img.shape[1], txt.shape[1]
         sched = lambda n: util_schedule(n, Li, shift=not C["schnell"])
-        nranks = td.get_world_size() if world > 1 else 1
-        backend = td.get_backend() if world > 1 else None
+        nranks = td.get_world_size() if (world > 1 or group1) else 1
+        backend = td.get_backend() if (world > 1 or group1) else None
         calibration = None
         if C["quant"] is not None:
             # calibration (untimed): 13 unfused steps freeze every F8Linear input scale.  Batch-sharded replicas MAX-reduce each layer's
@@ -469,7 +485,7 @@ def main():
             # cannot rejoin the others' collectives: it reports and exits non-zero (torch.distributed.run then tears the job down) --
             # there is no silent per-rank fallback.  FLUXMI_BENCH_AMAX_XCHG=0 selects the coarser scheme on purpose: per-rank
             # calibration, then ONE all-reduce of the running-amax trials (fluxmi.dist.sync_calibration).
-            xchg = world > 1 and os.environ.get("FLUXMI_BENCH_AMAX_XCHG", "1") != "0"
+            xchg = (world > 1 or group1) and os.environ.get("FLUXMI_BENCH_AMAX_XCHG", "1") != "0"
             calibration = "in-step per-layer amax all-reduce(MAX)" if xchg else ("per-rank + one all-reduce of the trials" if world > 1 else "single rank")
             try:
                 if xchg:
@@ -503,14 +519,14 @@ def main():
         setup_s = time.time() - t_setup
 
         ts = sched(spr)
-        if world > 1:
+        if world > 1 or group1:
             td.barrier()
         sync()
         t0 = time.perf_counter()
         for _ in range(n_req):
             out = model.denoise(img, img_ids, txt, txt_ids, vec, ts, guidance=3.5, use_graph=not args.no_graph)
         sync()
-        if world > 1:
+        if world > 1 or group1:
             td.barrier()
         elapsed = time.perf_counter() - t0
         finite = bool(torch.isfinite(out.float()).all())
@@ -520,7 +536,7 @@ def main():
             ms_ev, n_ev = _lib.C.c_float(0), _lib.C.c_int(0)
             _lib.call("fluxmi_engine_last_timing", model._engine, _lib.C.byref(ms_ev), _lib.C.byref(n_ev))
             ms_ev_v, n_ev_v = ms_ev.value, n_ev.value
-        if world > 1:
+        if world > 1 or group1:
             tt = torch.tensor([elapsed, 0.0 if finite else 1.0], device=dev, dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             elapsed, finite = float(tt[0].item()), float(tt[1].item()) == 0.0
@@ -607,10 +623,11 @@ def main():
                 result["cpu_baseline"] = {"value": None, "unit": "it/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {ex}"}
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or group1:
         td.barrier()
         td.destroy_process_group()
+    if rank == 0:
+        emit(json.dumps(result))
 
 
 def util_schedule(num_steps, image_seq_len, shift=True):
