@@ -162,7 +162,7 @@ def measure_attention(torch, ops, dev, L, iters=10, H=24):
     Lp = (L + 63) // 64 * 64
     q = torch.randn(1, H, L, 128, device=dev).bfloat16()
     k = torch.randn(1, H, L, 128, device=dev).bfloat16()
-    f16k = os.environ.get("FLUXMI_ATTN_F16K", "1") != "0" and os.environ.get("FLUXMI_ATTN_V") != "1"  # what the engine launches
+    f16k = os.environ.get("FLUXMI_ATTN_F16K", "1") != "0"  # what the engine launches
     if f16k:
         k = k.half()
     vt = torch.randn(1, H, 128, Lp, device=dev).bfloat16()
@@ -179,8 +179,10 @@ def measure_attention(torch, ops, dev, L, iters=10, H=24):
     t = e0.elapsed_time(e1) * 1e-3 / iters
     f = 4.0 * L * L * 128 * H
     wgs = ((L + 255) // 256) * H
-    kern = "attention_kernel (round 1)" if os.environ.get("FLUXMI_ATTN_V") == "1" else (
-        "attention2_kernel (skewed pipeline, deferred rescale" + (", scale + max folded into the f16 QK^T MFMAs)" if f16k else ")"))
+    if f16k and os.environ.get("FLUXMI_ATTN_V") != "2":
+        kern = "attention4_kernel (4 waves x 64 query rows, half-tile skewed pipeline, deferred rescale, scale + max folded into the f16 QK^T MFMAs)"
+    else:
+        kern = "attention2_kernel (8 waves x 32 rows, skewed pipeline, deferred rescale" + (", folded)" if f16k else ")")
     return {"kernel": kern + ", bf16/f16 MFMA 32x32x16, fp8 output", "per_step": 57, "us": round(t * 1e6, 1),
             "achieved": round(f / t / 1e12, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / BF16_PEAK_TFLOPS, 4),
             "note": f"{wgs} workgroups on 256 CUs = {wgs / 256:.2f} rounds"}

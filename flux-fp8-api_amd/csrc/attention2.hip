@@ -1,8 +1,9 @@
-// fluxmi -- flash-attention forward, round-2 pipeline (bf16, head_dim 128, non-causal), gfx950.
+// fluxmi -- flash-attention forward, 8-wave kernel (bf16, head_dim 128, non-causal), gfx950: bf16 K (the unfolded arithmetic) and the
+// cross-check of attention4.hip (FLUXMI_ATTN_V=2).
 //
-// Same math, operands, LDS image and launch geometry as attention.hip (8 waves x 32 query rows, KV tiles of 64, swapped QK^T,
-// P fed to the PV MFMA straight from the accumulator, K / V^T tiles by LDS-DMA into 4-deep rings); what changes is the schedule
-// inside the wave.  The round-1 ISA (profiles/r02_attention_isa_notes.txt) showed where its time went:
+// 8 waves x 32 query rows, KV tiles of 64, swapped QK^T, P fed to the PV MFMA straight from the accumulator, K / V^T tiles by LDS-DMA
+// into 4-deep rings (attention.hip).  The schedule inside the wave answers what the ISA of the round-1 kernel with the same geometry
+// (profiles/r02_attention_isa_notes.txt) showed:
 //   * hipcc sank the whole softmax of tile j (33 v_exp, 21 fma, 16 cvt) plus the 16 v_max3 of tile j+1 into the 16 PV MFMAs
 //     (5.4 VALU per MFMA gap, more than the <= 5 the matrix pipe hides) while the 16 QK^T MFMAs ran with an idle VALU, and the
 //     16 row-sum adds formed ONE dependent chain of v_pk_add behind the barrier with the matrix pipe empty;
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int nqb = (a.L + QB - 1) / QB;
-  const int lid = xcd_remap(blockIdx.x, nqb * a.H * a.B);  // whole heads per XCD (see attention.hip)
+  const int lid = xcd_remap(blockIdx.x, nqb * a.H * a.B);  // whole heads per XCD: a head's K / V^T (2.4 MB at L = 4608) is fetched into one 4 MiB L2 once and shared by its q-blocks
   const int bhid = lid / nqb;
   const int h = bhid % a.H, b = bhid / a.H;
   const int q0 = (lid - bhid * nqb) * QB + wave * 32;

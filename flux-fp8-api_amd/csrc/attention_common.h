@@ -1,4 +1,4 @@
-// fluxmi -- pieces shared by the two attention kernels (attention.hip: round-1 kernel, attention2.hip: the round-2 pipeline).
+// fluxmi -- pieces shared by the two attention kernels (attention2.hip: 8 waves x 32 query rows, attention4.hip: 4 waves x 64) and attention.hip.
 #pragma once
 #include <stdlib.h>
 #include <type_traits>
@@ -17,8 +17,8 @@ struct AttnArgs {
   int B, L, Lp, H;
   float scale_log2;
   int k_f16;  // K holds fp16: the folded kernel (scale * log2 e in Q, -max in the accumulator init), f16 MFMAs for QK^T
-  int abl;  // A/B knobs (FLUXMI_ATTN_ABL, read per call): 1 = no LDS-DMA in the tile loop (round-1 kernel), 2 = no barrier (both timing-only),
-            // 8 = round-1 fp8 store (16 x 4 B per lane)
+  int abl;  // A/B knobs (FLUXMI_ATTN_ABL, read per call): 2 = no barrier in the 8-wave kernel (timing only), 8 = fp8 output through 16 x 4 B
+            // stores per lane (also taken when the output rows are not 16-byte aligned)
 };
 
 namespace {
@@ -133,7 +133,7 @@ __device__ __forceinline__ void store_o(const AttnArgs& a, const v16f (&o)[4], f
       for (int g = 0; g < 4; ++g)
         w[db][g] = cvt4_fp8<FMT>(q_prepare<FMT>(rbf(o[db][g * 4 + 0] * inv), qs), q_prepare<FMT>(rbf(o[db][g * 4 + 1] * inv), qs),
                                  q_prepare<FMT>(rbf(o[db][g * 4 + 2] * inv), qs), q_prepare<FMT>(rbf(o[db][g * 4 + 3] * inv), qs));
-    if (a.abl & 8) {  // round-1 store: 16 x 4 B per lane (A/B)
+    if (a.abl & 8) {  // 16 x 4 B per lane (unaligned rows; A/B)
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -168,5 +168,6 @@ __device__ __forceinline__ void store_o(const AttnArgs& a, const v16f (&o)[4], f
 
 }  // namespace
 
-// round-2 kernel (attention2.hip)
+// round-2 kernel (attention2.hip: 8 waves x 32 rows) and round-3 kernel (attention4.hip: 4 waves x 64 rows, fp16 K)
 int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s);
+int fluxmi_launch_attention4(const AttnArgs& a, int fmt, hipStream_t s);

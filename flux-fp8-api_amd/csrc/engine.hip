@@ -108,15 +108,14 @@ int fuse_kv_level() {
   return lvl;
 }
 
-// FLUXMI_ATTN_F16K (default 1): the K relayout stores fp16 and the attention kernel runs its folded schedule (softmax scale in Q,
-// running max in the accumulator init; include/fluxmi.h, fluxmi_attention).  0 = bf16 K, unfolded kernel.  The fused-K GEMM epilogue
-// (FLUXMI_FUSE_KV=2) writes bf16 K and therefore switches it off.
+// FLUXMI_ATTN_F16K (default 1): the K relayout stores fp16 and attention runs the folded arithmetic (softmax scale in Q, running max in
+// the accumulator init; include/fluxmi.h, fluxmi_attention) on the 4-wave kernel (attention4.hip).  0 = bf16 K, the unfolded 8-wave
+// kernel (attention2.hip).  The fused-K GEMM epilogue (FLUXMI_FUSE_KV=2) writes bf16 K and therefore switches it off.
 int attn_f16k() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("FLUXMI_ATTN_F16K");
-    const char* av = getenv("FLUXMI_ATTN_V");  // FLUXMI_ATTN_V=1: the round-1 cross-check kernel, bf16 K only
-    v = (e ? atoi(e) : 1) && fuse_kv_level() < 2 && !(av && atoi(av) == 1);
+    v = (e ? atoi(e) : 1) && fuse_kv_level() < 2;
   }
   return v;
 }

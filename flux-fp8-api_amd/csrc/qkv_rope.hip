@@ -7,7 +7,7 @@
 //   Q [B,H,L,128]  K [B,H,L,128]      (normalised, rotated, bf16)
 //   VT[B,H,128,Lp]                    V transposed; inside every 16-key group the key order is
 //                                      bit2<->bit3 swapped, which is exactly the k-slot order the PV
-//                                      MFMA of attention.hip consumes -> no transpose in the hot loop.
+//                                      MFMA of the attention kernels consumes -> no transpose in the hot loop.
 // Rows l < split use norm-scale set 0 (txt stream), the rest set 1 (img stream).  Q == nullptr / VT == nullptr: that output is skipped (produced elsewhere).
 #include "common.h"
 #include "fluxmi_internal.h"

@@ -469,7 +469,7 @@ def test_qkv_rope(ops, dev, L, Lt):
     assert torch.equal(VT.cpu(), vpad[:, :, key].transpose(-1, -2))
 
 
-@pytest.mark.parametrize("B,H,L,Lt", [(1, 2, 320, 64), (2, 1, 200, 40), (1, 1, 4608, 512)])
+@pytest.mark.parametrize("B,H,L,Lt", [(1, 2, 320, 64), (2, 1, 200, 40), (1, 2, 33, 8), (1, 1, 97, 32), (1, 1, 4608, 512)])
 def test_attention(ops, dev, B, H, L, Lt):
     """K7: softmax(QK^T/sqrt(128))V vs fp64 (flux_model.py:41-45); bf16 and fused-fp8 outputs."""
     torch.manual_seed(8)
@@ -500,6 +500,16 @@ def test_attention(ops, dev, B, H, L, Lt):
     refq = torch.cat((fo.to_fp8_saturated(out[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float() / s0,
                       fo.to_fp8_saturated(out[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float() / s1), 1)
     assert torch.equal(deq, refq), f"fp8 attention output differs from quantise(bf16 output): {(deq != refq).float().mean().item()}"
+    # fp16 K -> the 4-wave kernel (attention4.hip; what the engine launches): same checks, and its fp8 output == quantise(its bf16 output)
+    k16 = torch.where(k.abs() < 6.2e-5, torch.zeros_like(k), k)  # below fp16's normal range a bf16 value is not exact in fp16
+    ref16 = fo.attention_fp64(q, k16, v).transpose(1, 2).reshape(B, L, H * 128)
+    out4 = ops.attention(d(q), d(k16.half()), d(VT)).cpu()
+    err4 = (out4.double() - ref16).abs().max().item()
+    assert torch.isfinite(out4).all() and err4 <= 2e-2 * v.abs().max().item(), f"attention (4-wave kernel): max abs err {err4}"
+    got4 = ops.attention(d(q), d(k16.half()), d(VT), q_scale0=d(s0), q_scale1=d(s1), split=Lt).cpu()
+    refq4 = torch.cat((fo.to_fp8_saturated(out4[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float(),
+                       fo.to_fp8_saturated(out4[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float()), 1)
+    assert torch.equal(got4.float(), refq4), "fp8 output of the 4-wave kernel differs from quantise(its bf16 output)"
 
 
 def _vt_layout(v, L):
@@ -516,13 +526,13 @@ def _vt_layout(v, L):
 
 @pytest.mark.parametrize("L", [448, 1100, 4608])
 def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
-    """The round-2 kernel rescales O / l / the pending P tile only when a row max grew by more than 2^8 (guide T13).  The branch is
-    rare on random data, so it is FORCED: key rows are spiked against chosen query rows so that the row max jumps by far more than
-    the threshold at chosen tiles (first tile, an odd tile, an even tile, the last tile), some rows several times; every row of the
-    full tensor is checked against fp64, and the builds -- deferred, exact running max (FLUXMI_ATTN_VAR=2), the folded kernel (fp16 K:
-    softmax scale in Q, running max in the accumulator init) with either max tracking, and the independently written round-1 kernel
-    (FLUXMI_ATTN_V=1) -- must agree to rounding.  The fused fp8 output through the regrouped 16-byte stores must equal the round-1
-    4-byte stores bit for bit."""
+    """Both kernels rescale O / l / the pending P tile only when a row max grew by more than 2^8 (guide T13).  The branch is rare on
+    random data, so it is FORCED: key rows are spiked against chosen query rows so that the row max jumps by far more than the threshold
+    at chosen tiles (first tile, an odd tile, an even tile, the last tile; both 32-key halves of a tile), some rows several times; every
+    row of the full tensor is checked against fp64, and the builds -- the 8-wave kernel (attention2.hip) with bf16 K (unfolded) and fp16
+    K (folded: softmax scale in Q, running max in the accumulator init; FLUXMI_ATTN_V=2), the 4-wave kernel (attention4.hip, fp16 K, the
+    engine's default), each with deferred and with exact running max (FLUXMI_ATTN_VAR=2) -- must agree to rounding.  The fused fp8
+    output through the regrouped 16-byte stores must equal the 4-byte stores bit for bit."""
     torch.manual_seed(81)
     B, H = 1, 2
     q = torch.randn(B, H, L, 128).bfloat16()
@@ -532,7 +542,7 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     # scores are q.k/sqrt(128)*log2(e) ~ N(0, 1.44) in the exp2 domain; a key equal to +7 x a query row scores ~ 7*128/11.3*1.44 = 114
     for t_i, (row, tile, gain) in enumerate([(3, 0, 5.0), (3, 3, 7.0), (3, nt - 1, 9.0), (40, 2, 6.0), (41, nt - 2, 6.0), (L - 1, 1, 8.0),
                                              (L // 2, nt // 2, 6.0), (L // 2, nt // 2 + 1, 8.0)]):
-        key = min(tile * 64 + 5 + t_i, L - 1)
+        key = min(tile * 64 + 5 + t_i + 32 * (t_i & 1), L - 1)
         k[:, :, key] = (q[:, :, row].float() * gain).bfloat16()
     k = torch.where(k.abs() < 6.2e-5, torch.zeros_like(k), k)  # below fp16's normal range a bf16 value is not exact in fp16 (engine: |k| ~ 1)
     assert torch.equal(k.half().float(), k.float())
@@ -541,8 +551,8 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     d = lambda t: t.to(dev)
     outs = {}
     knobs = ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V", "FLUXMI_ATTN_ABL")
-    variants = (("deferred", {}, False), ("exact", {"FLUXMI_ATTN_VAR": "2"}, False), ("fold", {}, True), ("fold_exact", {"FLUXMI_ATTN_VAR": "2"}, True),
-                ("round1", {"FLUXMI_ATTN_V": "1"}, False))
+    variants = (("deferred", {}, False), ("exact", {"FLUXMI_ATTN_VAR": "2"}, False), ("fold", {"FLUXMI_ATTN_V": "2"}, True),
+                ("fold_exact", {"FLUXMI_ATTN_V": "2", "FLUXMI_ATTN_VAR": "2"}, True), ("w4", {}, True), ("w4_exact", {"FLUXMI_ATTN_VAR": "2"}, True))
     s0, s1 = torch.tensor(3000.0), torch.tensor(9000.0)
     for name, env, f16 in variants:
         for kk in knobs:
@@ -567,11 +577,14 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     r = lambda n: ((outs[n].double() - ref).norm() / ref.norm()).item()
     # the fold must not cost accuracy (a bf16 fold did: rel-L2 1.8e-3 -> 3.3e-3 on these inputs)
     assert r("fold") <= 1.15 * r("deferred") + 1e-4 and r("fold_exact") <= 1.15 * r("exact") + 1e-4, (r("fold"), r("deferred"), r("fold_exact"), r("exact"))
+    assert r("w4") <= 1.15 * r("deferred") + 1e-4 and r("w4_exact") <= 1.15 * r("exact") + 1e-4, (r("w4"), r("deferred"), r("w4_exact"), r("exact"))
     same = (outs["deferred"] == outs["exact"]).float().mean().item()
     same_f = (outs["deferred"] == outs["fold"]).float().mean().item()
+    same_4 = (outs["fold"] == outs["w4"]).float().mean().item()
     print(f"L={L}: max |err| vs fp64 deferred {e('deferred'):.2e} / exact {e('exact'):.2e} / fold {e('fold'):.2e} / fold_exact {e('fold_exact'):.2e} / "
-          f"round-1 {e('round1'):.2e}; rel-L2 deferred {r('deferred'):.3e} fold {r('fold'):.3e} exact {r('exact'):.3e} fold_exact {r('fold_exact'):.3e} "
-          f"round-1 {r('round1'):.3e}; deferred == exact on {same:.4f}, == fold on {same_f:.4f} of the outputs")
+          f"4-wave {e('w4'):.2e} / 4-wave exact {e('w4_exact'):.2e}; rel-L2 deferred {r('deferred'):.3e} fold {r('fold'):.3e} exact {r('exact'):.3e} "
+          f"fold_exact {r('fold_exact'):.3e} 4-wave {r('w4'):.3e} 4-wave exact {r('w4_exact'):.3e}; deferred == exact on {same:.4f}, == fold on {same_f:.4f}, "
+          f"fold == 4-wave on {same_4:.4f} of the outputs")
 
 
 @pytest.mark.parametrize("L,Lt", [(320, 64), (200, 40)])
