@@ -179,7 +179,7 @@ def measure_attention(torch, ops, dev, L, iters=10, H=24):
     t = e0.elapsed_time(e1) * 1e-3 / iters
     f = 4.0 * L * L * 128 * H
     wgs = ((L + 255) // 256) * H
-    if f16k and os.environ.get("FLUXMI_ATTN_V") != "2":
+    if f16k and os.environ.get("FLUXMI_ATTN_V") == "4":
         kern = "attention4_kernel (4 waves x 64 query rows, half-tile skewed pipeline, deferred rescale, scale + max folded into the f16 QK^T MFMAs)"
     else:
         kern = "attention2_kernel (8 waves x 32 rows, skewed pipeline, deferred rescale" + (", folded)" if f16k else ")")

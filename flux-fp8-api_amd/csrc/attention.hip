@@ -28,14 +28,20 @@ int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, 
   a.scale_log2 = 0.08838834764831845f * 1.4426950408889634f;  // 128^-0.5 * log2(e)
   a.k_f16 = k_f16;
   {
+    // Deferred running max (guide T13): P is bounded by 2^defer_log2 instead of 1, O and l carry the same factor, so the quotient is
+    // unchanged; fp32 holds 4608 keys x 2^24 x |V| with a hundred binades to spare.  FLUXMI_ATTN_THR (read per call) overrides.
+    const char* e = getenv("FLUXMI_ATTN_THR");
+    a.defer_log2 = e ? (float)atof(e) : 8.0f;
+  }
+  {
     const char* e = getenv("FLUXMI_ATTN_ABL");  // read per call (A/B probes flip it inside one process)
     a.abl = e ? atoi(e) : 0;
     // the regrouped fp8 epilogue stores 16 B per lane: rows that are not 16-byte aligned keep the 4-byte stores
     if (out_fp8 && ((((uintptr_t)out) | (uintptr_t)ld_out | (uintptr_t)col_off) & 15)) a.abl |= 8;
   }
-  // fp16 K: the 4-wave kernel (attention4.hip: one wave per SIMD, 64 query rows per wave); bf16 K, or FLUXMI_ATTN_V=2 (read per call: the
-  // tests compare the kernels in one process): the 8-wave kernel (attention2.hip), the independently scheduled cross-check
+  // The 8-wave kernel (attention2.hip) by default.  FLUXMI_ATTN_V=4 (read per call: the tests compare the kernels in one process) selects
+  // the 4-wave kernel (attention4.hip: one wave per SIMD, 64 query rows per wave; fp16 K only): faster on flat score distributions,
+  // slower whenever the deferred running max has to be rescaled, equal inside the step (see its header)
   const char* e = getenv("FLUXMI_ATTN_V");
-  const int v = e ? atoi(e) : 0;
-  return (k_f16 && v != 2) ? fluxmi_launch_attention4(a, fmt, s) : fluxmi_launch_attention2(a, fmt, s);
+  return (k_f16 && e && atoi(e) == 4) ? fluxmi_launch_attention4(a, fmt, s) : fluxmi_launch_attention2(a, fmt, s);
 }

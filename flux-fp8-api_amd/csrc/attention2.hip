@@ -1,5 +1,5 @@
-// fluxmi -- flash-attention forward, 8-wave kernel (bf16, head_dim 128, non-causal), gfx950: bf16 K (the unfolded arithmetic) and the
-// cross-check of attention4.hip (FLUXMI_ATTN_V=2).
+// fluxmi -- flash-attention forward, 8-wave kernel (bf16, head_dim 128, non-causal), gfx950: the engine's kernel (fp16 K: the folded
+// arithmetic; bf16 K: the unfolded one); attention4.hip (FLUXMI_ATTN_V=4) is the 4-wave alternative.
 //
 // 8 waves x 32 query rows, KV tiles of 64, swapped QK^T, P fed to the PV MFMA straight from the accumulator, K / V^T tiles by LDS-DMA
 // into 4-deep rings (attention.hip).  The schedule inside the wave answers what the ISA of the round-1 kernel with the same geometry
@@ -47,7 +47,6 @@ __device__ __forceinline__ void fence() {
 
 constexpr int NW2 = 8, RD2 = 4, LPW2 = 16 / NW2;
 constexpr int VRING2 = RD2 * K_BYTES;
-constexpr float DEFER_LOG2 = 8.0f;  // rescale only when a row max grew by more than 2^8 (in the exp2 domain)
 // EXACT (tests + A/B): exact max tracking, i.e. rescale whenever any row max grows.
 // Measured and dropped in round 2 (profiles/r02_attention_ab.txt): refills in the PV half (-0.4 %), softmax work skewed by one gap so that
 // nothing inside a gap depends on anything in it (-4 %: +17 register moves), row sums by an all-ones MFMA (-4 %), V fragments 2 instead of
@@ -218,7 +217,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     float nmc = 0.f;
     if constexpr (FOLD) {
       // mx = row max of S_j - M.  Rows that grew are moved to their new max (delta = max(mx, 0)); S_j itself was produced with the old M
-      if (__any(mx > (EXACT ? 0.0f : DEFER_LOG2))) {
+      if (__any(mx > (EXACT ? 0.0f : a.defer_log2))) {
         const float delta = fmaxf(mx, 0.f);
         rescale_state(__builtin_amdgcn_exp2f(-delta));
 #pragma unroll
@@ -232,7 +231,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       }
     } else {
       const float m_new = fmaxf(m_run, mx);
-      if (__any((m_new - m_run) * c > (EXACT ? 0.0f : DEFER_LOG2))) {
+      if (__any((m_new - m_run) * c > (EXACT ? 0.0f : a.defer_log2))) {
         rescale_state(__builtin_amdgcn_exp2f((m_run - m_new) * c));
         m_run = m_new;
       }

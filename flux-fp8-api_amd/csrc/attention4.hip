@@ -1,6 +1,15 @@
 // fluxmi -- flash-attention forward, round-3 kernel: FOUR waves per workgroup, one per SIMD, 64 query rows per wave (head_dim 128,
 // non-causal), gfx950.   Reference: `attention` flux_model.py:60-65 (F.scaled_dot_product_attention on bf16 q / k / v).
 //
+// STATUS: selectable (FLUXMI_ATTN_V=4), parity-tested, NOT the engine's default.  Measured on MI355X (profiles/r03_attention4.txt): at
+// B = 1, H = 24, L = 4608 it runs 226 us against 233 us for the 8-wave kernel on scores of unit spread (+3.5 %), but every rescale of
+// the deferred running max costs it ~2000 cycles (128 O registers per wave behind v_accvgpr_read / write, and nothing else on the SIMD
+// to hide them): 236 vs 231 us at a score spread of 3.2 (exp2 domain), 327 vs 258 us at 9; inside the denoise step the two are within
+// 0.2 % (44.41 vs 44.32 ms/step).  Both kernels turn out to be bound by VALU / LDS / LDS-DMA ISSUE, not by the matrix pipe: per 32 MFMAs
+// (1024 cycles) a wave issues 32 v_exp (8.6 cycles each: tools/probes/issue_probe.hip), 32 v_add, 16 v_max3, 16 v_cvt_pk, 16
+// ds_read_b128 (16 cycles each) and 4 LDS-DMA (~39) = ~1000 cycles, and the chip runs the loop at ~1.67 GHz (power); MFMA-busy is 71 %
+// of a workgroup's life for either kernel (profiles/r03_attention4_pmc.txt).
+//
 // Why: the 8-wave kernel (attention2.hip, 32 rows per wave) reads every K and V^T fragment from LDS once per 32 query rows: 8 waves x
 // 32 KiB = 256 KiB of ds_read_b128 traffic per 64-key tile and CU, half of the LDS read rate for the 2 x 1024 MFMA cycles the two waves
 // of a SIMD need for that tile (MFMA busy 57 %, a third of the wave cycles in s_waitcnt: profiles/r02_attention_pmc.txt).  Here a wave
@@ -89,7 +98,6 @@ __device__ __forceinline__ void gapwork4(v16f (&cur)[2], v16f (&nxt)[2], v4i (&p
 
 constexpr int NW4 = 4, RD4 = 4, LPW4 = 16 / NW4;
 constexpr int VRING4 = RD4 * K_BYTES;
-constexpr float DEFER4_LOG2 = 8.0f;  // as attention2.hip: rescale only when a row max grew by more than 2^8
 
 // ABL (timing-only ablations, FLUXMI_ATTN4_ABL): 1 no softmax VALU work, 2 no LDS-DMA refills, 4 no barrier / vmcnt wait, 8 no fragment
 // reads in the loop, 16 no cross-lane max finish / rescale decision, 32 no MFMAs
@@ -343,7 +351,7 @@ __global__ void __launch_bounds__(NW4 * 64, 1) attention4_kernel(const AttnArgs 
         }
         if constexpr (!(ABL & 1)) gapwork4<16 + g>(cur, nxt, pc, l2, m0);
 
-        if constexpr (!(ABL & 17) && g == 14) need = __any(fmaxf(m0[0], m0[1]) > (EXACT ? 0.0f : DEFER4_LOG2));
+        if constexpr (!(ABL & 17) && g == 14) need = __any(fmaxf(m0[0], m0[1]) > (EXACT ? 0.0f : a.defer_log2));
         if constexpr (!(ABL & 2) && T == 0 && (g & 3) == 3) dma_k(PAR, j + 4, g >> 2);
         fence4();
       });

@@ -109,8 +109,8 @@ int fuse_kv_level() {
 }
 
 // FLUXMI_ATTN_F16K (default 1): the K relayout stores fp16 and attention runs the folded arithmetic (softmax scale in Q, running max in
-// the accumulator init; include/fluxmi.h, fluxmi_attention) on the 4-wave kernel (attention4.hip).  0 = bf16 K, the unfolded 8-wave
-// kernel (attention2.hip).  The fused-K GEMM epilogue (FLUXMI_FUSE_KV=2) writes bf16 K and therefore switches it off.
+// the accumulator init; include/fluxmi.h, fluxmi_attention).  0 = bf16 K, the unfolded kernel.  The fused-K GEMM epilogue
+// (FLUXMI_FUSE_KV=2) writes bf16 K and therefore switches it off.
 int attn_f16k() {
   static int v = -1;
   if (v < 0) {

@@ -156,8 +156,9 @@ int fluxmi_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q
 /* softmax(QK^T/sqrt(128))V -> [B,L,H*128] (bf16, or fp8 with the consumer's input scale)   flux_model.py:41-45
  * k_f16 != 0: K holds fp16 (fluxmi_qkv_rope(k_f16 = 1)).  The kernel then multiplies Q by 128^-0.5 * log2(e) while it builds its
  * fragments (fp16, 2^-11 relative rounding), runs QK^T on the f16 MFMA and starts every score accumulator from minus the running
- * maximum, so a score costs one exp2 instead of fma + exp2.  Q and V^T are bf16 either way.  fp16 K runs on the 4-wave kernel
- * (one wave per SIMD, 64 query rows per wave: csrc/attention4.hip), bf16 K on the 8-wave kernel (csrc/attention2.hip). */
+ * maximum, so a score costs one exp2 instead of fma + exp2 (+4.7 % at L = 4608).  Q and V^T are bf16 either way.  Environment, read
+ * per call: FLUXMI_ATTN_V=4 runs fp16-K calls on the 4-wave kernel (csrc/attention4.hip) instead of the 8-wave one (attention2.hip);
+ * FLUXMI_ATTN_THR = log2 of the deferred-rescale threshold (default 8); FLUXMI_ATTN_VAR=2 = exact running max. */
 int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
                      const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, int k_f16,
                      void* stream);

@@ -470,7 +470,7 @@ def test_qkv_rope(ops, dev, L, Lt):
 
 
 @pytest.mark.parametrize("B,H,L,Lt", [(1, 2, 320, 64), (2, 1, 200, 40), (1, 2, 33, 8), (1, 1, 97, 32), (1, 1, 4608, 512)])
-def test_attention(ops, dev, B, H, L, Lt):
+def test_attention(ops, dev, B, H, L, Lt, monkeypatch):
     """K7: softmax(QK^T/sqrt(128))V vs fp64 (flux_model.py:41-45); bf16 and fused-fp8 outputs."""
     torch.manual_seed(8)
     q = torch.randn(B, H, L, 128).bfloat16()
@@ -500,16 +500,21 @@ def test_attention(ops, dev, B, H, L, Lt):
     refq = torch.cat((fo.to_fp8_saturated(out[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float() / s0,
                       fo.to_fp8_saturated(out[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float() / s1), 1)
     assert torch.equal(deq, refq), f"fp8 attention output differs from quantise(bf16 output): {(deq != refq).float().mean().item()}"
-    # fp16 K -> the 4-wave kernel (attention4.hip; what the engine launches): same checks, and its fp8 output == quantise(its bf16 output)
+    # fp16 K (the engine's operand format) through both kernels: the 8-wave folded one and the 4-wave one (FLUXMI_ATTN_V=4)
     k16 = torch.where(k.abs() < 6.2e-5, torch.zeros_like(k), k)  # below fp16's normal range a bf16 value is not exact in fp16
     ref16 = fo.attention_fp64(q, k16, v).transpose(1, 2).reshape(B, L, H * 128)
-    out4 = ops.attention(d(q), d(k16.half()), d(VT)).cpu()
-    err4 = (out4.double() - ref16).abs().max().item()
-    assert torch.isfinite(out4).all() and err4 <= 2e-2 * v.abs().max().item(), f"attention (4-wave kernel): max abs err {err4}"
-    got4 = ops.attention(d(q), d(k16.half()), d(VT), q_scale0=d(s0), q_scale1=d(s1), split=Lt).cpu()
-    refq4 = torch.cat((fo.to_fp8_saturated(out4[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float(),
-                       fo.to_fp8_saturated(out4[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float()), 1)
-    assert torch.equal(got4.float(), refq4), "fp8 output of the 4-wave kernel differs from quantise(its bf16 output)"
+    for ver in (None, "4"):
+        monkeypatch.delenv("FLUXMI_ATTN_V", raising=False)
+        if ver:
+            monkeypatch.setenv("FLUXMI_ATTN_V", ver)
+        out4 = ops.attention(d(q), d(k16.half()), d(VT)).cpu()
+        err4 = (out4.double() - ref16).abs().max().item()
+        assert torch.isfinite(out4).all() and err4 <= 2e-2 * v.abs().max().item(), f"attention (fp16 K, FLUXMI_ATTN_V={ver}): max abs err {err4}"
+        got4 = ops.attention(d(q), d(k16.half()), d(VT), q_scale0=d(s0), q_scale1=d(s1), split=Lt).cpu()
+        refq4 = torch.cat((fo.to_fp8_saturated(out4[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float(),
+                           fo.to_fp8_saturated(out4[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float()), 1)
+        assert torch.equal(got4.float(), refq4), f"fp8 output (fp16 K, FLUXMI_ATTN_V={ver}) differs from quantise(its bf16 output)"
+    monkeypatch.delenv("FLUXMI_ATTN_V", raising=False)
 
 
 def _vt_layout(v, L):
@@ -530,8 +535,8 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     random data, so it is FORCED: key rows are spiked against chosen query rows so that the row max jumps by far more than the threshold
     at chosen tiles (first tile, an odd tile, an even tile, the last tile; both 32-key halves of a tile), some rows several times; every
     row of the full tensor is checked against fp64, and the builds -- the 8-wave kernel (attention2.hip) with bf16 K (unfolded) and fp16
-    K (folded: softmax scale in Q, running max in the accumulator init; FLUXMI_ATTN_V=2), the 4-wave kernel (attention4.hip, fp16 K, the
-    engine's default), each with deferred and with exact running max (FLUXMI_ATTN_VAR=2) -- must agree to rounding.  The fused fp8
+    K (folded: softmax scale in Q, running max in the accumulator init; the engine's default), the 4-wave kernel (attention4.hip, fp16 K,
+    FLUXMI_ATTN_V=4), each with deferred and with exact running max (FLUXMI_ATTN_VAR=2) -- must agree to rounding.  The fused fp8
     output through the regrouped 16-byte stores must equal the 4-byte stores bit for bit."""
     torch.manual_seed(81)
     B, H = 1, 2
@@ -551,8 +556,9 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     d = lambda t: t.to(dev)
     outs = {}
     knobs = ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V", "FLUXMI_ATTN_ABL")
-    variants = (("deferred", {}, False), ("exact", {"FLUXMI_ATTN_VAR": "2"}, False), ("fold", {"FLUXMI_ATTN_V": "2"}, True),
-                ("fold_exact", {"FLUXMI_ATTN_V": "2", "FLUXMI_ATTN_VAR": "2"}, True), ("w4", {}, True), ("w4_exact", {"FLUXMI_ATTN_VAR": "2"}, True))
+    variants = (("deferred", {}, False), ("exact", {"FLUXMI_ATTN_VAR": "2"}, False), ("fold", {}, True),
+                ("fold_exact", {"FLUXMI_ATTN_VAR": "2"}, True), ("w4", {"FLUXMI_ATTN_V": "4"}, True),
+                ("w4_exact", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN_VAR": "2"}, True))
     s0, s1 = torch.tensor(3000.0), torch.tensor(9000.0)
     for name, env, f16 in variants:
         for kk in knobs:

@@ -11,9 +11,9 @@ for H in Hs:
     q = torch.randn(B, H, L, 128, device=dev).bfloat16(); k16 = torch.randn(B, H, L, 128, device=dev).half()
     vt = torch.randn(B, H, 128, L, device=dev).bfloat16(); one = torch.tensor(1.0, device=dev)
     o8 = torch.empty(B, L, H * 128, dtype=torch.float8_e5m2, device=dev)
-    variants = [("v2 (8x32)", {"FLUXMI_ATTN_V": "2"}), ("v4", {}), ("v4 -softmax VALU", {"FLUXMI_ATTN4_ABL": "1"}), ("v4 -DMA", {"FLUXMI_ATTN4_ABL": "2"}),
-                ("v4 -barrier/vmcnt", {"FLUXMI_ATTN4_ABL": "4"}), ("v4 -ds_read", {"FLUXMI_ATTN4_ABL": "8"}), ("v4 -finish/decision", {"FLUXMI_ATTN4_ABL": "16"}),
-                ("v4 -MFMA", {"FLUXMI_ATTN4_ABL": "32"}), ("v4 MFMA+barrier only", {"FLUXMI_ATTN4_ABL": "27"})]
+    variants = [("v2 (8x32)", {"FLUXMI_ATTN_V": "2"}), ("v4", {"FLUXMI_ATTN_V": "4"}), ("v4 -softmax VALU", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN4_ABL": "1"}), ("v4 -DMA", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN4_ABL": "2"}),
+                ("v4 -barrier/vmcnt", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN4_ABL": "4"}), ("v4 -ds_read", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN4_ABL": "8"}), ("v4 -finish/decision", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN4_ABL": "16"}),
+                ("v4 -MFMA", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN4_ABL": "32"}), ("v4 MFMA+barrier only", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN4_ABL": "27"})]
     def setenv(env):
         for kk in ("FLUXMI_ATTN_V", "FLUXMI_ATTN4_ABL"): os.environ.pop(kk, None)
         os.environ.update(env)

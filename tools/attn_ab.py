@@ -1,6 +1,6 @@
 """Interleaved A/B of the attention kernels in ONE process (guide rule 24): the 8-wave kernel (attention2.hip) with bf16 K (unfolded) and fp16 K
-(folded: softmax scale in Q, running max in the accumulator init, f16 MFMAs for QK^T; FLUXMI_ATTN_V=2) vs the 4-wave kernel (attention4.hip, fp16 K,
-the default); FLUXMI_ATTN_VAR=2 = exact running max, FLUXMI_ATTN_ABL 8 = 4-byte fp8 stores, 2 = no barrier [timing only].  Flux-dev shapes, random data.
+(folded: softmax scale in Q, running max in the accumulator init, f16 MFMAs for QK^T; the default) vs the 4-wave kernel (attention4.hip, fp16 K,
+FLUXMI_ATTN_V=4); FLUXMI_ATTN_VAR=2 = exact running max, FLUXMI_ATTN_ABL 8 = 4-byte fp8 stores, 2 = no barrier [timing only].  Flux-dev shapes, random data.
     python tools/attn_ab.py [--rounds 5] [--iters 20] [--L 4608 2816]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,9 +14,9 @@ ap.add_argument("--rounds", type=int, default=5)
 a = ap.parse_args()
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 VARIANTS = [("8-wave bf16 K, 4 B stores", {"FLUXMI_ATTN_ABL": "8"}, False), ("8-wave bf16 K", {}, False),
-            ("8-wave fp16 K (folded)", {"FLUXMI_ATTN_V": "2"}, True), ("8-wave folded, no barrier*", {"FLUXMI_ATTN_V": "2", "FLUXMI_ATTN_ABL": "2"}, True),
-            ("8-wave folded, exact max", {"FLUXMI_ATTN_V": "2", "FLUXMI_ATTN_VAR": "2"}, True), ("4-wave fp16 K", {}, True),
-            ("4-wave, exact max", {"FLUXMI_ATTN_VAR": "2"}, True)]
+            ("8-wave fp16 K (folded)", {}, True), ("8-wave folded, no barrier*", {"FLUXMI_ATTN_ABL": "2"}, True),
+            ("8-wave folded, exact max", {"FLUXMI_ATTN_VAR": "2"}, True), ("4-wave fp16 K", {"FLUXMI_ATTN_V": "4"}, True),
+            ("4-wave, exact max", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN_VAR": "2"}, True)]
 
 
 def setenv(env):

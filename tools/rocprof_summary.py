@@ -1,6 +1,8 @@
-"""Turn a rocprofv3 (ROCm 7.2, rocpd sqlite output) kernel trace into the plain-text per-kernel summary that is
-committed under profiles/:   python tools/rocprof_summary.py <dir-with-*.db> [-o profiles/xyz.txt] [--steady]"""
+"""Turn a rocprofv3 (ROCm 7.2) kernel trace -- rocpd sqlite output (*.db) or `--output-format csv` (*kernel_trace.csv) -- into the
+plain-text per-kernel summary that is committed under profiles/:
+    python tools/rocprof_summary.py <dir-with-*.db or *_kernel_trace.csv> [-o profiles/xyz.txt] [--steady]"""
 import argparse
+import csv
 import glob
 import os
 import re
@@ -27,15 +29,27 @@ def main():
                          "euler_kernel; prints per-step time and launch count per kernel")
     args = ap.parse_args()
     dbs = glob.glob(os.path.join(args.path, "**", "*.db"), recursive=True) if os.path.isdir(args.path) else [args.path]
+    if not dbs and os.path.isdir(args.path):
+        dbs = glob.glob(os.path.join(args.path, "**", "*kernel_trace.csv"), recursive=True)
     if not dbs:
-        sys.exit("no .db found under " + args.path)
+        sys.exit("no .db / *kernel_trace.csv found under " + args.path)
     rows = {}
     steps = 0
     span_ns = 0
     for db in dbs:
-        cur = sqlite3.connect(db).cursor()
+        if db.endswith(".csv"):
+            ks = sorted(((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(db))), key=lambda k: k[1])
+            if not args.steady:
+                for n, s_, e in ks:
+                    k = short(n)
+                    c, t = rows.get(k, (0, 0.0))
+                    rows[k] = (c + 1, t + (e - s_))
+                continue
+        else:
+            cur = sqlite3.connect(db).cursor()
         if args.steady:
-            ks = list(cur.execute("select name, start, end from kernels order by start"))
+            if not db.endswith(".csv"):
+                ks = list(cur.execute("select name, start, end from kernels order by start"))
             calib_end = max([e for n, s_, e in ks if "amax_kernel" in n or "calib_update" in n] or [0])
             eul = [e for n, s_, e in ks if "euler_kernel" in n and s_ > calib_end]
             if not eul:
