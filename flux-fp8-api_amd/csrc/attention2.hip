@@ -216,9 +216,11 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     };
     float nmc = 0.f;
     if constexpr (FOLD) {
-      // mx = row max of S_j - M.  Rows that grew are moved to their new max (delta = max(mx, 0)); S_j itself was produced with the old M
-      if (__any(mx > (EXACT ? 0.0f : a.defer_log2))) {
-        const float delta = fmaxf(mx, 0.f);
+      // mx = this lane's part (32 of the row's 64 keys) of the row max of S_j - M: some row exceeds the threshold iff some lane does, so
+      // the decision needs no cross-lane step; the other half of the row (lane ^ 32) is fetched inside the rare branch.  Rows that grew
+      // are moved to their new max (delta = max(row max, 0)); S_j itself was produced with the old M
+      if (__builtin_expect(__any(mx > (EXACT ? 0.0f : a.defer_log2)), 0)) {
+        const float delta = fmaxf(finish_max(mx), 0.f);
         rescale_state(__builtin_amdgcn_exp2f(-delta));
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -230,8 +232,8 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         asm volatile("" : "+v"(ninit));
       }
     } else {
-      const float m_new = fmaxf(m_run, mx);
-      if (__any((m_new - m_run) * c > (EXACT ? 0.0f : a.defer_log2))) {
+      if (__builtin_expect(__any((mx - m_run) * c > (EXACT ? 0.0f : a.defer_log2)), 0)) {  // per-lane part of the row max, as above
+        const float m_new = fmaxf(m_run, finish_max(mx));
         rescale_state(__builtin_amdgcn_exp2f((m_run - m_new) * c));
         m_run = m_new;
       }
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         rmax(SC);
       });
     }
-    mx = finish_max(m0);
+    mx = m0;
   };
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
