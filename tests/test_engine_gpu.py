@@ -9,7 +9,7 @@ order is bit-identical; residual differences come from attention (flash vs math 
   * bf16 model: pred vs oracle rel-L2 <= 1e-2 per call (measured 5e-3)
   * fp8 models: e5m2 activations have 2 mantissa bits, so a 1-bf16-ulp upstream difference flips ~1/64 of the quantised
     bytes by 25 %: swapping F.scaled_dot_product_attention for an exact fp64 softmax INSIDE the oracle already moves its
-    own output by 3.5e-2 rel-L2 (measured, tests/README).  Gates: rel-L2(engine, oracle-fp8) <= 6e-2 and, SURVEY.md §8c
+    own output by 3.5e-2 rel-L2 (measured).  Gates: rel-L2(engine, oracle-fp8) <= 6e-2 and, SURVEY.md §8c
     gate (iv), rel-L2(engine, oracle-bf16) <= 1.25 x rel-L2(oracle-fp8, oracle-bf16)
   * calibrated input scales (max over 12 running amax values of chaotic activations): within 30 % of the oracle's,
     >= 30 % bit-identical; weight scales and float8_data bytes: bit-identical
