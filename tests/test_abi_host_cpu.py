@@ -438,3 +438,30 @@ def test_diffusers_lora_key_conversion_matches_reference_fixture():
     _, k2 = ll.resolve_lora_state_dict({"lora_unet_double_blocks_0_img_attn_qkv.lora_down.weight": torch.zeros(2, 4),
                                         "lora_unet_single_blocks_1_linear2.lora_up.weight": torch.zeros(4, 2), "not_a_lo_ra_key": torch.zeros(1)})
     assert set(k2) == {"double_blocks.0.img_attn.qkv.lora_A.weight", "single_blocks.1.linear2.lora_B.weight"}
+
+
+def test_rocprof_summary_reads_csv_kernel_trace(tmp_path):
+    """tools/rocprof_summary.py turns a `rocprofv3 --kernel-trace --output-format csv` trace into the per-kernel table committed under
+    profiles/; --steady keeps the fused steps only (dispatches after the last calibration kernel, from the first euler_kernel on)."""
+    import subprocess
+    import sys
+
+    rows = [("amax_kernel", 0, 10), ("calib_update_kernel", 10, 20), ("gemm_pp_kernel<true>", 20, 120), ("euler_kernel", 120, 125)]
+    t = 125
+    for _ in range(3):  # three graph-replayed steps: two GEMMs + one attention + euler each
+        for name, dur in (("gemm_pp_kernel<true>", 100), ("gemm_pp_kernel<true>", 100), ("attention2_kernel<1, true, false>", 50), ("euler_kernel", 5)):
+            rows.append((name, t, t + dur))
+            t += dur
+    d = tmp_path / "prof"
+    d.mkdir()
+    with open(d / "x_kernel_trace.csv", "w") as f:
+        f.write('"Kind","Kernel_Name","Start_Timestamp","End_Timestamp"\n')
+        for name, s, e in rows:
+            f.write(f'"KERNEL_DISPATCH","void (anonymous namespace)::{name}(Args)",{s},{e}\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rocprof_summary.py"), str(d), "--steady"], capture_output=True, text=True, check=True).stdout
+    assert "3 fused graph-replayed denoise steps" in out and "4 launches/step" in out, out
+    line = [ln for ln in out.splitlines() if ln.startswith("gemm_pp_kernel<true>")][0].split()
+    assert line[-4:-1] == ["6", "0.6", "0.10"], line  # 6 calls, 600 ns = 0.6 us in total, 0.10 us each
+    allk = subprocess.run([sys.executable, os.path.join(root, "tools", "rocprof_summary.py"), str(d)], capture_output=True, text=True, check=True).stdout
+    assert [ln for ln in allk.splitlines() if ln.startswith("gemm_pp_kernel<true>")][0].split()[-4] == "7"
