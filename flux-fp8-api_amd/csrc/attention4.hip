@@ -99,7 +99,7 @@ __device__ __forceinline__ void gapwork4(v16f (&cur)[2], v16f (&nxt)[2], v4i (&p
 constexpr int NW4 = 4, RD4 = 4, LPW4 = 16 / NW4;
 constexpr int VRING4 = RD4 * K_BYTES;
 
-// ABL (timing-only ablations, FLUXMI_ATTN4_ABL): 1 no softmax VALU work, 2 no LDS-DMA refills, 4 no barrier / vmcnt wait, 8 no fragment
+// ABL (timing-only ablations, compiled only with -DFLUXMI_ATTN4_ABLATIONS and selected by FLUXMI_ATTN4_ABL): 1 no softmax VALU work, 2 no LDS-DMA refills, 4 no barrier / vmcnt wait, 8 no fragment
 // reads in the loop, 16 no cross-lane max finish / rescale decision, 32 no MFMAs
 template <int FMT, bool EXACT, int ABL = 0>
 __global__ void __launch_bounds__(NW4 * 64, 1) attention4_kernel(const AttnArgs a) {
@@ -424,7 +424,8 @@ template <bool EXACT, int ABL = 0> int launch4(const AttnArgs& a, int fmt, hipSt
 // fp16 K only (the folded arithmetic).  FLUXMI_ATTN_VAR=2 (read per call: the tests sweep it) = exact instead of deferred max tracking.
 int fluxmi_launch_attention4(const AttnArgs& a, int fmt, hipStream_t s) {
   FLUXMI_REQUIRE(a.k_f16, "attention: the 4-wave kernel takes fp16 K");
-  if (const char* ab = getenv("FLUXMI_ATTN4_ABL")) {  // timing-only ablations (results are garbage)
+#ifdef FLUXMI_ATTN4_ABLATIONS  // make EXTRA=-DFLUXMI_ATTN4_ABLATIONS: the timing-only variants behind tools/attn4_abl.py (results are garbage)
+  if (const char* ab = getenv("FLUXMI_ATTN4_ABL")) {
     switch (atoi(ab)) {
       case 1: return launch4<false, 1>(a, fmt, s);
       case 2: return launch4<false, 2>(a, fmt, s);
@@ -436,6 +437,7 @@ int fluxmi_launch_attention4(const AttnArgs& a, int fmt, hipStream_t s) {
       default: break;
     }
   }
+#endif
   const char* e = getenv("FLUXMI_ATTN_VAR");
   return (e && (atoi(e) & 2)) ? launch4<true>(a, fmt, s) : launch4<false>(a, fmt, s);
 }

@@ -1,4 +1,5 @@
-"""Timing-only ablations of attention4 (FLUXMI_ATTN4_ABL): where does a lone wave's time go?"""
+"""Timing-only ablations of attention4 (FLUXMI_ATTN4_ABL): where does a lone wave's time go?
+Needs a library built with the ablation variants:  make -C flux-fp8-api_amd/csrc EXTRA=-DFLUXMI_ATTN4_ABLATIONS"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flux-fp8-api_amd"))
