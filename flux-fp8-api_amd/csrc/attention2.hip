@@ -162,7 +162,10 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       sa[1] = mfma_qk(k_frag(0, cc, 1), qf[cc], sa[1]);
     }
   }
-  if (ragged && ntiles == 1) mask_tile(sa, 0);
+  if (ragged && ntiles == 1) {
+    asm volatile("" ::: "memory");
+    mask_tile(sa, 0);
+  }
   float mx;
   {
     float m0 = sa[0][0];
@@ -293,7 +296,12 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         fence();
       });
     }
-    if (ragged && j + 2 == ntiles) mask_tile(nxt, (j + 1) * KT);  // rare wave-uniform branch between the two halves
+    // Rare wave-uniform branch between the two halves.  The empty asm statement keeps it a BRANCH: without a side effect hipcc
+    // if-converts it into 32 x (v_add, v_cmp, v_cndmask) executed on every tile (96 VALU instructions per wave and tile, found in round 3)
+    if (__builtin_expect(ragged && j + 2 == ntiles, 0)) {
+      asm volatile("" ::: "memory");
+      mask_tile(nxt, (j + 1) * KT);
+    }
     // -- C: O^T += V_{j-1}^T P_{j-1}^T, four independent accumulators; V fragments two ahead; the other 16 scores of P_j and the
     //       row max of S_{j+1} (two scores per gap, v_max3)
     float m0 = nxt[0][0];
