@@ -5,10 +5,10 @@
 // B = 1, H = 24, L = 4608 it runs 226 us against 233 us for the 8-wave kernel on scores of unit spread (+3.5 %), but every rescale of
 // the deferred running max costs it ~2000 cycles (128 O registers per wave behind v_accvgpr_read / write, and nothing else on the SIMD
 // to hide them): 236 vs 231 us at a score spread of 3.2 (exp2 domain), 327 vs 258 us at 9; inside the denoise step the two are within
-// 0.2 % (44.41 vs 44.32 ms/step).  Both kernels turn out to be bound by VALU / LDS / LDS-DMA ISSUE, not by the matrix pipe: per 32 MFMAs
-// (1024 cycles) a wave issues 32 v_exp (8.6 cycles each: tools/probes/issue_probe.hip), 32 v_add, 16 v_max3, 16 v_cvt_pk, 16
+// 0.2 % (44.41 vs 44.32 ms/step).  This kernel is bound by VALU / LDS / LDS-DMA ISSUE as much as by the matrix pipe: per 32 MFMAs (1024
+// cycles) its lone wave issues 32 v_exp (8.6 cycles each: tools/probes/issue_probe.hip), 32 v_add, 16 v_max3, 16 v_cvt_pk, 16
 // ds_read_b128 (16 cycles each) and 4 LDS-DMA (~39) = ~1000 cycles, and the chip runs the loop at ~1.67 GHz (power); MFMA-busy is 71 %
-// of a workgroup's life for either kernel (profiles/r03_attention4_pmc.txt).
+// of a workgroup's life (8-wave kernel: 74 %, held there by its per-tile rendezvous, not by instruction count: profiles/r03_attention4.txt).
 //
 // Why: the 8-wave kernel (attention2.hip, 32 rows per wave) reads every K and V^T fragment from LDS once per 32 query rows: 8 waves x
 // 32 KiB = 256 KiB of ds_read_b128 traffic per 64-key tile and CU, half of the LDS read rate for the 2 x 1024 MFMA cycles the two waves
