@@ -43,5 +43,7 @@ int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, 
   // the 4-wave kernel (attention4.hip: one wave per SIMD, 64 query rows per wave; fp16 K only): faster on flat score distributions,
   // slower whenever the deferred running max has to be rescaled, equal inside the step (see its header)
   const char* e = getenv("FLUXMI_ATTN_V");
-  return (k_f16 && e && atoi(e) == 4) ? fluxmi_launch_attention4(a, fmt, s) : fluxmi_launch_attention2(a, fmt, s);
+  const int v = e ? atoi(e) : 0;
+  if (k_f16 && v == 4) return fluxmi_launch_attention4(a, fmt, s);
+  return fluxmi_launch_attention2(a, fmt, s, k_f16 && v == 3);  // 3: the 8-wave kernel with the barrier between its two MFMA groups
 }

@@ -53,7 +53,12 @@ constexpr int VRING2 = RD2 * K_BYTES;
 // 4 MFMAs ahead (-0.5 %), Q arithmetic under the prologue DMA (-0.7 %), s_setprio 1 for the younger half (-0.3 %), no barrier at all
 // (+0.4 ... 1.8 %, timing only: the barrier is not what the waves wait for), the consumers of a score's exp2 (row-sum add, cvt_pk) run one
 // gap later so that nothing in a gap reads that gap's v_exp_f32 (270 fewer s_nop per four tiles, +-0 %: instruction issue is not the limit)
-template <int FMT, bool FOLD, bool EXACT>
+// MIDBAR (FLUXMI_ATTN_V=3, round 3, selectable): the per-tile barrier sits BETWEEN the two MFMA groups of a step instead of in front of it,
+// so the first K fragments of step j + 1 are read under the last PV MFMAs of step j and the first V^T fragments under the last QK^T
+// MFMAs (with the barrier in front, all eight waves leave it in lockstep and both waves of every SIMD wait out the LDS latency of their
+// first fragments with the matrix pipe idle).  Refill order K0 K1 K2 V0 K3 | step j: V_{j+1} (QK^T half), K_{j+4} (PV half, behind
+// the barrier of step j, where K_j is dead); the barrier of step j waits for K_{j+2} and V_j (two younger groups stay in flight).
+template <int FMT, bool FOLD, bool EXACT, bool MIDBAR = false>
 __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs a) {
   constexpr int QB = NW2 * 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -141,9 +146,11 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   {
     auto iss_k = [&](int t) { dma_k(t, t * KT, 0); dma_k(t, t * KT, 1); };
     auto iss_v = [&](int t) { dma_v(t, t * KT, 0); dma_v(t, t * KT, 1); };
-    iss_k(0); iss_k(1); iss_v(0); iss_k(2); iss_v(1); iss_k(3);
+    if constexpr (MIDBAR) { iss_k(0); iss_k(1); iss_k(2); iss_v(0); iss_k(3); }
+    else { iss_k(0); iss_k(1); iss_v(0); iss_k(2); iss_v(1); iss_k(3); }
   }
-  wait_vm<5 * LPW2>();
+  if constexpr (MIDBAR) wait_vm<3 * LPW2>();  // K0 and K1 (step 0 reads K1 before its barrier)
+  else wait_vm<5 * LPW2>();
   __builtin_amdgcn_s_barrier();
   v16f sa[2], sb[2];
   v4i pfa[4], pfb[4];  // bf16 P fragments as packed words (two tiles: the one the PV MFMAs consume and the one being produced)
@@ -187,6 +194,11 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     mx = 0.f;
   }
 
+  v8bf kpre[2][2], vpre[4];  // MIDBAR: first fragments of the next MFMA group, read one group ahead
+  if constexpr (MIDBAR) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kpre[q >> 1][q & 1] = k_frag(1, q >> 1, q & 1);
+  }
   // ---- one step, compile-time ring slot PAR = j % 4; FIRST: no pending tile (j == 0) ------------------------------------------------
   // cur = S_j (raw scores, turned into P_j in place), nxt = S_{j+1}, pp = bf16 fragments of P_{j-1} (consumed), pc = of P_j (produced)
   auto step = [&](auto PARC, auto FIRSTC, v16f (&cur)[2], v16f (&nxt)[2], v4i (&pp)[4], v4i (&pc)[4], int j) {
@@ -196,9 +208,11 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     constexpr int VS = (PAR + 3) & 3;  // slot of V_{j-1}
     constexpr int VR = (PAR + 2) & 3;  // slot V_{j+2} refills (held V_{j-2})
     // K_{j+1} and V_{j-1} have landed (own pieces; the barrier extends that to every wave); the two younger tile pairs stay in flight
-    wait_vm<4 * LPW2>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!(a.abl & 2)) __builtin_amdgcn_s_barrier();
+    if constexpr (!MIDBAR) {
+      wait_vm<4 * LPW2>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(a.abl & 2)) __builtin_amdgcn_s_barrier();
+    }
     // -- A: running max with deferred rescale (wave-uniform branch, out of the steady state)
     auto rescale_state = [&](float alpha) {
 #pragma unroll
@@ -279,8 +293,13 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
           for (int r = 0; r < 16; ++r) nxt[t][r] = 0.f;
       }
       v8bf kf[3][2];
-      kf[0][0] = k_frag(KS, 0, 0); kf[0][1] = k_frag(KS, 0, 1);
-      kf[1][0] = k_frag(KS, 1, 0); kf[1][1] = k_frag(KS, 1, 1);
+      if constexpr (MIDBAR) {
+        kf[0][0] = kpre[0][0]; kf[0][1] = kpre[0][1];
+        kf[1][0] = kpre[1][0]; kf[1][1] = kpre[1][1];
+      } else {
+        kf[0][0] = k_frag(KS, 0, 0); kf[0][1] = k_frag(KS, 0, 1);
+        kf[1][0] = k_frag(KS, 1, 0); kf[1][1] = k_frag(KS, 1, 1);
+      }
       fence();
       static_for<16>([&](auto SC) {
         constexpr int s = decltype(SC)::value, cc = s >> 1, t = s & 1;
@@ -289,10 +308,16 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         if constexpr (cc + 2 < 8) kf[(cc + 2) % 3][t] = k_frag(KS, cc + 2, t);
         gapwork(std::integral_constant<int, s>{});
         // refills ride in the QK^T half (in the PV half: -0.4 %, profiles/r02_attention_ab.txt)
-        if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
-        if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
-        if constexpr (s == 11) dma_v(VR, (j + 2) * KT, 0);
-        if constexpr (s == 15) dma_v(VR, (j + 2) * KT, 1);
+        if constexpr (MIDBAR) {
+          if constexpr (s == 3) dma_v(KS, (j + 1) * KT, 0);  // V_{j+1} into slot (j + 1) % 4 (held V_{j-3})
+          if constexpr (s == 7) dma_v(KS, (j + 1) * KT, 1);
+          if constexpr (!FIRST && s >= 12) vpre[s - 12] = v_frag(VS, 0, s - 12);
+        } else {
+          if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
+          if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
+          if constexpr (s == 11) dma_v(VR, (j + 2) * KT, 0);
+          if constexpr (s == 15) dma_v(VR, (j + 2) * KT, 1);
+        }
         fence();
       });
     }
@@ -302,6 +327,21 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       asm volatile("" ::: "memory");
       mask_tile(nxt, (j + 1) * KT);
     }
+    if constexpr (MIDBAR) {
+      // K_{j+2} and V_j have landed (own pieces; the barrier extends that to every wave).  Behind it every wave is done with K_j (read by
+      // step j - 1) and K_{j+1} (read above): K_{j+4} goes into K_j's slot below; V_{j-1}, read below, is refilled two steps from now.
+      wait_vm<2 * LPW2>();
+      if (!(a.abl & 2)) __builtin_amdgcn_s_barrier();
+    }
+    constexpr int KSN = (PAR + 2) & 3;  // MIDBAR: slot of K_{j+2}, whose first fragments are read at the end of this step
+    auto midbar_pv_gap = [&](auto SC) {
+      constexpr int s = decltype(SC)::value;
+      if constexpr (MIDBAR) {
+        if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
+        if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
+        if constexpr (s >= 12) kpre[(s - 12) >> 1][(s - 12) & 1] = k_frag(KSN, (s - 12) >> 1, (s - 12) & 1);
+      }
+    };
     // -- C: O^T += V_{j-1}^T P_{j-1}^T, four independent accumulators; V fragments two ahead; the other 16 scores of P_j and the
     //       row max of S_{j+1} (two scores per gap, v_max3)
     float m0 = nxt[0][0];
@@ -316,7 +356,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       constexpr int VPF = 4;
       v8bf vf[VPF + 1];
 #pragma unroll
-      for (int q = 0; q < VPF; ++q) vf[q] = v_frag(VS, q >> 2, q & 3);
+      for (int q = 0; q < VPF; ++q) vf[q] = MIDBAR ? vpre[q] : v_frag(VS, q >> 2, q & 3);
       fence();
       static_for<16>([&](auto SC) {
         constexpr int s = decltype(SC)::value, ch4 = s >> 2, db = s & 3;
@@ -325,6 +365,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         if constexpr (s + VPF < 16) vf[(s + VPF) % (VPF + 1)] = v_frag(VS, (s + VPF) >> 2, (s + VPF) & 3);
         gapwork(std::integral_constant<int, 16 + s>{});
         rmax(SC);
+        midbar_pv_gap(SC);
         fence();
       });
     } else {
@@ -332,6 +373,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         constexpr int s = decltype(SC)::value;
         gapwork(std::integral_constant<int, 16 + s>{});
         rmax(SC);
+        midbar_pv_gap(SC);
       });
     }
     mx = m0;
@@ -374,25 +416,27 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
 
 }  // namespace
 
-template <bool FOLD, bool EXACT> static int launch2(const AttnArgs& a, int fmt, hipStream_t s) {
+template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(const AttnArgs& a, int fmt, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
-    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, MIDBAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, MIDBAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
     attr = true;
   }
   const dim3 grid(((a.L + 255) / 256) * a.H * a.B);
-  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT>), grid, dim3(512), 4 * A_STAGE, s, a);
-  else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT>), grid, dim3(512), 4 * A_STAGE, s, a);
+  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, a);
+  else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, a);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }
 
 // The kernel follows the K operand: fp16 K (AttnArgs.k_f16, produced by fluxmi_qkv_rope(k_f16 = 1)) -> folded kernel, bf16 K -> the
-// unfolded one.  FLUXMI_ATTN_VAR=2 (read per call: the tests sweep it) selects exact instead of deferred max tracking.
-int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s) {
+// unfolded one.  FLUXMI_ATTN_VAR=2 (read per call: the tests sweep it) selects exact instead of deferred max tracking; midbar (fp16 K
+// only): the variant with the barrier between the two MFMA groups (FLUXMI_ATTN_V=3).
+int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s, int midbar) {
   const char* e = getenv("FLUXMI_ATTN_VAR");
   const bool exact = e && (atoi(e) & 2);
+  if (a.k_f16 && midbar) return exact ? launch2<true, true, true>(a, fmt, s) : launch2<true, false, true>(a, fmt, s);
   if (a.k_f16) return exact ? launch2<true, true>(a, fmt, s) : launch2<true, false>(a, fmt, s);
   return exact ? launch2<false, true>(a, fmt, s) : launch2<false, false>(a, fmt, s);
 }

@@ -170,5 +170,5 @@ __device__ __forceinline__ void store_o(const AttnArgs& a, const v16f (&o)[4], f
 }  // namespace
 
 // round-2 kernel (attention2.hip: 8 waves x 32 rows) and round-3 kernel (attention4.hip: 4 waves x 64 rows, fp16 K)
-int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s);
+int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s, int midbar = 0);
 int fluxmi_launch_attention4(const AttnArgs& a, int fmt, hipStream_t s);

@@ -157,7 +157,8 @@ int fluxmi_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q
  * k_f16 != 0: K holds fp16 (fluxmi_qkv_rope(k_f16 = 1)).  The kernel then multiplies Q by 128^-0.5 * log2(e) while it builds its
  * fragments (fp16, 2^-11 relative rounding), runs QK^T on the f16 MFMA and starts every score accumulator from minus the running
  * maximum, so a score costs one exp2 instead of fma + exp2 (+4.7 % at L = 4608).  Q and V^T are bf16 either way.  Environment, read
- * per call: FLUXMI_ATTN_V=4 runs fp16-K calls on the 4-wave kernel (csrc/attention4.hip) instead of the 8-wave one (attention2.hip);
+ * per call: FLUXMI_ATTN_V=4 runs fp16-K calls on the 4-wave kernel (csrc/attention4.hip) instead of the 8-wave one (attention2.hip),
+ * FLUXMI_ATTN_V=3 on the 8-wave kernel with its per-tile barrier between the two MFMA groups (bit-identical results, -1.6 %);
  * FLUXMI_ATTN_THR = log2 of the deferred-rescale threshold (default 8); FLUXMI_ATTN_VAR=2 = exact running max. */
 int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
                      const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, int k_f16,

@@ -503,7 +503,8 @@ def test_attention(ops, dev, B, H, L, Lt, monkeypatch):
     # fp16 K (the engine's operand format) through both kernels: the 8-wave folded one and the 4-wave one (FLUXMI_ATTN_V=4)
     k16 = torch.where(k.abs() < 6.2e-5, torch.zeros_like(k), k)  # below fp16's normal range a bf16 value is not exact in fp16
     ref16 = fo.attention_fp64(q, k16, v).transpose(1, 2).reshape(B, L, H * 128)
-    for ver in (None, "4"):
+    outs16 = {}
+    for ver in (None, "3", "4"):  # 8-wave folded (default), the same with the barrier between its MFMA groups, 4-wave
         monkeypatch.delenv("FLUXMI_ATTN_V", raising=False)
         if ver:
             monkeypatch.setenv("FLUXMI_ATTN_V", ver)
@@ -514,7 +515,9 @@ def test_attention(ops, dev, B, H, L, Lt, monkeypatch):
         refq4 = torch.cat((fo.to_fp8_saturated(out4[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float(),
                            fo.to_fp8_saturated(out4[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float()), 1)
         assert torch.equal(got4.float(), refq4), f"fp8 output (fp16 K, FLUXMI_ATTN_V={ver}) differs from quantise(its bf16 output)"
+        outs16[ver] = out4
     monkeypatch.delenv("FLUXMI_ATTN_V", raising=False)
+    assert torch.equal(outs16[None], outs16["3"]), "the mid-barrier variant runs the same arithmetic as the default 8-wave kernel: bit-identical"
 
 
 def _vt_layout(v, L):
@@ -558,7 +561,8 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     knobs = ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V", "FLUXMI_ATTN_ABL")
     variants = (("deferred", {}, False), ("exact", {"FLUXMI_ATTN_VAR": "2"}, False), ("fold", {}, True),
                 ("fold_exact", {"FLUXMI_ATTN_VAR": "2"}, True), ("w4", {"FLUXMI_ATTN_V": "4"}, True),
-                ("w4_exact", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN_VAR": "2"}, True))
+                ("w4_exact", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN_VAR": "2"}, True), ("mb", {"FLUXMI_ATTN_V": "3"}, True),
+                ("mb_exact", {"FLUXMI_ATTN_V": "3", "FLUXMI_ATTN_VAR": "2"}, True))
     s0, s1 = torch.tensor(3000.0), torch.tensor(9000.0)
     for name, env, f16 in variants:
         for kk in knobs:
@@ -584,6 +588,8 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     # the fold must not cost accuracy (a bf16 fold did: rel-L2 1.8e-3 -> 3.3e-3 on these inputs)
     assert r("fold") <= 1.15 * r("deferred") + 1e-4 and r("fold_exact") <= 1.15 * r("exact") + 1e-4, (r("fold"), r("deferred"), r("fold_exact"), r("exact"))
     assert r("w4") <= 1.15 * r("deferred") + 1e-4 and r("w4_exact") <= 1.15 * r("exact") + 1e-4, (r("w4"), r("deferred"), r("w4_exact"), r("exact"))
+    # FLUXMI_ATTN_V=3 moves the 8-wave kernel's barrier between its two MFMA groups: same arithmetic, bit-identical results
+    assert torch.equal(outs["mb"], outs["fold"]) and torch.equal(outs["mb_exact"], outs["fold_exact"])
     same = (outs["deferred"] == outs["exact"]).float().mean().item()
     same_f = (outs["deferred"] == outs["fold"]).float().mean().item()
     same_4 = (outs["fold"] == outs["w4"]).float().mean().item()

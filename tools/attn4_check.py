@@ -44,7 +44,7 @@ if not a.skip_check:
         VT = vt_layout(v, L)
         d = lambda t: t.to(dev)
         res = {}
-        for name, ver, var in (("v4", 4, None), ("v4_exact", 4, 2), ("v2", 0, None)):
+        for name, ver, var in (("v4", 4, None), ("v4_exact", 4, 2), ("v3", 3, None), ("v3_exact", 3, 2), ("v2", 0, None)):
             setv(ver, var)
             o = ops.attention(d(q), d(k.half()), d(VT)).cpu()
             res[name] = o
@@ -53,6 +53,7 @@ if not a.skip_check:
             good = fin and err <= 2e-2 * v.abs().max().item()
             ok &= good
             print(f"B={B} H={H} L={L:5d} spike={int(spike)} {name:9s}: finite={fin} max|err|={err:.3e} rel-L2={rel:.3e} {'ok' if good else 'FAIL'}", flush=True)
+        print(f"      v3 == v2 on {(res['v3'] == res['v2']).float().mean().item():.4f}; v3_exact == v3 on {(res['v3'] == res['v3_exact']).float().mean().item():.4f}")
         print(f"      v4 == v2 on {(res['v4'] == res['v2']).float().mean().item():.4f}; v4 == v4_exact on {(res['v4'] == res['v4_exact']).float().mean().item():.4f}")
         s0, s1 = torch.tensor(3000.0), torch.tensor(9000.0)
         setv(4)
@@ -60,6 +61,11 @@ if not a.skip_check:
         o = res["v4"]; Lt = L // 3
         refq = torch.cat((fo.to_fp8_saturated(o[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float(), fo.to_fp8_saturated(o[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float()), 1)
         same = torch.equal(g8.float(), refq)
+        setv(3)
+        g83 = ops.attention(d(q), d(k.half()), d(VT), q_scale0=d(s0), q_scale1=d(s1), split=L // 3).cpu()
+        o3 = res["v3"]
+        refq3 = torch.cat((fo.to_fp8_saturated(o3[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float(), fo.to_fp8_saturated(o3[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float()), 1)
+        same = same and torch.equal(g83.float(), refq3)
         ok &= same
         print(f"      fp8 output == quantise(bf16 output): {same}")
     print("CHECK", "PASSED" if ok else "FAILED", flush=True)
@@ -71,7 +77,7 @@ for L in a.L:
     q = torch.randn(B, H, L, 128, device=dev).bfloat16(); k16 = torch.randn(B, H, L, 128, device=dev).half()
     vt = torch.randn(B, H, 128, Lp, device=dev).bfloat16(); one = torch.tensor(1.0, device=dev)
     o8 = torch.empty(B, L, H * 128, dtype=torch.float8_e5m2, device=dev)
-    variants = [("v2 8x32 folded", 0), ("v4 4x64", 4)]
+    variants = [("v2 8x32 folded", 0), ("v3 8x32 mid-barrier", 3), ("v4 4x64", 4)]
     res = {n: [] for n, _ in variants}
     for n, ver in variants:
         setv(ver)
