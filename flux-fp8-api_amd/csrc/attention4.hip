@@ -2,13 +2,14 @@
 // non-causal), gfx950.   Reference: `attention` flux_model.py:60-65 (F.scaled_dot_product_attention on bf16 q / k / v).
 //
 // STATUS: selectable (FLUXMI_ATTN_V=4), parity-tested, NOT the engine's default.  Measured on MI355X (profiles/r03_attention4.txt): at
-// B = 1, H = 24, L = 4608 it runs 226 us against 233 us for the 8-wave kernel on scores of unit spread (+3.5 %), but every rescale of
-// the deferred running max costs it ~2000 cycles (128 O registers per wave behind v_accvgpr_read / write, and nothing else on the SIMD
-// to hide them): 236 vs 231 us at a score spread of 3.2 (exp2 domain), 327 vs 258 us at 9; inside the denoise step the two are within
-// 0.2 % (44.41 vs 44.32 ms/step).  This kernel is bound by VALU / LDS / LDS-DMA ISSUE as much as by the matrix pipe: per 32 MFMAs (1024
-// cycles) its lone wave issues 32 v_exp (8.6 cycles each: tools/probes/issue_probe.hip), 32 v_add, 16 v_max3, 16 v_cvt_pk, 16
-// ds_read_b128 (16 cycles each) and 4 LDS-DMA (~39) = ~1000 cycles, and the chip runs the loop at ~1.67 GHz (power); MFMA-busy is 71 %
-// of a workgroup's life (8-wave kernel: 74 %, held there by its per-tile rendezvous, not by instruction count: profiles/r03_attention4.txt).
+// B = 1, H = 24, L = 4608 it ran 226 us against 233 us for the 8-wave kernel of that day on scores of unit spread (+3.5 %; the 8-wave
+// kernel has since taken over its per-lane rescale decision and runs 225-229 us), but every rescale of the deferred running max costs
+// it ~2000 cycles (128 O registers per wave behind v_accvgpr_read / write, and nothing else on the SIMD to hide them): 237 vs 229 us at
+// a score spread of 3.2 (exp2 domain), 328 vs 255 us at 9; inside the denoise step the two are within 0.2 % (44.41 vs 44.32 ms/step).
+// This kernel is bound by VALU / LDS / LDS-DMA ISSUE as much as by the matrix pipe: per 32 MFMAs (1024 cycles) its lone wave issues
+// 32 v_exp (8.6 cycles each: tools/probes/issue_probe.hip), 32 v_add, 16 v_max3, 16 v_cvt_pk, 16 ds_read_b128 (16 cycles each) and
+// 4 LDS-DMA (~39) = ~1000 cycles, and the chip runs the loop at ~1.67 GHz (power); MFMA-busy is 71 % of a workgroup's life (8-wave
+// kernel: 74 %, held there by its per-tile rendezvous, not by instruction count: profiles/r03_attention4.txt).
 //
 // Why: the 8-wave kernel (attention2.hip, 32 rows per wave) reads every K and V^T fragment from LDS once per 32 query rows: 8 waves x
 // 32 KiB = 256 KiB of ds_read_b128 traffic per 64-key tile and CU, half of the LDS read rate for the 2 x 1024 MFMA cycles the two waves
@@ -31,9 +32,10 @@
 // VALU read; hipcc pads with s_nop, which a lone wave cannot hide): see gapwork4.  The compiler sees no MFMA there, so the MFMA -> VALU
 // read distance is kept by construction (a score block is read >= 16 MFMAs after its last accumulation; the rare rescale / mask
 // branches pad with s_nop).  Nothing of a half-step waits on LDS latency with the matrix pipe idle: the first K fragments of half-step
-// h + 1 are read under the last PV MFMAs of half-step h, the first V^T fragments under the last QK^T MFMAs, the cross-lane finish of the
-// row max and the rescale decision under the PV MFMAs; the one barrier per 64-key tile sits between the two MFMA groups of the even
-// half-step, where the next tiles' visibility is needed neither by the fragments already in registers nor by the refills issued next.
+// h + 1 are read under the last PV MFMAs of half-step h, the first V^T fragments under the last QK^T MFMAs, the rescale decision (on the
+// per-lane part of the row max; the cross-lane finish lives in the cold branch) is taken two gaps before the branch that reads it; the
+// one barrier per 64-key tile sits between the two MFMA groups of the even half-step, where the next tiles' visibility is needed neither
+// by the fragments already in registers nor by the refills issued next.
 #include "attention_common.h"
 
 namespace {
