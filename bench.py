@@ -92,7 +92,7 @@ def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
 
     one = torch.tensor(1.0, device=dev)
     H = 3072
-    lut = ops.build_quant_lut(one, _lib.E5M2, act=1) if (fp8 and os.environ.get("FLUXMI_QLUT", "1") != "0") else None
+    lut = ops.build_quant_lut(one, _lib.E5M2, act=1) if (fp8 and _lib.get_tuning().qlut) else None
     lut_ptr = lut.data_ptr() if lut is not None else None
     tot_t = tot_f = tot_b = 0.0
     n_launch, table = 0, []
@@ -162,7 +162,9 @@ def measure_attention(torch, ops, dev, L, iters=10, H=24):
     Lp = (L + 63) // 64 * 64
     q = torch.randn(1, H, L, 128, device=dev).bfloat16()
     k = torch.randn(1, H, L, 128, device=dev).bfloat16()
-    f16k = os.environ.get("FLUXMI_ATTN_F16K", "1") != "0"  # what the engine launches
+    from fluxmi import _lib
+
+    f16k = bool(_lib.get_tuning().attn_f16k)  # what the engine launches
     if f16k:
         k = k.half()
     vt = torch.randn(1, H, 128, Lp, device=dev).bfloat16()
@@ -179,17 +181,14 @@ def measure_attention(torch, ops, dev, L, iters=10, H=24):
     t = e0.elapsed_time(e1) * 1e-3 / iters
     f = 4.0 * L * L * 128 * H
     wgs = ((L + 255) // 256) * H
-    if f16k and os.environ.get("FLUXMI_ATTN_V") == "4":
-        kern = "attention4_kernel (4 waves x 64 query rows, half-tile skewed pipeline, deferred rescale, scale + max folded into the f16 QK^T MFMAs)"
-    else:
-        kern = "attention2_kernel (8 waves x 32 rows, skewed pipeline, deferred rescale" + (", folded)" if f16k else ")")
+    kern = "attention2_kernel (8 waves x 32 rows, skewed pipeline, deferred rescale" + (", folded, barrier between the MFMA groups)" if f16k else ")")
     return {"kernel": kern + ", bf16/f16 MFMA 32x32x16, fp8 output", "per_step": 57, "us": round(t * 1e6, 1),
             "achieved": round(f / t / 1e12, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / BF16_PEAK_TFLOPS, 4),
             "note": f"{wgs} workgroups on 256 CUs = {wgs / 256:.2f} rounds"}
 
 
 def pmc_file(kind, cfg_id):
-    return os.path.join(ROOT, "profiles", f"r03_{kind}_config{cfg_id}.json")
+    return os.path.join(ROOT, "profiles", f"r04_{kind}_config{cfg_id}.json")
 
 
 def read_pmc(kind, cfg_id):
@@ -222,8 +221,9 @@ def collect_pmc(cfg_id, Li, Lt):
             if left < 20:
                 return
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
-                   sys.executable, os.path.join(ROOT, "tools", "gemm_probe.py"), "--shape", f"{sum(Ms)},{N},{K}", "--cfg", "-1", "--iters", "4",
-                   "--epi", {"bf16": "bf16", "gate_resid": "gate", "gelu_quant": "gelu", "split": "bf16"}[epi]]
+                   sys.executable, os.path.join(ROOT, "tools", "gemm_probe.py"), "--shape", f"{sum(Ms)},{N},{K}",
+                   *(["--groups", ",".join(str(m) for m in Ms)] if len(Ms) > 1 else []), "--cfg", "-1", "--iters", "4",
+                   "--epi", {"bf16": "bf16", "gate_resid": "gate", "gelu_quant": "gelu", "split": "split"}[epi]] + (["--vt"] if epi == "split" else [])
             try:
                 subprocess.run(cmd, env=env, cwd="/tmp", check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=min(150.0, left))
             except Exception:  # noqa
@@ -231,7 +231,7 @@ def collect_pmc(cfg_id, Li, Lt):
 
 
 def summarize_pmc(cfg_id, Li, Lt):
-    """raw CSVs -> profiles/r03_{traffic,mfma}_config<id>.json, keyed by the kernel-source hash.  HBM bytes per launch =
+    """raw CSVs -> profiles/r04_{traffic,mfma}_config<id>.json, keyed by the kernel-source hash.  HBM bytes per launch =
     (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 tallies a 128-B fabric read at 64 B: MI355X_MICROARCH.md 'HBM'); matrix-pipe busy fraction =
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs).  The first dispatch of every kernel (cold caches, lazy init) is
     dropped; the 256x256 kernels of a launch are summed with its 128x128 peel."""
@@ -312,6 +312,72 @@ def synthetic_lora(p, rank=16, seed=5):
     return lora
 
 
+def _clock_from_samples(c):
+    """[R + 1][8 blocks][xcc id, s_memtime, s_memrealtime] -> per repeat the average shader clock in GHz (None if the counters do not
+    behave like a shader-clock / 100 MHz pair).  Block b of a sample runs on some XCD; consecutive samples are paired by XCC id because
+    the shader-clock counters of different XCDs are not aligned."""
+    out = []
+    for r in range(c.shape[0] - 1):
+        per_x = []
+        a = {int(c[r, b, 0]): (int(c[r, b, 1]), int(c[r, b, 2])) for b in range(8)}
+        for b in range(8):
+            x, t1, rt1 = int(c[r + 1, b, 0]), int(c[r + 1, b, 1]), int(c[r + 1, b, 2])
+            if x in a and rt1 > a[x][1] and t1 > a[x][0]:
+                per_x.append((t1 - a[x][0]) / (rt1 - a[x][1]) * 0.1)  # cycles per 10 ns tick -> GHz
+        per_x.sort()
+        out.append(round(per_x[len(per_x) // 2], 3) if per_x else None)
+    return out
+
+
+class _PowerSampler:
+    """Board power (and sclk, when hwmon exposes it) sampled from sysfs every 20 ms while a timed repeat runs.  Best effort: absent
+    files -> summary() is None.  Reading sysfs from a host thread does not touch the GPU queue."""
+
+    def __init__(self):
+        import glob
+        import threading
+
+        self._threading = threading
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+        self.pfile = cands[0] if cands else None
+        f = sorted(glob.glob(os.path.dirname(self.pfile) + "/freq1_input")) if self.pfile else []
+        self.ffile = f[0] if f else None
+        self.watts, self.mhz, self._run, self._th = [], [], False, None
+
+    def _loop(self):
+        while self._run:
+            try:
+                with open(self.pfile) as fh:
+                    self.watts.append(int(fh.read().strip()) / 1e6)
+                if self.ffile:
+                    with open(self.ffile) as fh:
+                        self.mhz.append(int(fh.read().strip()) / 1e6)
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.02)
+
+    def start(self):
+        if not self.pfile:
+            return
+        self._run = True
+        self._th = self._threading.Thread(target=self._loop, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._run = False
+        if self._th:
+            self._th.join(timeout=1.0)
+            self._th = None
+
+    def summary(self):
+        if not self.watts:
+            return None
+        d = {"source": self.pfile, "samples": len(self.watts), "watts_mean": round(sum(self.watts) / len(self.watts), 1), "watts_max": round(max(self.watts), 1)}
+        if self.mhz:
+            d["hwmon_sclk_mhz_mean"] = round(sum(self.mhz) / len(self.mhz), 1)
+        return d
+
+
 class _StubFlux:
     """--dry-run: CPU stand-in with the surface of modules.flux_model.Flux that this script drives (denoise, calibration state, amax
     exchange).  Per-sample arithmetic only, like the real model, so sharded == whole-batch; every calibrating step issues one
@@ -377,7 +443,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--pmc", action="store_true", help="force the live rocprofv3 PMC passes (default: on at N = 1 when rocprofv3 is on PATH)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (~2 min)")
-    ap.add_argument("--pmc-summarize", action="store_true", help="no GPU: rebuild profiles/r03_*_config<id>.json from gpurun_out/pmc_config<id>/")
+    ap.add_argument("--pmc-summarize", action="store_true", help="no GPU: rebuild profiles/r04_*_config<id>.json from gpurun_out/pmc_config<id>/")
+    ap.add_argument("--requests", type=int, default=3, help="timed repeats of the K steps (each bracketed and timed on its own; the median is reported)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: run the multi-rank control flow on a stub engine (CPU tensors)")
@@ -521,44 +588,83 @@ def main():
         setup_s = time.time() - t_setup
 
         ts = sched(spr)
-        if world > 1 or group1:
-            td.barrier()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(n_req):
-            out = model.denoise(img, img_ids, txt, txt_ids, vec, ts, guidance=3.5, use_graph=not args.no_graph)
-        sync()
-        if world > 1 or group1:
-            td.barrier()
-        elapsed = time.perf_counter() - t0
-        finite = bool(torch.isfinite(out.float()).all())
+        # ---- timed region: R back-to-back repeats of the SAME K steps, each bracketed by barrier + synchronize on both sides and timed
+        # on its own; the line reports the MEDIAN repeat (">= 3 full graph replays, median") and every repeat beside it.
+        # Around each repeat one tiny kernel samples the shader-clock counter and the 100 MHz real-time counter on every XCD
+        # (fluxmi_clock_sample): their ratio is the clock the chip SUSTAINED over that repeat -- this workload is power-limited, and a
+        # slow box or a throttling one shows up here instead of as unexplained spread.  Board power / sclk from hwmon, when readable.
+        R = max(1, args.requests)
+        clk = None if dry else torch.zeros((R + 1) * 8 * 3, dtype=torch.int64, device=dev)
+        power = _PowerSampler() if (not dry and rank == 0) else None
+        elapsed_each, finite = [], True
+        out = None
+        for rep in range(R):
+            if world > 1 or group1:
+                td.barrier()
+            sync()
+            if clk is not None and rep == 0:
+                _lib.call("fluxmi_clock_sample", clk.data_ptr(), ops._stream())
+                sync()
+            if power:
+                power.start()
+            t0 = time.perf_counter()
+            for _ in range(n_req):
+                out = model.denoise(img, img_ids, txt, txt_ids, vec, ts, guidance=3.5, use_graph=not args.no_graph)
+            sync()
+            if world > 1 or group1:
+                td.barrier()
+            el = time.perf_counter() - t0
+            if power:
+                power.stop()
+            if clk is not None:
+                _lib.call("fluxmi_clock_sample", clk.data_ptr() + (rep + 1) * 8 * 3 * 8, ops._stream())
+                sync()
+            finite = finite and bool(torch.isfinite(out.float()).all())
+            if world > 1 or group1:
+                tt = torch.tensor([el, 0.0 if finite else 1.0], device=dev, dtype=torch.float64)
+                td.all_reduce(tt, op=td.ReduceOp.MAX)
+                el, finite = float(tt[0].item()), float(tt[1].item()) == 0.0
+            elapsed_each.append(el)
+        elapsed = sorted(elapsed_each)[len(elapsed_each) // 2] if len(elapsed_each) % 2 else sorted(elapsed_each)[len(elapsed_each) // 2 - 1]
         ms_ev_v, n_ev_v = 0.0, 0
         if not dry:
             # engine-side meter: hipEvents recorded on the launch stream around the graph replays of the LAST request
             ms_ev, n_ev = _lib.C.c_float(0), _lib.C.c_int(0)
             _lib.call("fluxmi_engine_last_timing", model._engine, _lib.C.byref(ms_ev), _lib.C.byref(n_ev))
             ms_ev_v, n_ev_v = ms_ev.value, n_ev.value
+        clock_each = _clock_from_samples(clk.cpu().view(R + 1, 8, 3)) if clk is not None else None
         if world > 1 or group1:
-            tt = torch.tensor([elapsed, 0.0 if finite else 1.0], device=dev, dtype=torch.float64)
-            td.all_reduce(tt, op=td.ReduceOp.MAX)
-            elapsed, finite = float(tt[0].item()), float(tt[1].item()) == 0.0
+            # nranks is what the process group REPORTS after a collective over every rank (sum of rank ids): a silently degraded group
+            # (a rank that fell back to a private communicator) shows up here, not as a wrong throughput
+            rid = torch.tensor([float(rank), 1.0], device=dev, dtype=torch.float64)
+            td.all_reduce(rid, op=td.ReduceOp.SUM)
+            nranks_seen, id_sum = int(round(rid[1].item())), int(round(rid[0].item()))
+            if nranks_seen != world or id_sum != world * (world - 1) // 2:
+                print(json.dumps({"error": f"rank {rank}: process group degraded: {nranks_seen} ranks answered (id sum {id_sum}), expected {world}"}),
+                      file=sys.stderr, flush=True)
+                os._exit(4)
+            nranks = nranks_seen
 
         result = None
         if rank == 0:
             steps_done = n_req * spr
             ms_per_step = elapsed / steps_done * 1e3
             its = world * steps_done / elapsed
+            ms_each = [round(e / steps_done * 1e3, 3) for e in elapsed_each]
             fp8 = C["quant"] is not None
             cfg_block = {"workload": f"BASELINE.json configs[{args.config - 1}]: {C['name']}; batch 1 per GPU, Li={Li}+Lt={Lt} tokens, "
-                                     f"{p.depth} double + {p.depth_single_blocks} single blocks, {spr} step(s) per request x {n_req} request(s), "
-                                     "hipGraph denoise loop",
+                                     f"{p.depth} double + {p.depth_single_blocks} single blocks, {spr} step(s) per request x {n_req} request(s) = {steps_done} "
+                                     f"timed steps, repeated {R} times (median reported), hipGraph denoise loop",
                          "baseline_config": args.config, "images_per_gpu": 1, "parallelism": f"batch-sharded replicas x{world}",
                          "nranks": nranks, "backend": backend, "calibration": calibration, "finite_output": finite,
                          "depth_override": args.depth, "lora_fuse_s": None if lora_s is None else round(lora_s, 2)}
             result = {
                 "metric": "denoise it/s, " + C["name"],
                 "value": round(its, 4), "unit": "it/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup,
-                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": round(ms_per_step, 3), "requests": R, "ms_per_step_each": ms_each,
+                "value_range": [round(world * steps_done / max(elapsed_each), 4), round(world * steps_done / min(elapsed_each), 4)],
+                "sustained_shader_clock_ghz_each": clock_each, "board_power": power.summary() if power else None,
+                "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None,
                 "dtype": ("fp8_e4m3 weights x fp8_e5m2 activations (fp32 accumulate), bf16 flow" if fp8 else "bf16 (nn.Linear weights and flow)"),
                 "data": "synthetic seeded request + random-init Flux weights (no checkpoint available offline)",

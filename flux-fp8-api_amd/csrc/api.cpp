@@ -20,13 +20,9 @@ void fluxmi_set_error(const char* fmt, ...) {
 }
 
 // Tile choice: minimise (#waves of tiles over the 256 CUs) x (per-tile cost).  Relative per-tile
-// efficiencies were measured on MI355X (profiles/r01_kernel_sweep.txt); FLUXMI_GEMM_CFG overrides.
+// efficiencies were measured on MI355X (profiles/r01_kernel_sweep.txt); fluxmi_tuning_t.gemm_cfg overrides.
 int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8) {
-  static int forced = -2;
-  if (forced == -2) {
-    const char* e = getenv("FLUXMI_GEMM_CFG");
-    forced = e ? atoi(e) : -1;
-  }
+  const int forced = fluxmi_tuning().gemm_cfg;
   if (forced >= 0 && fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, forced)) return forced;
   // candidates, in order of preference at equal cost; eff = measured relative rate per flop on MI355X at full occupancy
   // (profiles/r01_kernel_sweep.txt): 13 = 256x256 ping-pong ring (1 block/CU), 2 = 128x128 double-buffered (2 blocks/CU), 15 = 128x64
@@ -71,11 +67,11 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
   p.N = N; p.K = K; p.epi = epi;
   int cfg = force_cfg >= 0 && fluxmi_gemm_tile_ok(N, K, is_fp8, force_cfg) ? force_cfg : fluxmi_gemm_auto_cfg(p, is_fp8);
   // small-M launches (M <= 512: schnell 256x256, the text encoders, the modulation GEMMs): 24-96 tiles of 256x256 for 256 CUs, weight-stream
-  // bound -> split K over several workgroups per tile (fp32 partials + a reduce / epilogue pass).  FLUXMI_GEMM_SPLITK=0 turns it off;
+  // bound -> split K over several workgroups per tile (fp32 partials + a reduce / epilogue pass).  fluxmi_tuning_t.gemm_splitk = 0 turns it off;
   // fluxmi_gemm_grouped(tile_cfg = 113 + S) forces S splits (tests).
   {
-    static int sk_on = -1;
-    if (sk_on < 0) { const char* e = getenv("FLUXMI_GEMM_SPLITK"); sk_on = e ? atoi(e) : 1; }
+    const fluxmi_tuning_t tun = fluxmi_tuning();
+    const int sk_on = tun.gemm_splitk;
     int S = 0;
     const int nk = K * (is_fp8 ? 1 : 2) / 64;
     bool fused_out = false;
@@ -85,19 +81,28 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
     const bool can = !fused_out && (epi == FLUXMI_EPI_BF16 || epi == FLUXMI_EPI_GATE_RESID) && fluxmi_gemm_tile_ok(N, K, is_fp8, 13) && tiles > 0;
     // measured on M = 512 bf16 launches (tools/bf16_gemm_probe.py, profiles/r03_small_m.txt): below ~190 K-steps per tile the 128x128 tiles at two
     // workgroups per CU are as fast as any split; above, ~40-50 K-steps per workgroup is the sweet spot (K = 15360: 72 us vs 158 us unsplit)
-    if (force_cfg < 0 && sk_on && !g_splitk_block && can && !is_fp8 && getenv("FLUXMI_GEMM_CFG") == nullptr && tiles <= 128 && nk >= 192)
+    if (force_cfg < 0 && sk_on && !g_splitk_block && can && !is_fp8 && tun.gemm_cfg < 0 && tiles <= 128 && nk >= 192)
       S = (int)std::max<long long>(2, std::min<long long>(std::min<long long>(256 / tiles, (nk + 24) / 48), 16));
     while (S >= 2 && (size_t)S * rows * N * 4 > ((size_t)256 << 20)) --S;
     if (S >= 2) return fluxmi_launch_gemm_splitk(p, is_fp8, act_fmt, S, s);
   }
   // bf16 operands, one thin round of 256x256 tiles (Flux-schnell linear1 at M = 512: 168 tiles): the one-wave-per-SIMD kernel runs the
   // single tile per CU fastest (74 us vs 95 / 98 us for configs 13 / 2, profiles/r03_small_m.txt)
-  if (!is_fp8 && force_cfg < 0 && getenv("FLUXMI_GEMM_CFG") == nullptr && fluxmi_gemm_tile_ok(N, K, is_fp8, 16)) {
+  if (!is_fp8 && force_cfg < 0 && fluxmi_tuning().gemm_cfg < 0 && fluxmi_gemm_tile_ok(N, K, is_fp8, 16)) {
     long long t256 = 0;
     bool fused_out = false;
     for (int i = 0; i < n; ++i) { t256 += (gs[i].M + 255) / 256; fused_out |= (gs[i].vt_out || gs[i].k_out); }
     t256 *= N / 256;
     if (t256 > 128 && t256 <= 256 && (!fused_out || cfg == 13)) cfg = 16;
+  }
+  // multi-round fp8 launches of the step (single-block linear1: 5.9 rounds of the 256 CUs, double-block mlp.0: 3.0, qkv: 2.25): one
+  // persistent workgroup per CU walks the tiles -- no workgroup relaunch, cold prologue or store drain per tile (gemm_persist.hip).
+  // Single-round launches gain nothing from it and keep the one-tile-per-workgroup kernel.
+  if (cfg == 13 && fluxmi_tuning().gemm_persist && fluxmi_tuning().gemm_cfg < 0 && fluxmi_gemm_persist_ok(p, is_fp8, act_fmt)) {
+    long long t256 = 0;
+    for (int i = 0; i < n; ++i) t256 += (gs[i].M + 255) / 256;
+    t256 *= N / 256;
+    if (t256 > 256) cfg = 18;
   }
   const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0);
   if (cfg < 0 || !split_ok) return fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, s);
@@ -109,8 +114,8 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
 // with 128x128 tiles at two workgroups per CU: 3 + ~0.6 rounds instead of 4.  Results do not depend on the tile shape.
 int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs_in, int n_in, int N, int K, int is_fp8, int act_fmt, int epi, hipStream_t s) {
   std::vector<FluxmiGemmGroup> gs(gs_in, gs_in + n_in);
-  static int hybrid = -1;
-  if (hybrid < 0) { const char* e = getenv("FLUXMI_GEMM_HYBRID"); hybrid = e ? atoi(e) : 1; }
+  const fluxmi_tuning_t tun = fluxmi_tuning();
+  const int hybrid = tun.gemm_hybrid;
   bool fused_attn = false;
   for (auto& g : gs) fused_attn |= (g.vt_out != nullptr || g.k_out != nullptr);
   if (fused_attn) {
@@ -126,7 +131,7 @@ int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs_in, int n_in, int N, int K, i
       FLUXMI_TRY(run_gemm_chunk(gs.data() + off, (int)std::min<size_t>(FLUXMI_MAX_GROUPS, gs.size() - off), N, K, is_fp8, act_fmt, epi, cfg, s));
     return 0;
   }
-  if (hybrid && gs.size() >= 2 && gs.size() <= FLUXMI_MAX_GROUPS && getenv("FLUXMI_GEMM_CFG") == nullptr &&
+  if (hybrid && gs.size() >= 2 && gs.size() <= FLUXMI_MAX_GROUPS && tun.gemm_cfg < 0 &&
       fluxmi_gemm_tile_ok(N, K, is_fp8, 13) && fluxmi_gemm_tile_ok(N, K, is_fp8, 2) &&
       (epi != FLUXMI_EPI_SPLIT || gs[0].split_n % 256 == 0)) {
     std::vector<int> order(gs.size());
@@ -303,6 +308,10 @@ int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, con
 }
 int fluxmi_timestep_embedding(const void* t, const float* freqs, void* out, int B, int half, float time_factor, void* stream) {
   return fluxmi_k_timestep_embedding(t, freqs, out, B, half, time_factor, (hipStream_t)stream);
+}
+int fluxmi_clock_sample(void* out2_dev_u64, void* stream) {
+  FLUXMI_REQUIRE(out2_dev_u64, "clock_sample: NULL argument");
+  return fluxmi_k_clock_sample((unsigned long long*)out2_dev_u64, (hipStream_t)stream);
 }
 int fluxmi_euler(void* img, const void* pred, const float* dts, const int* step, long long n, void* stream) {
   return fluxmi_k_euler(img, pred, dts, step, n, (hipStream_t)stream);

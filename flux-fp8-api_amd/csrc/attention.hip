@@ -1,7 +1,7 @@
 // fluxmi -- flash-attention forward for Flux joint attention (head_dim 128, non-causal), gfx950: argument checks and kernel selection.
 //
 // Replaces F.scaled_dot_product_attention + transpose/reshape (reference flux_model.py:41-45) and, in fused mode, the fp8 quantise of
-// the consumer F8Linear (float8_quantize.py:274-276).  Common to both kernels (attention2.hip, attention4.hip):
+// the consumer F8Linear (float8_quantize.py:274-276).  The kernel (attention2.hip):
 //  * KV tiles of 64 keys; K tile [64][128] and V^T tile [128][64] arrive by LDS-DMA into 4-deep rings, XOR-swizzled via the source
 //    address; one workgroup = 256 query rows, whole heads per XCD (xcd_remap);
 //  * "swapped" QK^T: S^T = K . Q^T on the 32x32x16 MFMA, so a lane owns ONE query row (col = lane & 31) and 16 keys per 32x32 tile ->
@@ -27,23 +27,12 @@ int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, 
   a.B = B; a.L = L; a.Lp = Lp; a.H = H;
   a.scale_log2 = 0.08838834764831845f * 1.4426950408889634f;  // 128^-0.5 * log2(e)
   a.k_f16 = k_f16;
-  {
-    // Deferred running max (guide T13): P is bounded by 2^defer_log2 instead of 1, O and l carry the same factor, so the quotient is
-    // unchanged; fp32 holds 4608 keys x 2^24 x |V| with a hundred binades to spare.  FLUXMI_ATTN_THR (read per call) overrides.
-    const char* e = getenv("FLUXMI_ATTN_THR");
-    a.defer_log2 = e ? (float)atof(e) : 8.0f;
-  }
-  {
-    const char* e = getenv("FLUXMI_ATTN_ABL");  // read per call (A/B probes flip it inside one process)
-    a.abl = e ? atoi(e) : 0;
-    // the regrouped fp8 epilogue stores 16 B per lane: rows that are not 16-byte aligned keep the 4-byte stores
-    if (out_fp8 && ((((uintptr_t)out) | (uintptr_t)ld_out | (uintptr_t)col_off) & 15)) a.abl |= 8;
-  }
-  // The 8-wave kernel (attention2.hip) by default.  FLUXMI_ATTN_V=4 (read per call: the tests compare the kernels in one process) selects
-  // the 4-wave kernel (attention4.hip: one wave per SIMD, 64 query rows per wave; fp16 K only): faster on flat score distributions,
-  // slower whenever the deferred running max has to be rescaled, equal inside the step (see its header)
-  const char* e = getenv("FLUXMI_ATTN_V");
-  const int v = e ? atoi(e) : 0;
-  if (k_f16 && v == 4) return fluxmi_launch_attention4(a, fmt, s);
-  return fluxmi_launch_attention2(a, fmt, s, k_f16 && v == 3);  // 3: the 8-wave kernel with the barrier between its two MFMA groups
+  const fluxmi_tuning_t tun = fluxmi_tuning();
+  // Deferred running max (guide T13): P is bounded by 2^defer_log2 instead of 1, O and l carry the same factor, so the quotient is
+  // unchanged; fp32 holds 4608 keys x 2^24 x |V| with a hundred binades to spare.  fluxmi_tuning_t.attn_defer_log2, validated to [0, 16].
+  a.defer_log2 = tun.attn_defer_log2;
+  a.abl = tun.attn_abl;
+  // the regrouped fp8 epilogue stores 16 B per lane: rows that are not 16-byte aligned keep the 4-byte stores
+  if (out_fp8 && ((((uintptr_t)out) | (uintptr_t)ld_out | (uintptr_t)col_off) & 15)) a.abl |= 8;
+  return fluxmi_launch_attention2(a, fmt, s, (tun.attn_var & 2) != 0);
 }

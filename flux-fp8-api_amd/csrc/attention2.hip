@@ -1,5 +1,7 @@
 // fluxmi -- flash-attention forward, 8-wave kernel (bf16, head_dim 128, non-causal), gfx950: the engine's kernel (fp16 K: the folded
-// arithmetic; bf16 K: the unfolded one); attention4.hip (FLUXMI_ATTN_V=4) is the 4-wave alternative.
+// arithmetic with the per-tile barrier between the two MFMA groups; bf16 K: the unfolded one, barrier at the step start).  The 4-wave
+// kernel of round 3 (one wave per SIMD, 64 query rows per wave) measured equal inside the step and slower on peaky score
+// distributions (profiles/r03_attention4.txt) and left the tree in round 4 (git history: attention4.hip).
 //
 // 8 waves x 32 query rows, KV tiles of 64, swapped QK^T, P fed to the PV MFMA straight from the accumulator, K / V^T tiles by LDS-DMA
 // into 4-deep rings (attention.hip).  The schedule inside the wave answers what the ISA of the round-1 kernel with the same geometry
@@ -430,13 +432,11 @@ template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(const A
   return 0;
 }
 
-// The kernel follows the K operand: fp16 K (AttnArgs.k_f16, produced by fluxmi_qkv_rope(k_f16 = 1)) -> folded kernel, bf16 K -> the
-// unfolded one.  FLUXMI_ATTN_VAR=2 (read per call: the tests sweep it) selects exact instead of deferred max tracking; midbar (fp16 K
-// only): the variant with the barrier between the two MFMA groups (FLUXMI_ATTN_V=3).
-int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s, int midbar) {
-  const char* e = getenv("FLUXMI_ATTN_VAR");
-  const bool exact = e && (atoi(e) & 2);
-  if (a.k_f16 && midbar) return exact ? launch2<true, true, true>(a, fmt, s) : launch2<true, false, true>(a, fmt, s);
-  if (a.k_f16) return exact ? launch2<true, true>(a, fmt, s) : launch2<true, false>(a, fmt, s);
+// The kernel follows the K operand: fp16 K (AttnArgs.k_f16, produced by fluxmi_qkv_rope(k_f16 = 1)) -> the folded kernel with its
+// per-tile barrier between the two MFMA groups (round 3's "mid-barrier" variant: fragments of the next group are read under the last
+// MFMAs of the current one; bit-identical to the barrier-at-step-start build it replaced, -1.6 %), bf16 K -> the unfolded kernel.
+// `exact` (fluxmi_tuning_t.attn_var bit 1) selects exact instead of deferred max tracking (tests).
+int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s, bool exact) {
+  if (a.k_f16) return exact ? launch2<true, true, true>(a, fmt, s) : launch2<true, false, true>(a, fmt, s);
   return exact ? launch2<false, true>(a, fmt, s) : launch2<false, false>(a, fmt, s);
 }

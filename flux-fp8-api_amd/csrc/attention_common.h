@@ -1,4 +1,4 @@
-// fluxmi -- pieces shared by the two attention kernels (attention2.hip: 8 waves x 32 query rows, attention4.hip: 4 waves x 64) and attention.hip.
+// fluxmi -- pieces shared by the attention kernel (attention2.hip: 8 waves x 32 query rows) and attention.hip.
 #pragma once
 #include <stdlib.h>
 #include <type_traits>
@@ -169,6 +169,4 @@ __device__ __forceinline__ void store_o(const AttnArgs& a, const v16f (&o)[4], f
 
 }  // namespace
 
-// round-2 kernel (attention2.hip: 8 waves x 32 rows) and round-3 kernel (attention4.hip: 4 waves x 64 rows, fp16 K)
-int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s, int midbar = 0);
-int fluxmi_launch_attention4(const AttnArgs& a, int fmt, hipStream_t s);
+int fluxmi_launch_attention2(const AttnArgs& a, int fmt, hipStream_t s, bool exact);

@@ -657,10 +657,9 @@ int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void
   a.mod_bstride = mod_bstride; a.q_scale[0] = q0; a.q_scale[1] = q1;
   a.B = B; a.L = L; a.split = split; a.H = H;
   const int nch = (H + 511) / 512;
-  // FLUXMI_LN_V (read per call): 2 = streaming kernel (one 8-wave workgroup per CU, next row's loads under this row's arithmetic),
+  // fluxmi_tuning_t.ln_variant: 2 = streaming kernel (one 8-wave workgroup per CU, next row's loads under this row's arithmetic),
   // 1 = one wave per row, every row resident at once
-  int lnv = 2;
-  { const char* e = getenv("FLUXMI_LN_V"); if (e) lnv = atoi(e); }
+  const int lnv = fluxmi_tuning().ln_variant;
   if (lnv == 2) {
     const int rows = B * L;
     const int n_wg = min(256, (rows + 7) / 8);
@@ -774,6 +773,20 @@ int fluxmi_k_euler(void* img, const void* pred, const float* dts, const int* ste
 int fluxmi_k_set_timestep(void* t_vec, const float* ts, const int* step, int B, hipStream_t s) {
   FLUXMI_REQUIRE(B <= 64, "set_timestep: batch %d > 64", B);
   hipLaunchKernelGGL(set_timestep_kernel, dim3(1), dim3(64), 0, s, (u16*)t_vec, ts, step, B);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+// eight one-lane workgroups (the dispatcher puts block b on XCD b % 8): out[3 b .. 3 b + 2] = {XCC id, shader-clock counter, 100 MHz
+// real-time counter}.  Two samples around a region, paired by XCC id (the shader-clock counters of different XCDs are not aligned),
+// give the average shader clock the chip sustained over it.
+__global__ void clock_sample_kernel(unsigned long long* out) {
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15;  // HW_REG_XCC_ID, bits [3:0]
+  out[3 * blockIdx.x + 0] = xcc;
+  out[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+  out[3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+}
+int fluxmi_k_clock_sample(unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(clock_sample_kernel, dim3(8), dim3(1), 0, s, out);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }

@@ -65,6 +65,7 @@ struct fluxmi_engine {
   bool qlut_valid = false;  // the quantising-epilogue tables reflect the current input scales
   hipGraphExec_t exec = nullptr;
   bool graph_ok = false;
+  unsigned graph_gen = 0;          // fluxmi_tuning_generation() the step graph was captured under: a changed tuning struct re-captures
   bool warmed = false;             // one frozen step of this shape has run eagerly (lazy one-time inits done): later calls may capture at once
   bool txt_emb_valid = false;
   int* d_step0 = nullptr;          // first step of the modulation table (device scalar: the captured graph reads it)
@@ -99,25 +100,17 @@ static u16 host_f2bf(double v) {
   return (u16)(u >> 16);
 }
 
-// FLUXMI_FUSE_KV: 0 = K / V^T by the relayout kernel, 1 (default) = V^T from the qkv GEMM epilogue, 2 = K and V^T from the epilogue.
+// fluxmi_tuning_t.fuse_kv (FLUXMI_FUSE_KV): 0 = K / V^T by the relayout kernel, 1 (default) = V^T from the qkv GEMM epilogue, 2 = K and V^T from the epilogue.
 // Measured in one process (profiles/r01_fuse_kv_ab.txt): 52.23 / 51.50 / 51.70 ms per step -- the transposed V store is free in
 // the epilogue, but K's norm + RoPE is VALU work that the GEMM's 8 waves do slower than the memory-bound relayout kernel.
-int fuse_kv_level() {
-  static int lvl = -1;
-  if (lvl < 0) { const char* e = getenv("FLUXMI_FUSE_KV"); lvl = e ? atoi(e) : 1; }
-  return lvl;
-}
+int fuse_kv_level() { return fluxmi_tuning().fuse_kv; }
 
-// FLUXMI_ATTN_F16K (default 1): the K relayout stores fp16 and attention runs the folded arithmetic (softmax scale in Q, running max in
+// fluxmi_tuning_t.attn_f16k (FLUXMI_ATTN_F16K, default 1): the K relayout stores fp16 and attention runs the folded arithmetic (softmax scale in Q, running max in
 // the accumulator init; include/fluxmi.h, fluxmi_attention).  0 = bf16 K, the unfolded kernel.  The fused-K GEMM epilogue
 // (FLUXMI_FUSE_KV=2) writes bf16 K and therefore switches it off.
 int attn_f16k() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FLUXMI_ATTN_F16K");
-    v = (e ? atoi(e) : 1) && fuse_kv_level() < 2;
-  }
-  return v;
+  const fluxmi_tuning_t t = fluxmi_tuning();
+  return t.attn_f16k && t.fuse_kv < 2;
 }
 
 int lin_count(const fluxmi_model_desc_t& d) { return 6 + (d.guidance_embed ? 2 : 0) + d.depth * 10 + d.depth_single * 3 + 2; }
@@ -396,13 +389,9 @@ int precompute_mods(E* e, int step0, int step_end, const u16* g_vec, const u16* 
 // ---------------------------------------------------------------------------------------------------------
 // Quantising-epilogue tables (frozen scales): one 64 KiB bf16 -> fp8 table per GELU -> F8Linear hand-off (double-block mlp.0 -> mlp.2
 // per stream, single-block linear1 -> linear2), see fluxmi_gemm_group_t.q_lut.  Rebuilt (77 tiny launches) whenever a fused
-// sequence starts, so they always reflect the current input scales.  FLUXMI_QLUT=0 turns them off.
+// sequence starts, so they always reflect the current input scales.  fluxmi_tuning_t.qlut = 0 turns them off.
 // ---------------------------------------------------------------------------------------------------------
-bool qlut_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("FLUXMI_QLUT"); on = e ? atoi(e) : 1; }
-  return on != 0;
-}
+bool qlut_enabled() { return fluxmi_tuning().qlut != 0; }
 int build_qluts(E* e, hipStream_t s) {
   uint8_t* lut = buf<uint8_t>(e, "qlut");
   if (!lut || !qlut_enabled() || e->qlut_valid) return 0;
@@ -728,14 +717,13 @@ void free_ws(E* e) {
 }  // namespace
 
 // roctx ranges (rocprofv3 --marker-trace) around the phases of a denoise call, resolved at run time so that the library has no
-// hard dependency on the profiler: FLUXMI_ROCTX=1 turns them on.
+// hard dependency on the profiler: fluxmi_tuning_t.roctx (FLUXMI_ROCTX=1) turns them on.
 namespace {
 struct Roctx {
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
   Roctx() {
-    const char* on = getenv("FLUXMI_ROCTX");
-    if (!on || !atoi(on)) return;
+    if (!fluxmi_tuning().roctx) return;
     void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return;
@@ -758,6 +746,7 @@ int fluxmi_engine_num_linears(const fluxmi_model_desc_t* desc) { return desc ? l
 int fluxmi_engine_create(const fluxmi_model_desc_t* desc, const fluxmi_linear_t* linears, int n_linears,
                          const void* const* norm_scales, int n_norm_scales, fluxmi_engine_t** out) {
   FLUXMI_REQUIRE(desc && linears && norm_scales && out, "engine_create: NULL argument");
+  fluxmi_log_tuning("engine_create");  // the kernel choices this engine will run with (FLUXMI_LOG=1)
   FLUXMI_REQUIRE(desc->hidden == desc->heads * 128, "engine_create: head_dim must be 128 (hidden %d, heads %d)", desc->hidden, desc->heads);
   FLUXMI_REQUIRE(desc->axes_dim[0] + desc->axes_dim[1] + desc->axes_dim[2] == 128, "engine_create: sum(axes_dim) must be 128");
   FLUXMI_REQUIRE(n_linears == lin_count(*desc), "engine_create: expected %d linears, got %d", lin_count(*desc), n_linears);
@@ -998,6 +987,11 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
         Range r("step-ahead modulation table");
         FLUXMI_TRY(precompute_mods(e, step, win_end, g_arg, y_s, s));
       }
+      if (e->graph_ok && e->graph_gen != fluxmi_tuning_generation()) {
+        e->graph_ok = false;  // kernel choices are baked into a captured graph: never replay one captured under other knobs
+        e->warmed = false;
+        e->qlut_valid = false;
+      }
       if (use_graph && !e->graph_ok) {
         // the first frozen step of a shape runs eagerly so that every lazy one-time init (function attributes) happens outside capture
         if (!e->warmed) {
@@ -1025,6 +1019,7 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
           hipStreamDestroy(cs);
           if (ie != hipSuccess) { fluxmi_set_error("engine_denoise: hipGraphInstantiate failed: %s", hipGetErrorString(ie)); return 2; }
           e->graph_ok = true;
+          e->graph_gen = fluxmi_tuning_generation();
         }
       }
       Range r("frozen steps (hipGraph replay)");

@@ -10,10 +10,11 @@ typedef fluxmi_gemm_group_t FluxmiGemmGroup;
 struct FluxmiGemmParams {
   FluxmiGemmGroup g[FLUXMI_MAX_GROUPS];
   int n_groups, N, K, epi, tiles_m_total, group_m;
-  // split-K (small-M launches, gemm_ring.hip): `split_k` workgroups per tile, each over its own K range, fp32 partial tiles in
+  // split-K (small-M launches, gemm_pp.hip): `split_k` workgroups per tile, each over its own K range, fp32 partial tiles in
   // partial[split][tiles_m_total * 256][N]; fluxmi_launch_splitk_reduce sums them in split order and applies the epilogue
   int split_k;
   float* partial;
+  unsigned long long* dbg;  // per-tile timestamps of the persistent kernel's timing build (tile config 19), else null
 };
 
 // ---- batched skinny GEMV (modulations + embedders, M = batch <= 8) ----------------------------
@@ -59,6 +60,11 @@ void fluxmi_set_error(const char* fmt, ...);
     if (_rc) return _rc;        \
   } while (0)
 
+// ---- kernel-selection knobs (tuning.cpp): a copy of the process-wide struct, and the counter fluxmi_set_tuning bumps
+fluxmi_tuning_t fluxmi_tuning();
+unsigned fluxmi_tuning_generation();
+void fluxmi_log_tuning(const char* why);
+
 // ---- internal launchers (defined in the .hip files) --------------------------------------------
 int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg);
 int fluxmi_gemm_tile_bn(int cfg);
@@ -66,6 +72,9 @@ int fluxmi_gemm_tile_bm(int cfg);
 int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int tile_cfg, hipStream_t s);
 int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
 int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8);
+// persistent 256x256 ping-pong kernel (gemm_persist.hip, tile config 18; 19 = with per-tile timestamps)
+int fluxmi_gemm_persist_ok(const FluxmiGemmParams& p, int is_fp8, int act_fmt);
+int fluxmi_launch_gemm_persist(FluxmiGemmParams& p, int is_fp8, int act_fmt, int timing, hipStream_t s);
 // 256x256 ping-pong tiles with `split_k` K ranges per tile + the reduce / epilogue pass (BF16 and GATE_RESID epilogues)
 void fluxmi_gemm_block_splitk(int on);  // +1 / -1: no M-dependent split-K choice while > 0 (thread-local)
 int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int split_k, hipStream_t s);
@@ -101,6 +110,7 @@ int fluxmi_k_rope_table(const void* ids, const float* omega, const int* axis, vo
 int fluxmi_k_euler(void* img, const void* pred, const float* dts, const int* step, long long n, hipStream_t s);
 int fluxmi_k_set_timestep(void* t_vec, const float* ts, const int* step, int B, hipStream_t s);
 int fluxmi_k_advance_step(int* step, hipStream_t s);
+int fluxmi_k_clock_sample(unsigned long long* out2, hipStream_t s);
 int fluxmi_k_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int up, hipStream_t s);
 int fluxmi_k_groupnorm(const void* x, const void* gamma, const void* beta, void* y, float* work, int B, int P, int C, int swish, float eps,
                        hipStream_t s);

@@ -306,19 +306,21 @@ int launch_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
 }  // namespace
 
 // tile configs (the numbers are part of the C ABI, fluxmi_gemm_grouped): 2 = 128x128 and 15 = 128x64 double-buffered kernels of this
-// file, 13 = 256x256 ping-pong ring (gemm_ring.hip), 16 = 256x256 one wave per SIMD (gemm_w1.hip), 100 = generic.  The other numbers
+// file, 13 = 256x256 ping-pong ring (gemm_pp.hip), 16 = 256x256 one wave per SIMD (gemm_w1.hip), 18 = persistent ping-pong
+// (gemm_persist.hip; 19 = its timing build), 100 = generic.  The other numbers
 // belonged to kernel generations that were measured slower and removed in round 3 (profiles/r01_kernel_sweep.txt, r02_gemm_ab.txt).
-int fluxmi_launch_gemm_ring(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s);
+int fluxmi_launch_gemm_pp(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s);
 int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
 
-int fluxmi_gemm_tile_bn(int cfg) { return cfg == 2 ? 128 : cfg == 15 ? 64 : (cfg == 13 || cfg == 16) ? 256 : 0; }
-int fluxmi_gemm_tile_bm(int cfg) { return (cfg == 2 || cfg == 15) ? 128 : (cfg == 13 || cfg == 16) ? 256 : 0; }
+int fluxmi_gemm_tile_bn(int cfg) { return cfg == 2 ? 128 : cfg == 15 ? 64 : (cfg == 13 || cfg == 16 || cfg == 18 || cfg == 19) ? 256 : 0; }
+int fluxmi_gemm_tile_bm(int cfg) { return (cfg == 2 || cfg == 15) ? 128 : (cfg == 13 || cfg == 16 || cfg == 18 || cfg == 19) ? 256 : 0; }
 
 int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg) {
   const int bn = fluxmi_gemm_tile_bn(cfg);
   if (!bn) return 0;
   const int kb = K * (is_fp8 ? 1 : 2);
-  const int kstep = cfg == 16 ? 256 : cfg == 13 ? 64 : 128;
+  const int kstep = (cfg == 16 || cfg == 18 || cfg == 19) ? 256 : cfg == 13 ? 64 : 128;
+  if ((cfg == 18 || cfg == 19) && kb < 512) return 0;
   return (N % bn == 0) && (kb % kstep == 0) && kb >= kstep;
 }
 
@@ -329,9 +331,10 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
     FLUXMI_REQUIRE(p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0, "gemm: split_n=%d must be a multiple of the N tile", p.g[0].split_n);
   for (int i = 0; i < p.n_groups; ++i)
     if (p.g[i].vt_out || p.g[i].k_out)
-      FLUXMI_REQUIRE(cfg == 13 || cfg == 16, "gemm: fused K / V^T outputs exist only in tile configs 13 and 16 (got %d)", cfg);
+      FLUXMI_REQUIRE(cfg == 13 || cfg == 16 || cfg == 18 || cfg == 19, "gemm: fused K / V^T outputs exist only in the 256x256 tile configs (got %d)", cfg);
+  if (cfg == 18 || cfg == 19) return fluxmi_launch_gemm_persist(p, is_fp8, act_fmt, cfg == 19, s);
   if (cfg == 16) return fluxmi_launch_gemm_w1(p, is_fp8, act_fmt, s);
-  if (cfg == 13) return fluxmi_launch_gemm_ring(p, is_fp8, act_fmt, cfg, s);
+  if (cfg == 13) return fluxmi_launch_gemm_pp(p, is_fp8, act_fmt, cfg, s);
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) return launch_cfg<true, FLUXMI_FMT_E5M2>(p, cfg, s);
     return launch_cfg<true, FLUXMI_FMT_E4M3>(p, cfg, s);

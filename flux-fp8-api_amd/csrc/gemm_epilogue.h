@@ -1,4 +1,4 @@
-// fluxmi -- GEMM epilogue helpers shared by the tile kernels (gemm.hip, gemm_ring.hip).
+// fluxmi -- GEMM epilogue helpers shared by the tile kernels (gemm.hip, gemm_pp.hip).
 #pragma once
 #include "common.h"
 #include "fluxmi_internal.h"

@@ -1,0 +1,599 @@
+// fluxmi -- PERSISTENT ping-pong GEMM (tile config 18): the 256x256 / 8-wave body of gemm_pp.hip, one workgroup per CU walking a static
+// list of tiles, for the multi-round F8Linear launches of the step (single-block linear1: 5.9 rounds of the 256 CUs, double-block
+// mlp.0: 3.0, qkv: 2.25).
+//
+// What the one-tile-per-workgroup kernel pays PER TILE and this one does not (profiles/r03_gemm_noepilogue.txt, r03_streamk.txt):
+//  * workgroup launch, descriptor set-up and the cold prologue (three K-steps of LDS-DMA from L2 with the matrix pipes idle);
+//  * the drain: the epilogue's stores have to reach L2 before the CU takes the next workgroup.
+// Here the LDS ring never drains: the refill slots of a tile's last three K-steps take the FIRST three K-steps of the workgroup's next
+// tile, so when the epilogue ends the next tile's operands are already in LDS, and the epilogue's stores retire under the next K loop.
+// That needs the ring to stay untouched by the epilogue: the bf16 transposition goes through a 4 KiB per-wave scratch beside the ring
+// (160 KiB of LDS = 4 x 32 KiB ring + 8 x 4 KiB), one 32-row block of the wave's 128 x 64 tile at a time.  The table-driven
+// GELU -> fp8 epilogue (64 KiB table, gemm_epilogue.h) borrows ring slots 2 and 3 -- a table tile therefore prefetches only two K-steps
+// of its successor and issues the third right after its table reads.
+//
+// K loop = gemm_pp.hip's (4-slot ring of 64-byte K-steps filled three steps ahead by `buffer_load ... lds`, ONE raw s_barrier per step,
+// counted vmcnt, the two waves of a SIMD in opposite phase), unrolled by four so that ring slots are immediates (K bytes % 256 == 0).
+// vmcnt protocol across tiles: every path of the epilogue converts its accumulators (VALU only), then waits vmcnt(0) ONCE -- as the
+// builtin, so that hipcc's own wait-count pass knows it: with LDS-DMA pending in its model it puts vmcnt(0) in front of every scratch
+// access it cannot prove disjoint, i.e. drains the epilogue's stores block by block -- and only then touches LDS and stores.  The
+// successor's K-steps were issued before that point, so steps 0 and 1 of the next K loop open without a wait and the stores retire under
+// it; from step 2 on the counted vmcnt(4) is exact again (VMEM operations of a wave retire in order on gfx9).
+// Tile order = the XCD-aware order of the one-tile-per-workgroup kernels: workgroup b sits on XCD b % 8 and walks that XCD's contiguous
+// range of logical tile ids 32 at a time (GROUP_M = 8 rasterisation: 8 x 4 tiles share A / W panels through the XCD's L2).
+#include <type_traits>
+
+#include "gemm_epilogue.h"
+
+namespace {
+
+// wave-uniform description of one 256 x 256 output tile: descriptors + tile offsets of its A / W panels, group index, tile origin.
+// Plain scalars on purpose: as a struct (copied cur <- nxt once per tile) hipcc kept the ints in scratch memory, and every scratch access
+// is a VMEM operation that waits vmcnt(1) -- i.e. for the epilogue's stores and the LDS-DMA in flight.
+__device__ __forceinline__ void ps_setup(const FluxmiGemmParams& P, int lid, int eb, __amdgpu_buffer_rsrc_t& ars, __amdgpu_buffer_rsrc_t& wrs,
+                                         unsigned& a_soff0, unsigned& w_soff0, int& gi_out, int& m0, int& n0) {
+  const int tiles_n = P.N >> 8;
+  const int width = P.group_m * tiles_n;
+  const int first_m = (lid / width) * P.group_m;
+  const int gsz = min(P.tiles_m_total - first_m, P.group_m);
+  const int tm = first_m + (lid % width) % gsz;
+  const int tn = (lid % width) / gsz;
+  int gi = 0;
+  for (int i = 1; i < P.n_groups; ++i) gi = (tm >= P.g[i].m_tile_start) ? i : gi;
+  const FluxmiGemmGroup& G = P.g[gi];
+  gi_out = gi;
+  m0 = (tm - G.m_tile_start) * 256;
+  n0 = tn * 256;
+  const long long a_row_b = (long long)G.lda * eb, w_row_b = (long long)P.K * eb;
+  ars = make_rsrc(G.A, (unsigned)min((long long)G.M * a_row_b, 0xffffffffLL));
+  wrs = make_rsrc(G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
+  a_soff0 = uni_u32((unsigned)(m0 * a_row_b));
+  w_soff0 = uni_u32((unsigned)(n0 * w_row_b));
+}
+
+// s_waitcnt vmcnt(0) as the BUILTIN (expcnt / lgkmcnt fields = no wait): unlike an asm statement, hipcc's own wait-count pass sees it and
+// knows that nothing older is pending -- with the asm form it kept every epilogue load "in flight" in its model and drained vmcnt (i.e.
+// the epilogue's stores) at the first register reuse of the next tile
+__device__ __forceinline__ void ps_wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+__device__ __forceinline__ unsigned long long ps_clock() { return __builtin_amdgcn_s_memtime(); }
+__device__ __forceinline__ unsigned long long ps_realtime() { return __builtin_amdgcn_s_memrealtime(); }
+
+// ---- epilogue of one wave's 128 x 64 block through its 4 KiB scratch ------------------------------------------------------------
+// EPI: BF16 (plain rows or the fused V^T layout), GATE_RESID, SPLIT (columns < split_n as BF16, the rest through the table),
+// GELU_QUANT (table).  `lut` selects the table path (tile-uniform).  Ends with its stores in flight.  `after_table` is called once
+// (table path only) when every wave of the workgroup is done reading the table.
+// the lane's bias words (4 consecutive columns per 8-column group) of its wave's 64 columns; issued by the kernel four K-steps before the
+// end of the K loop, i.e. AHEAD of the last LDS-DMA refills: loads retire in order, so the epilogue's first use of a bias word then
+// waits for nothing but the bias itself (issued behind the refills it would wait out their full L2 latency with the matrix pipes idle)
+__device__ __forceinline__ void ps_load_bias(const FluxmiGemmGroup& G, int n_wave0, int hi, uint2 (&braw)[2][4]) {
+  const fluxmi_gptr<const u16> bias_p = uni_ptr((const u16*)G.bias);
+  const fluxmi_gptr<const u16> bias_src = bias_p != nullptr ? bias_p : uni_ptr((const u16*)G.W);  // never a branch around the loads (gemm_epilogue.h)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      braw[j][g4] = __builtin_bit_cast(uint2, *(fluxmi_gptr<const fluxmi_v2i>)(bias_src + n_wave0 + j * 32 + g4 * 8 + hi * 4));
+}
+
+template <int EPI, int FMT, class AfterTable>
+__device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc)[4][2], uint2 (&braw)[2][4], float s, unsigned char* wbuf,
+                                            unsigned char* table, int m_wave0, int n_wave0, int M, int lane, int wave, bool lut,
+                                            AfterTable after_table) {
+  constexpr int TM = 4, TN = 2;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const bool has_bias = uni_ptr((const u16*)G.bias) != nullptr;
+  auto pin_bias = [&]() {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        asm volatile("" : "+v"(braw[j][g4].x), "+v"(braw[j][g4].y));
+        if (!has_bias) braw[j][g4] = make_uint2(0, 0);
+      }
+  };
+  auto bias_of = [&](int j, int g4, float* b) {
+    const uint2 v = braw[j][g4];
+    b[0] = __uint_as_float(v.x << 16); b[1] = __uint_as_float(v.x & 0xffff0000u);
+    b[2] = __uint_as_float(v.y << 16); b[3] = __uint_as_float(v.y & 0xffff0000u);
+  };
+
+  // phase 0, common to every path and VALU only: h = bf16(acc * s + bias), two per register, block-major (an accumulator block is dead
+  // once its 16 words are packed).  It runs BEFORE the one vmcnt(0) of the epilogue, i.e. under the L2 latency of the successor's last
+  // K-step (issued in the last K-step of this tile) and of the first residual rows.
+  unsigned hp[TM][TN][4][2];
+  auto convert_all = [&]() {
+    pin_bias();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float bias[4];
+          bias_of(j, g4, bias);
+          hp[i][j][g4][0] = pack_bf2(fmaf(acc[i][j][g4 * 4 + 0], s, bias[0]), fmaf(acc[i][j][g4 * 4 + 1], s, bias[1]));
+          hp[i][j][g4][1] = pack_bf2(fmaf(acc[i][j][g4 * 4 + 2], s, bias[2]), fmaf(acc[i][j][g4 * 4 + 3], s, bias[3]));
+        }
+  };
+
+  if constexpr (EPI == FLUXMI_EPI_GELU_QUANT || EPI == FLUXMI_EPI_SPLIT) {
+    if (lut) {
+      // ---- table path (see gemm_epilogue.h, lds_epilogue): fp8 = table[bf16(acc * s + bias)] ------------------------------------
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave has read the last K-steps out of ring slots 2 and 3
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int piece = wave * 8 + q;
+        glds16((const unsigned char*)G.q_lut + piece * 1024 + lane * 16, table + piece * 1024);
+      }
+      convert_all();
+      ps_wait_all_vmem();  // the table (and the next tile's two K-steps) landed
+      __builtin_amdgcn_s_barrier();
+      unsigned qw[TM][TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const unsigned a = hp[i][j][g4][0], b = hp[i][j][g4][1];
+            const unsigned q0 = table[a & 0xffffu], q1 = table[a >> 16], q2 = table[b & 0xffffu], q3 = table[b >> 16];
+            qw[i][j][g4] = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+          }
+      // 32 rows x 64 B of fp8 per block through the wave's scratch: lane owns 4 consecutive columns of row l31 -> one dword, 16-B chunks
+      // XOR-swizzled by row; read back as (row, 16-B chunk) per lane.  ALL of it happens before the successor's third K-step is issued:
+      // hipcc orders every LDS read behind a pending LDS-DMA it cannot prove disjoint (vmcnt(0) in front of each read, and with it a full
+      // drain of the stores issued so far)
+      uint4 raw[TM][2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int nl = j * 32 + g4 * 8 + hi * 4;
+            const int chunk = (nl >> 4) ^ ((l31 >> 1) & 3);
+            *(unsigned*)(wbuf + l31 * 64 + chunk * 16 + (nl & 12)) = qw[i][j][g4];
+          }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int ml = it * 16 + (lane >> 2), c = lane & 3;
+          raw[i][it] = *(const uint4*)(wbuf + ml * 64 + ((c ^ ((ml >> 1) & 3)) * 16));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) asm volatile("" : "+v"(raw[i][it].x), "+v"(raw[i][it].y), "+v"(raw[i][it].z), "+v"(raw[i][it].w));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done with the table: its slots go back to the ring
+      after_table();
+      const fluxmi_gptr<unsigned char> c8 = EPI == FLUXMI_EPI_SPLIT ? uni_ptr((unsigned char*)G.C2) : uni_ptr((unsigned char*)G.C);
+      const long long ld8 = EPI == FLUXMI_EPI_SPLIT ? uni_i64(G.ldc2) : uni_i64(G.ldc);
+      const int col0 = EPI == FLUXMI_EPI_SPLIT ? (int)uni_u32((unsigned)(G.c2_col0 - G.split_n)) : 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int ml = it * 16 + (lane >> 2), c = lane & 3;
+          const int m = m_wave0 + i * 32 + ml;
+          if (m < M) *(fluxmi_gptr<v4i>)(c8 + (long long)m * ld8 + col0 + n_wave0 + c * 16) = __builtin_bit_cast(v4i, raw[i][it]);
+        }
+      return;
+    }
+  }
+
+  const fluxmi_gptr<u16> c_p = uni_ptr((u16*)G.C);
+  const long long ldc_u = uni_i64(G.ldc);
+  if constexpr (EPI == FLUXMI_EPI_BF16 || EPI == FLUXMI_EPI_SPLIT) {
+    // ---- fused V^T (wave-uniform): [32 keys][64 d] of one head's V per block -> LDS as [64 d][32 keys] (keys in the PV MFMA's k-slot
+    // order: bits 2 and 3 swapped inside a 16-key group), leaves as 64-byte runs of one d-row of vt_out
+    const int vcol0 = G.kv_col0 + G.heads * 128;
+    if (G.vt_out && n_wave0 >= vcol0 && n_wave0 < vcol0 + G.heads * 128) {
+      const fluxmi_gptr<u16> vt_p = uni_ptr((u16*)G.vt_out);
+      const long long vt_ld = uni_i64(G.vt_ld);
+      const int d0 = n_wave0 - vcol0, tok0 = (int)uni_u32((unsigned)G.tok0), vt_rows = (int)uni_u32((unsigned)G.vt_rows);
+      const int posl = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+      convert_all();
+      ps_wait_all_vmem();  // the ONE vmcnt(0) of this path: from here on hipcc's wait-count model holds no LDS-DMA a scratch access could alias
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const bool live = m_wave0 + i * 32 + l31 < M;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int dl = j * 32 + g4 * 8 + hi * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned w = hp[i][j][g4][e >> 1];
+              const u16 v = live ? (u16)((e & 1) ? (w >> 16) : (w & 0xffffu)) : (u16)0;
+              *(u16*)(wbuf + (dl + e) * 64 + posl * 2) = v;
+            }
+          }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int dl = it * 16 + (lane >> 2), c = lane & 3;
+          const uint4 raw = *(const uint4*)(wbuf + dl * 64 + c * 16);
+          const int key = m_wave0 + i * 32 + c * 8;  // group-relative position of the 8 keys
+          if (key < vt_rows) *(fluxmi_gptr<v4i>)(vt_p + (long long)(d0 + dl) * vt_ld + tok0 + key) = __builtin_bit_cast(v4i, raw);
+        }
+      }
+      return;
+    }
+  }
+
+  // ---- bf16 rows: plain store, or x + bf16(gate * h) with the residual rows one 32-row block ahead ------------------------------
+  const fluxmi_gptr<const u16> resid_p = uni_ptr((const u16*)G.resid);
+  const fluxmi_gptr<const u16> gate_p = uni_ptr((const u16*)G.gate);
+  const long long ldr_u = uni_i64(G.ldr);
+  constexpr bool GR = EPI == FLUXMI_EPI_GATE_RESID;
+  const int c = lane & 7, rl = lane >> 3;  // phase 2: lane -> (row rl + 8 * it of the block, 16-B chunk c)
+  uint4 rres[2][GR ? 4 : 1];
+  uint4 graw = make_uint4(0, 0, 0, 0);
+  auto load_resid = [&](int i, uint4 (&dst)[GR ? 4 : 1]) {
+    if constexpr (GR) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = min(m_wave0 + i * 32 + it * 8 + rl, M - 1);  // clamped, not guarded: the load is unconditional, the store is not
+        dst[it] = __builtin_bit_cast(uint4, *(fluxmi_gptr<const v4i>)(resid_p + (long long)m * ldr_u + n_wave0 + c * 8));
+      }
+    }
+  };
+  if constexpr (GR) {
+    graw = __builtin_bit_cast(uint4, *(fluxmi_gptr<const v4i>)(gate_p + n_wave0 + c * 8));
+    load_resid(0, rres[0]);
+  }
+  convert_all();
+  ps_wait_all_vmem();  // the ONE vmcnt(0) of this path (see the V^T path); the first residual rows and the gate have landed as well
+  float g[8];
+  if constexpr (GR) unpack8(graw, g);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int nl = j * 32 + g4 * 8 + hi * 4;
+        uint2 v;
+        v.x = hp[i][j][g4][0];
+        v.y = hp[i][j][g4][1];
+        const int chunk = (nl >> 3) ^ (l31 & 7);
+        *(uint2*)(wbuf + l31 * 128 + chunk * 16 + (nl & 4) * 2) = v;
+      }
+    if constexpr (GR) {
+      if (i + 1 < TM) load_resid(i + 1, rres[(i + 1) & 1]);
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        asm volatile("" : "+v"(rres[i & 1][it].x), "+v"(rres[i & 1][it].y), "+v"(rres[i & 1][it].z), "+v"(rres[i & 1][it].w));
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int ml = it * 8 + rl;
+      const int m = m_wave0 + i * 32 + ml;
+      const uint4 raw = *(const uint4*)(wbuf + ml * 128 + ((c ^ (ml & 7)) * 16));
+      if constexpr (GR) {
+        float h[8], r[8], o[8];
+        unpack8(raw, h);
+        unpack8(rres[i & 1][it], r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = r[e] + rbf(g[e] * h[e]);
+        if (m < M) *(fluxmi_gptr<v4i>)(c_p + (long long)m * ldc_u + n_wave0 + c * 8) = __builtin_bit_cast(v4i, pack8(o));
+      } else {
+        if (m < M) *(fluxmi_gptr<v4i>)(c_p + (long long)m * ldc_u + n_wave0 + c * 8) = __builtin_bit_cast(v4i, raw);
+      }
+    }
+  }
+}
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+template <bool FP8, int ACT_FMT, int ESEL, bool TIMING>
+__global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams P) {
+  constexpr int NT = 512, TM = 4, TN = 2, STAGE = 32768, A_BYTES = 16384, LPT = 4, RING = 4 * STAGE;
+  constexpr int EB = FP8 ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- static tile list of this workgroup ---------------------------------------------------------------------------------------
+  const int nblk = P.tiles_m_total * (P.N >> 8);
+  const int xcd = blockIdx.x & 7, wg_in_x = blockIdx.x >> 3;
+  const int xq = nblk >> 3, xr = nblk & 7;
+  const int base = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+  const int cnt = xq + (xcd < xr ? 1 : 0);
+  const int stride = ((int)gridDim.x - xcd + 7) >> 3;  // workgroups of this launch on this XCD
+  if (wg_in_x >= cnt) return;
+  const int nk = (P.K * EB) / 64;
+  const unsigned a_row_b = (unsigned)(P.g[0].lda * EB), w_row_b = (unsigned)(P.K * EB);  // one lda for every group (host check)
+
+  // per-lane LDS-DMA source offsets of the lane's two A and two W pieces of a K-step (XOR swizzle on the source side)
+  auto lane_voffs = [&](int tid, unsigned (&a_voff)[2], unsigned (&w_voff)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
+      a_voff[i] = (unsigned)row * a_row_b + slot * 16;
+      w_voff[i] = (unsigned)row * w_row_b + slot * 16;
+    }
+  };
+  auto fence = []() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  __amdgpu_buffer_rsrc_t c_ars, c_wrs, n_ars, n_wrs;
+  unsigned c_asoff, c_wsoff, n_asoff, n_wsoff;
+  int c_gi, c_m0, c_n0, n_gi, n_m0, n_n0;
+  ps_setup(P, base + wg_in_x, EB, c_ars, c_wrs, c_asoff, c_wsoff, c_gi, c_m0, c_n0);
+  {
+    unsigned a_voff[2], w_voff[2];
+    lane_voffs(threadIdx.x, a_voff, w_voff);
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      unsigned char* dA = smem + st * STAGE + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dma16_buf(c_ars, dA + NT * 16 * i, a_voff[i], c_asoff + st * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dma16_buf(c_wrs, dA + A_BYTES + NT * 16 * i, w_voff[i], c_wsoff + st * 64);
+    }
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  for (int jt = 0;; ++jt) {
+    unsigned long long t_start = 0, t_kend = 0;
+    if constexpr (TIMING) t_start = ps_clock();
+    const int next_idx = wg_in_x + (jt + 1) * stride;
+    const bool has_next = next_idx < cnt;
+    // the last tile "prefetches" its own first K-steps again: valid, L2-hot addresses, and the vmcnt bookkeeping stays uniform
+    if (has_next) {
+      ps_setup(P, base + next_idx, EB, n_ars, n_wrs, n_asoff, n_wsoff, n_gi, n_m0, n_n0);
+    } else {
+      n_ars = c_ars; n_wrs = c_wrs; n_asoff = c_asoff; n_wsoff = c_wsoff; n_gi = c_gi; n_m0 = c_m0; n_n0 = c_n0;
+    }
+    const FluxmiGemmGroup& G = P.g[c_gi];
+    bool lut_tile = false;
+    if constexpr (ESEL == FLUXMI_EPI_GELU_QUANT) lut_tile = true;
+    if constexpr (ESEL == FLUXMI_EPI_SPLIT) lut_tile = c_n0 >= (int)uni_u32((unsigned)G.split_n);
+
+    // everything derived from the lane index is recomputed per tile from an opaque copy: values that stay live across the epilogue (the
+    // point of highest register pressure) are what hipcc spills, and a reload inside the K loop is a VMEM operation that drains vmcnt
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    unsigned a_voff[2], w_voff[2];
+    lane_voffs(tid, a_voff, w_voff);
+    int a_lo, a_hi, w_lo, w_hi;
+    {
+      const int ra = wm * 128 + l31, ka = (ra >> 2) & 3;
+      a_lo = ra * 64 + (((hi * 2) ^ ka) << 4);
+      a_hi = ra * 64 + (((hi * 2 + 1) ^ ka) << 4);
+      const int rw = wn * 64 + l31, kw = (rw >> 2) & 3;
+      w_lo = A_BYTES + rw * 64 + (((hi * 2) ^ kw) << 4);
+      w_hi = A_BYTES + rw * 64 + (((hi * 2 + 1) ^ kw) << 4);
+    }
+    auto dma_stage = [&](__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t wrs, unsigned asoff, unsigned wsoff, int kt, auto SLOT) {
+      constexpr int S = decltype(SLOT)::value;
+      unsigned char* dA = smem + S * STAGE + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dma16_buf(ars, dA + NT * 16 * i, a_voff[i], asoff + kt * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dma16_buf(wrs, dA + A_BYTES + NT * 16 * i, w_voff[i], wsoff + kt * 64);
+    };
+    v8i fa[TM], fw[TN];
+    auto read_frags = [&](auto SLOT) {
+      constexpr int S = decltype(SLOT)::value;
+      const unsigned char* sb = smem + S * STAGE;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const v4i lo = *(const v4i*)(sb + j * 2048 + w_lo), h4 = *(const v4i*)(sb + j * 2048 + w_hi);
+        fw[j] = (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const v4i lo = *(const v4i*)(sb + i * 2048 + a_lo), h4 = *(const v4i*)(sb + i * 2048 + a_hi);
+        fa[i] = (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
+      }
+    };
+    v16f acc[TM][TN];
+    auto mma_all = [&](auto ZERO) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          v16f c0;
+          if constexpr (decltype(ZERO)::value) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+          } else {
+            c0 = acc[i][j];
+          }
+          if constexpr (FP8) {
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[j], fa[i], c0, FLUXMI_FMT_E4M3, ACT_FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          } else {
+            const v4i alo = (v4i){fa[i][0], fa[i][1], fa[i][2], fa[i][3]}, ahi = (v4i){fa[i][4], fa[i][5], fa[i][6], fa[i][7]};
+            const v4i wlo = (v4i){fw[j][0], fw[j][1], fw[j][2], fw[j][3]}, whi = (v4i){fw[j][4], fw[j][5], fw[j][6], fw[j][7]};
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, wlo), __builtin_bit_cast(v8bf, alo), c0, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, whi), __builtin_bit_cast(v8bf, ahi), c0, 0, 0, 0);
+          }
+        }
+    };
+    // one K-step in ring slot S; the refill (slot S + 3) takes K-step `kt_src` of the current (NXT = 0) or the next (NXT = 1) tile,
+    // DMA = 0: no refill.  WAIT: 1 = counted wait, 0 = none.
+    // Group 0: barrier | 8 MFMA | refill | fragments of the next step;  group 1: barrier | fragments | refill | 8 MFMA.
+    auto refill = [&](auto SLOT, auto NXT, int kt_src) {
+      if constexpr (decltype(NXT)::value) dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, kt_src, SLOT);
+      else dma_stage(c_ars, c_wrs, c_asoff, c_wsoff, kt_src, SLOT);
+    };
+    auto step_g0 = [&](auto SLOT, auto WAIT, auto ZERO, auto READ_NEXT, auto DMA, auto NXT, int kt_src) {
+      constexpr int S = decltype(SLOT)::value, W = decltype(WAIT)::value;
+      if constexpr (W == 1) wait_vmcnt<LPT>();
+      __builtin_amdgcn_s_barrier();
+      fence();
+      mma_all(ZERO);
+      fence();
+      if constexpr (decltype(DMA)::value) refill(ic<(S + 3) & 3>{}, NXT, kt_src);
+      fence();
+      if constexpr (decltype(READ_NEXT)::value) read_frags(ic<(S + 1) & 3>{});
+      fence();
+    };
+    auto step_g1 = [&](auto SLOT, auto WAIT, auto ZERO, auto DMA, auto NXT, int kt_src) {
+      constexpr int S = decltype(SLOT)::value, W = decltype(WAIT)::value;
+      if constexpr (W == 1) wait_vmcnt<LPT>();
+      __builtin_amdgcn_s_barrier();
+      fence();
+      read_frags(SLOT);
+      fence();
+      if constexpr (decltype(DMA)::value) refill(ic<(S + 3) & 3>{}, NXT, kt_src);
+      fence();
+      mma_all(ZERO);
+      fence();
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    // the successor's third K-step goes into slot 2 (last read before barrier nk - 1): inside the last step where the epilogue never takes
+    // the table, behind the K loop for the non-table tiles of the split epilogue, after the table reads otherwise
+    using LASTDMA = std::integral_constant<bool, ESEL == FLUXMI_EPI_BF16 || ESEL == FLUXMI_EPI_GATE_RESID>;
+    // steps 0 and 1 of a tile: their operands landed before the epilogue's vmcnt(0) (the first tile: before the prologue's), and all
+    // that is in flight are the epilogue's stores -- no wait, they retire under the K loop.  A table tile issues its successor's third
+    // K-step AFTER that vmcnt(0): there step 1 keeps the counted wait.
+    using W1 = ic<(ESEL == FLUXMI_EPI_BF16 || ESEL == FLUXMI_EPI_GATE_RESID) ? 0 : 1>;
+    uint2 braw[2][4];
+    if (wm == 0) {
+      read_frags(ic<0>{});
+      step_g0(ic<0>{}, ic<0>{}, T{}, T{}, T{}, F{}, 3);
+      step_g0(ic<1>{}, W1{}, F{}, T{}, T{}, F{}, 4);
+      step_g0(ic<2>{}, ic<1>{}, F{}, T{}, T{}, F{}, 5);
+      step_g0(ic<3>{}, ic<1>{}, F{}, T{}, T{}, F{}, 6);
+      for (int kt = 4; kt < nk - 4; kt += 4) {
+        step_g0(ic<0>{}, ic<1>{}, F{}, T{}, T{}, F{}, kt + 3);
+        step_g0(ic<1>{}, ic<1>{}, F{}, T{}, T{}, F{}, kt + 4);
+        step_g0(ic<2>{}, ic<1>{}, F{}, T{}, T{}, F{}, kt + 5);
+        step_g0(ic<3>{}, ic<1>{}, F{}, T{}, T{}, F{}, kt + 6);
+      }
+      ps_load_bias(G, c_n0 + wn * 64, hi, braw);
+      step_g0(ic<0>{}, ic<1>{}, F{}, T{}, T{}, F{}, nk - 1);
+      step_g0(ic<1>{}, ic<1>{}, F{}, T{}, T{}, T{}, 0);
+      step_g0(ic<2>{}, ic<1>{}, F{}, T{}, T{}, T{}, 1);
+      step_g0(ic<3>{}, ic<1>{}, F{}, F{}, LASTDMA{}, T{}, 2);
+    } else {
+      step_g1(ic<0>{}, ic<0>{}, T{}, T{}, F{}, 3);
+      step_g1(ic<1>{}, W1{}, F{}, T{}, F{}, 4);
+      step_g1(ic<2>{}, ic<1>{}, F{}, T{}, F{}, 5);
+      step_g1(ic<3>{}, ic<1>{}, F{}, T{}, F{}, 6);
+      for (int kt = 4; kt < nk - 4; kt += 4) {
+        step_g1(ic<0>{}, ic<1>{}, F{}, T{}, F{}, kt + 3);
+        step_g1(ic<1>{}, ic<1>{}, F{}, T{}, F{}, kt + 4);
+        step_g1(ic<2>{}, ic<1>{}, F{}, T{}, F{}, kt + 5);
+        step_g1(ic<3>{}, ic<1>{}, F{}, T{}, F{}, kt + 6);
+      }
+      ps_load_bias(G, c_n0 + wn * 64, hi, braw);
+      step_g1(ic<0>{}, ic<1>{}, F{}, T{}, F{}, nk - 1);
+      step_g1(ic<1>{}, ic<1>{}, F{}, T{}, T{}, 0);
+      step_g1(ic<2>{}, ic<1>{}, F{}, T{}, T{}, 1);
+      step_g1(ic<3>{}, ic<1>{}, F{}, LASTDMA{}, T{}, 2);
+    }
+    if constexpr (ESEL == FLUXMI_EPI_SPLIT) {
+      if (!lut_tile) dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, ic<2>{});
+    }
+    if constexpr (TIMING) t_kend = ps_clock();
+
+    // ---- epilogue (the ring is not touched, except by the table path) ----------------------------------------------------------
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const float s = load_scale_u(G.sa_recip) * load_scale_u(G.sb_recip);
+    const int M = (int)uni_u32((unsigned)G.M);
+    unsigned char* wbuf = smem + RING + wave * 4096;
+    ps_epilogue<ESEL, ACT_FMT>(G, acc, braw, s, wbuf, smem + 2 * STAGE, c_m0 + wm * 128, c_n0 + wn * 64, M, lane_e, wave, lut_tile,
+                               [&]() { dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, ic<2>{}); });
+    if constexpr (TIMING) {
+      if (threadIdx.x == 0 && P.dbg) {
+        unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 8 + (jt < 8 ? jt : 7)) * 4;
+        d[0] = t_start; d[1] = t_kend; d[2] = ps_clock(); d[3] = ps_realtime();
+      }
+    }
+    if (!has_next) break;
+    c_ars = n_ars; c_wrs = n_wrs; c_asoff = n_asoff; c_wsoff = n_wsoff; c_gi = n_gi; c_m0 = n_m0; c_n0 = n_n0;
+  }
+  wait_vmcnt<0>();  // the trailing refills must land before the wave ends
+}
+
+template <bool FP8, int ACT, int ESEL, bool TIMING>
+int launch_ps(FluxmiGemmParams& p, hipStream_t s) {
+  constexpr int BM = 256, BN = 256;
+  int t = 0;
+  for (int i = 0; i < p.n_groups; ++i) {
+    p.g[i].m_tile_start = t;
+    t += (p.g[i].M + BM - 1) / BM;
+  }
+  p.tiles_m_total = t;
+  p.group_m = 8;
+  constexpr int SMEM = 4 * (BM + BN) * 64 + 8 * 4096;  // ring + per-wave epilogue scratch = all 160 KiB
+  auto kern = gemm_ps_kernel<FP8, ACT, ESEL, TIMING>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  const int nblk = t * (p.N / BN);
+  if (nblk == 0) return 0;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    FLUXMI_CHECK_HIP(hipGetDevice(&dev));
+    FLUXMI_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cu <= 0) n_cu = 256;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblk < n_cu ? nblk : n_cu), dim3(512), SMEM, s, p);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+unsigned long long* g_ps_dbg = nullptr;
+
+}  // namespace
+
+// timing probe (tools/ps_timeline.py): device buffer of [workgroup][tile < 8][t_start, t_k_end, t_end (shader clock), realtime (100 MHz)]
+extern "C" int fluxmi_gemm_debug_buffer(void* dev_u64) {
+  g_ps_dbg = (unsigned long long*)dev_u64;
+  return 0;
+}
+
+// What the persistent kernel is built for: fp8 x e5m2 operands, the step's four hot epilogues, K bytes % 256 == 0 and >= 512, one lda for
+// every group, no fused-K output; the quantising epilogues only through the table.
+int fluxmi_gemm_persist_ok(const FluxmiGemmParams& p, int is_fp8, int act_fmt) {
+  if (!is_fp8 || act_fmt != FLUXMI_FMT_E5M2) return 0;
+  if (p.N % 256 != 0 || p.K % 256 != 0 || p.K < 512) return 0;
+  if (p.epi != FLUXMI_EPI_BF16 && p.epi != FLUXMI_EPI_GATE_RESID && p.epi != FLUXMI_EPI_SPLIT && p.epi != FLUXMI_EPI_GELU_QUANT) return 0;
+  for (int i = 0; i < p.n_groups; ++i) {
+    const FluxmiGemmGroup& g = p.g[i];
+    if (g.lda != p.g[0].lda || g.k_out) return 0;
+    if ((long long)g.M * g.lda >= (1LL << 32) || (long long)p.N * p.K >= (1LL << 32)) return 0;
+    if ((p.epi == FLUXMI_EPI_SPLIT || p.epi == FLUXMI_EPI_GELU_QUANT) && !g.q_lut) return 0;
+    if (p.epi == FLUXMI_EPI_SPLIT && (g.split_n % 256 != 0 || g.split_n != p.g[0].split_n)) return 0;
+  }
+  return 1;
+}
+
+// config 18 = persistent 256x256 ping-pong; 19 = the same with per-tile timestamps into fluxmi_gemm_debug_buffer
+int fluxmi_launch_gemm_persist(FluxmiGemmParams& p, int is_fp8, int act_fmt, int timing, hipStream_t s) {
+  FLUXMI_REQUIRE(fluxmi_gemm_persist_ok(p, is_fp8, act_fmt),
+                 "gemm_persist: needs fp8 x e5m2 operands, N %% 256 == 0, K %% 256 == 0, K >= 512, a bf16 / gate_resid / split / gelu_quant "
+                 "epilogue (the quantising ones with a table), one lda, no fused-K output (N=%d K=%d epi=%d)", p.N, p.K, p.epi);
+  p.dbg = timing ? g_ps_dbg : nullptr;
+  if (timing) {
+    switch (p.epi) {
+      case FLUXMI_EPI_BF16: return launch_ps<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_BF16, true>(p, s);
+      case FLUXMI_EPI_GATE_RESID: return launch_ps<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, true>(p, s);
+      case FLUXMI_EPI_SPLIT: return launch_ps<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_SPLIT, true>(p, s);
+      default: return launch_ps<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GELU_QUANT, true>(p, s);
+    }
+  }
+  switch (p.epi) {
+    case FLUXMI_EPI_BF16: return launch_ps<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_BF16, false>(p, s);
+    case FLUXMI_EPI_GATE_RESID: return launch_ps<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, false>(p, s);
+    case FLUXMI_EPI_SPLIT: return launch_ps<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_SPLIT, false>(p, s);
+    default: return launch_ps<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GELU_QUANT, false>(p, s);
+  }
+}

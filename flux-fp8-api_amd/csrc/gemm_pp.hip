@@ -11,6 +11,10 @@
 // LDS rows are 64 B (4 x 16 B slots); bank-conflict-free ds_read_b128 needs slot ^= (row >> 2) & 3, applied on the DMA source address
 // and on the read address.  (Rounds 1-2 also carried a lock-step ring kernel in five tile shapes, a two-workgroups-per-CU variant and
 // timing-only ablations of it: measured slower everywhere -- profiles/r01_gemm_ablation*.txt, r02_gemm_ab.txt -- and removed in round 3.)
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "gemm_epilogue.h"
 
 namespace {
@@ -316,8 +320,30 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const FluxmiGemmPara
   }
 }
 
-float* g_splitk_ws[16] = {nullptr};
+// Split-K scratch: one 256 MiB fp32 buffer per (device, stream) that ever launches a split-K GEMM -- the partial tiles live from the
+// GEMM pass to the reduce pass of the SAME stream, so two streams must never share one -- created under a mutex on the first use, and
+// never under stream capture (a hipMalloc there would invalidate the capture: the launch is refused instead; run the shape once
+// eagerly first, as fluxmi_engine_denoise does with its warm step).
 constexpr size_t SPLITK_WS_BYTES = (size_t)256 << 20;
+std::mutex g_splitk_mu;
+std::map<std::pair<int, hipStream_t>, float*> g_splitk_ws;
+int splitk_workspace(hipStream_t s, float** out) {
+  int dev = 0;
+  FLUXMI_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_splitk_mu);
+  auto it = g_splitk_ws.find({dev, s});
+  if (it == g_splitk_ws.end()) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s) FLUXMI_CHECK_HIP(hipStreamIsCapturing(s, &cap));
+    FLUXMI_REQUIRE(cap == hipStreamCaptureStatusNone, "gemm split-K: first use on this stream happens under stream capture (no scratch yet): "
+                   "run the launch once eagerly before capturing");
+    float* p = nullptr;
+    FLUXMI_CHECK_HIP(hipMalloc((void**)&p, SPLITK_WS_BYTES));
+    it = g_splitk_ws.emplace(std::make_pair(dev, s), p).first;
+  }
+  *out = it->second;
+  return 0;
+}
 
 template <bool FP8, int ACT>
 int launch_pp_splitk(FluxmiGemmParams& p, int split_k, hipStream_t s) {
@@ -335,12 +361,11 @@ int launch_pp_splitk(FluxmiGemmParams& p, int split_k, hipStream_t s) {
   const size_t need = (size_t)split_k * t * BM * p.N * sizeof(float);
   FLUXMI_REQUIRE(split_k >= 2 && need <= SPLITK_WS_BYTES, "gemm split-K: %d splits of %d x %d need %zu bytes of scratch (have %zu)", split_k, t * BM, p.N,
                  need, SPLITK_WS_BYTES);
-  int dev = 0;
-  FLUXMI_CHECK_HIP(hipGetDevice(&dev));
-  FLUXMI_REQUIRE(dev >= 0 && dev < 16, "gemm split-K: device ordinal %d out of range", dev);
-  if (!g_splitk_ws[dev]) FLUXMI_CHECK_HIP(hipMalloc((void**)&g_splitk_ws[dev], SPLITK_WS_BYTES));  // once per device, on the first (eager) use
+  FLUXMI_REQUIRE(split_k <= (p.K * (FP8 ? 1 : 2)) / 64, "gemm split-K: %d splits for %d K-steps", split_k, (p.K * (FP8 ? 1 : 2)) / 64);
+  float* ws = nullptr;
+  FLUXMI_TRY(splitk_workspace(s, &ws));
   p.split_k = split_k;
-  p.partial = g_splitk_ws[dev];
+  p.partial = ws;
   constexpr int SMEM = 4 * (BM + BN) * 64 + 8 * 128 * 4;
   auto kern = gemm_pp_kernel<FP8, ACT, 2, -1, true>;
   static bool attr_set = false;
@@ -360,8 +385,7 @@ template <bool FP8, int ACT>
 int launch_pp_cfg(FluxmiGemmParams& p, hipStream_t s) {
   // the hot epilogues get a kernel compiled for them alone (fp8 x e5m2: the calibrated step; bf16: VAE / text encoders / bf16 flow)
   if constexpr (ACT == FLUXMI_FMT_E5M2) {
-    static int esel = -1;  // FLUXMI_GEMM_ESEL=0: the run-time-switch kernel for every epilogue (A/B)
-    if (esel < 0) { const char* e = getenv("FLUXMI_GEMM_ESEL"); esel = e ? atoi(e) : 1; }
+    const int esel = fluxmi_tuning().gemm_esel;  // 0: the run-time-switch kernel for every epilogue (A/B)
     if (esel) switch (p.epi) {
       case FLUXMI_EPI_BF16: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_BF16>(p, s);
       case FLUXMI_EPI_GATE_RESID: return launch_pp<FP8, ACT, 2, FLUXMI_EPI_GATE_RESID>(p, s);
@@ -386,8 +410,8 @@ int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int 
 }
 
 // config 13 = 256x256 ping-pong ring (8 waves)
-int fluxmi_launch_gemm_ring(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s) {
-  FLUXMI_REQUIRE(cfg == 13, "gemm_ring: unknown tile config %d", cfg);
+int fluxmi_launch_gemm_pp(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s) {
+  FLUXMI_REQUIRE(cfg == 13, "gemm_pp: unknown tile config %d", cfg);
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) return launch_pp_cfg<true, FLUXMI_FMT_E5M2>(p, s);
     return launch_pp_cfg<true, FLUXMI_FMT_E4M3>(p, s);

@@ -1,6 +1,6 @@
 // fluxmi -- "w1" GEMM: 256x256 tile, FOUR waves, one per SIMD, each owning a 128x128 accumulator block (gfx950).
 //
-// Same math, operands, grouping and epilogues as gemm.hip / gemm_ring.hip.  Why another shape: on real (non-zero) data the fp8
+// Same math, operands, grouping and epilogues as gemm.hip / gemm_pp.hip.  Why another shape: on real (non-zero) data the fp8
 // matrix pipe of MI355X is power-limited (tools/probes/mfma_rate.hip: 3.7 PF/s of MFMA-only work on random operands, 5.0 on
 // zeros), so what a GEMM reaches is set by how much energy it spends NOT doing MFMAs.  A 128x128 wave tile reads 8 fragments
 // per 16 MFMAs from LDS instead of 6 per 8 (-33 % LDS read traffic for the same flops), needs no partner wave (one wave per SIMD
@@ -217,8 +217,7 @@ int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStrea
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) {
       // the step's K >= 8192 launches (mlp.2, linear2) all end in gate*y + x
-      static int esel = -1;  // FLUXMI_GEMM_ESEL=0: the run-time-switch kernel for every epilogue (A/B)
-      if (esel < 0) { const char* e = getenv("FLUXMI_GEMM_ESEL"); esel = e ? atoi(e) : 1; }
+      const int esel = fluxmi_tuning().gemm_esel;  // 0: the run-time-switch kernel for every epilogue (A/B)
       if (esel && p.epi == FLUXMI_EPI_GATE_RESID) return launch_w1<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID>(p, s);
       return launch_w1<true, FLUXMI_FMT_E5M2>(p, s);
     }

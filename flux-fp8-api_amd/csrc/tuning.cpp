@@ -1,0 +1,115 @@
+// fluxmi -- kernel-selection knobs, resolved ONCE (include/fluxmi.h, fluxmi_tuning_t).
+//
+// Every FLUXMI_* environment variable that chooses a kernel or a fusion level is read here, at the first call that needs a knob, into one
+// process-wide struct; nothing else in the library calls getenv.  fluxmi_set_tuning replaces the struct at run time (A/B probes, the op
+// tests) and bumps a generation counter: an engine remembers the generation its step graph was captured under and re-captures when it
+// changed, so a replayed graph never runs with choices other than the ones in force.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <mutex>
+
+#include "fluxmi_internal.h"
+
+namespace {
+
+std::mutex g_mu;
+fluxmi_tuning_t g_tuning;
+std::atomic<unsigned> g_generation{0};
+std::once_flag g_once;
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+
+int validate(const fluxmi_tuning_t& t) {
+  FLUXMI_REQUIRE(t.struct_size == (int)sizeof(fluxmi_tuning_t), "tuning: struct_size %d != %d (ABI mismatch)", t.struct_size, (int)sizeof(fluxmi_tuning_t));
+  FLUXMI_REQUIRE(t.gemm_cfg >= -1 && t.gemm_cfg <= 200, "tuning: gemm_cfg %d out of range", t.gemm_cfg);
+  // P is bounded by 2^defer_log2, O and l carry the same factor: beyond 2^16 the fp32 sums of 4608 keys lose their headroom, and a
+  // negative or non-finite threshold makes the rescale test meaningless (inf / NaN images with no error otherwise)
+  FLUXMI_REQUIRE(isfinite(t.attn_defer_log2) && t.attn_defer_log2 >= 0.f && t.attn_defer_log2 <= 16.f,
+                 "tuning: attn_defer_log2 %g outside [0, 16]", (double)t.attn_defer_log2);
+  FLUXMI_REQUIRE(t.fuse_kv >= 0 && t.fuse_kv <= 2, "tuning: fuse_kv %d (0..2)", t.fuse_kv);
+  FLUXMI_REQUIRE(t.ln_variant == 1 || t.ln_variant == 2, "tuning: ln_variant %d (1 = wave per row, 2 = streaming)", t.ln_variant);
+  return 0;
+}
+
+void log_tuning(const fluxmi_tuning_t& t, const char* why) {
+  fprintf(stderr,
+          "fluxmi tuning (%s): gemm_cfg=%d splitk=%d hybrid=%d esel=%d persist=%d | attn var=%d abl=%d defer_log2=%g f16k=%d | "
+          "fuse_kv=%d qlut=%d ln=%d roctx=%d\n",
+          why, t.gemm_cfg, t.gemm_splitk, t.gemm_hybrid, t.gemm_esel, t.gemm_persist, t.attn_var, t.attn_abl,
+          (double)t.attn_defer_log2, t.attn_f16k, t.fuse_kv, t.qlut, t.ln_variant, t.roctx);
+}
+
+void init_from_env() {
+  fluxmi_tuning_t t;
+  memset(&t, 0, sizeof(t));
+  t.struct_size = (int)sizeof(t);
+  t.gemm_cfg = env_int("FLUXMI_GEMM_CFG", -1);
+  t.gemm_splitk = env_int("FLUXMI_GEMM_SPLITK", 1);
+  t.gemm_hybrid = env_int("FLUXMI_GEMM_HYBRID", 1);
+  t.gemm_esel = env_int("FLUXMI_GEMM_ESEL", 1);
+  t.gemm_persist = env_int("FLUXMI_GEMM_PERSIST", 1);
+  t.attn_var = env_int("FLUXMI_ATTN_VAR", 0);
+  t.attn_abl = env_int("FLUXMI_ATTN_ABL", 0);
+  {
+    const char* e = getenv("FLUXMI_ATTN_THR");
+    t.attn_defer_log2 = (e && *e) ? (float)atof(e) : 8.0f;
+  }
+  t.attn_f16k = env_int("FLUXMI_ATTN_F16K", 1);
+  t.fuse_kv = env_int("FLUXMI_FUSE_KV", 1);
+  t.qlut = env_int("FLUXMI_QLUT", 1);
+  t.ln_variant = env_int("FLUXMI_LN_V", 2);
+  t.roctx = env_int("FLUXMI_ROCTX", 0);
+  t.log = env_int("FLUXMI_LOG", 0);
+  if (validate(t) != 0) {  // a bad environment must not silently change the arithmetic: say so and keep the compiled defaults for that knob
+    fprintf(stderr, "fluxmi: ignoring invalid FLUXMI_* environment (%s)\n", fluxmi_last_error());
+    if (!(isfinite(t.attn_defer_log2) && t.attn_defer_log2 >= 0.f && t.attn_defer_log2 <= 16.f)) t.attn_defer_log2 = 8.0f;
+    if (t.fuse_kv < 0 || t.fuse_kv > 2) t.fuse_kv = 1;
+    if (t.ln_variant != 1 && t.ln_variant != 2) t.ln_variant = 2;
+    if (t.gemm_cfg < -1 || t.gemm_cfg > 200) t.gemm_cfg = -1;
+  }
+  g_tuning = t;
+  if (t.log) log_tuning(t, "environment");
+}
+
+}  // namespace
+
+fluxmi_tuning_t fluxmi_tuning() {
+  std::call_once(g_once, init_from_env);
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_tuning;
+}
+unsigned fluxmi_tuning_generation() { return g_generation.load(); }
+void fluxmi_log_tuning(const char* why) {
+  const fluxmi_tuning_t t = fluxmi_tuning();
+  if (t.log) log_tuning(t, why);
+}
+
+extern "C" {
+
+int fluxmi_get_tuning(fluxmi_tuning_t* out) {
+  FLUXMI_REQUIRE(out, "get_tuning: NULL argument");
+  *out = fluxmi_tuning();
+  return 0;
+}
+
+int fluxmi_set_tuning(const fluxmi_tuning_t* in) {
+  FLUXMI_REQUIRE(in, "set_tuning: NULL argument");
+  FLUXMI_TRY(validate(*in));
+  std::call_once(g_once, init_from_env);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_tuning = *in;
+  }
+  g_generation.fetch_add(1);
+  if (in->log) log_tuning(*in, "set_tuning");
+  return 0;
+}
+
+}  // extern "C"

@@ -37,6 +37,15 @@ class GemmGroup(C.Structure):
     ]
 
 
+class Tuning(C.Structure):
+    """fluxmi_tuning_t (include/fluxmi.h): the kernel-selection knobs, resolved once from the FLUXMI_* environment by the library."""
+    _fields_ = [
+        ("struct_size", i32), ("gemm_cfg", i32), ("gemm_splitk", i32), ("gemm_hybrid", i32), ("gemm_esel", i32), ("gemm_persist", i32),
+        ("attn_var", i32), ("attn_abl", i32), ("attn_defer_log2", f32), ("attn_f16k", i32), ("fuse_kv", i32), ("qlut", i32),
+        ("ln_variant", i32), ("roctx", i32), ("log", i32),
+    ]
+
+
 class Linear(C.Structure):
     _fields_ = [
         ("weight", vp), ("bias", vp), ("w_scale_recip", vp), ("in_scale", vp), ("in_scale_recip", vp),
@@ -54,6 +63,10 @@ class ModelDesc(C.Structure):
 
 _SIGS = {
     "fluxmi_abi_version": ([], i32),
+    "fluxmi_get_tuning": ([C.POINTER(Tuning)], i32),
+    "fluxmi_set_tuning": ([C.POINTER(Tuning)], i32),
+    "fluxmi_gemm_debug_buffer": ([vp], i32),
+    "fluxmi_clock_sample": ([vp, vp], i32),
     "fluxmi_gemm_grouped": ([C.POINTER(GemmGroup), i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_f8_gemm": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "fluxmi_gemv": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
@@ -105,8 +118,9 @@ for _name, (_args, _res) in _SIGS.items():
     _fn.argtypes = _args
     _fn.restype = _res
 
-if lib.fluxmi_abi_version() != 2:
-    raise ImportError(f"fluxmi: ABI version mismatch ({lib.fluxmi_abi_version()} != 2)")
+ABI_VERSION = 3
+if lib.fluxmi_abi_version() != ABI_VERSION:
+    raise ImportError(f"fluxmi: ABI version mismatch ({lib.fluxmi_abi_version()} != {ABI_VERSION})")
 
 
 def check(rc: int) -> None:
@@ -116,3 +130,36 @@ def check(rc: int) -> None:
 
 def call(name: str, *args) -> None:
     check(getattr(lib, name)(*args))
+
+
+def get_tuning() -> Tuning:
+    t = Tuning()
+    check(lib.fluxmi_get_tuning(C.byref(t)))
+    return t
+
+
+def set_tuning(**knobs) -> Tuning:
+    """Replace fields of the library's tuning struct (validated by the library); returns the struct that was in force before."""
+    old = get_tuning()
+    new = get_tuning()
+    for k, v in knobs.items():
+        if k not in {f[0] for f in Tuning._fields_} or k == "struct_size":
+            raise KeyError(f"fluxmi tuning has no knob {k!r}")
+        setattr(new, k, v)
+    check(lib.fluxmi_set_tuning(C.byref(new)))
+    return old
+
+
+class tuning:
+    """`with _lib.tuning(attn_var=2): ...` -- run a block under other kernel-selection knobs, then restore the previous struct."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        self.old = set_tuning(**self.knobs)
+        return self
+
+    def __exit__(self, *exc):
+        check(lib.fluxmi_set_tuning(C.byref(self.old)))
+        return False

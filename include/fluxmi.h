@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FLUXMI_ABI_VERSION 2
+#define FLUXMI_ABI_VERSION 3
 
 /* fp8 format codes (torch.float8_e4m3fn / torch.float8_e5m2, float8_quantize.py:39,43) */
 #define FLUXMI_E4M3 0
@@ -87,6 +87,39 @@ typedef struct fluxmi_gemm_group {
 
 const char* fluxmi_last_error(void);
 int fluxmi_abi_version(void);
+
+/* ---- kernel-selection knobs (ABI 3) --------------------------------------------------------------------------------------------
+ * The reference has no counterpart (its only switches are the ModelSpec flags of util.py:40-77); these choose between kernels /
+ * fusion levels that compute the same results.  They are resolved ONCE: the first call that needs a knob parses the FLUXMI_*
+ * environment variables named below into this struct (csrc/tuning.cpp -- the only getenv site of the library);
+ * fluxmi_set_tuning replaces it at run time (A/B probes, tests).  An engine re-captures its step graph when the struct changed
+ * since the capture, and fluxmi_engine_create logs it once under FLUXMI_LOG=1. */
+typedef struct fluxmi_tuning {
+  int struct_size;       /* sizeof(fluxmi_tuning_t): filled by fluxmi_get_tuning, checked by fluxmi_set_tuning */
+  int gemm_cfg;          /* FLUXMI_GEMM_CFG     -1 = cost model (default), else force this tile config where it applies */
+  int gemm_splitk;       /* FLUXMI_GEMM_SPLITK   1: small-M bf16 launches split K over several workgroups per tile */
+  int gemm_hybrid;       /* FLUXMI_GEMM_HYBRID   1: peel the thin groups of a grouped launch into a 128x128 launch */
+  int gemm_esel;         /* FLUXMI_GEMM_ESEL     1: one kernel instantiation per hot epilogue (0 = run-time switch, A/B) */
+  int gemm_persist;      /* FLUXMI_GEMM_PERSIST  1: multi-round fp8 launches on the persistent kernel (tile config 18) */
+  int attn_var;          /* FLUXMI_ATTN_VAR      bit 1: exact instead of deferred running max */
+  int attn_abl;          /* FLUXMI_ATTN_ABL      ablation bits of the 8-wave kernel (probes) */
+  float attn_defer_log2; /* FLUXMI_ATTN_THR      rescale threshold of the deferred running max, log2; [0, 16], default 8 */
+  int attn_f16k;         /* FLUXMI_ATTN_F16K     1: the engine stores K as fp16 and runs the folded attention arithmetic */
+  int fuse_kv;           /* FLUXMI_FUSE_KV       0 / 1 (default) / 2: K, V^T by the relayout kernel / V^T from the qkv GEMM / both */
+  int qlut;              /* FLUXMI_QLUT          1: table-driven GELU -> fp8 epilogues */
+  int ln_variant;        /* FLUXMI_LN_V          2 = streaming LayerNorm kernel (default), 1 = one wave per row */
+  int roctx;             /* FLUXMI_ROCTX         1: roctx ranges around the phases of a denoise call */
+  int log;               /* FLUXMI_LOG           1: print the struct to stderr when it is resolved / set / an engine is created */
+} fluxmi_tuning_t;
+int fluxmi_get_tuning(fluxmi_tuning_t* out);
+int fluxmi_set_tuning(const fluxmi_tuning_t* in); /* validates every field (non-zero + fluxmi_last_error on a bad value) */
+
+/* Probes (tools/): a device buffer of [workgroup][tile < 8][4] uint64 that the timing build of the persistent GEMM (tile config 19)
+ * fills with {tile start, K loop end, epilogue end} shader-clock stamps + the 100 MHz real-time counter; NULL switches it off.
+ * fluxmi_clock_sample writes {XCC id, s_memtime, s_memrealtime} of one wave per XCD to out[0..23] (24 uint64) on `stream`: two samples
+ * around a timed region, paired by XCC id, give the average shader clock the chip sustained over it (bench.py). */
+int fluxmi_gemm_debug_buffer(void* dev_u64);
+int fluxmi_clock_sample(void* out24_dev_u64, void* stream);
 
 /* ---- F8Linear / Linear ------------------------------------------------------------------------- */
 /* Grouped linear.  is_fp8=1: A is `act_fmt` fp8, W is e4m3fn (torch._scaled_mm, float8_quantize.py:284-292);

@@ -109,7 +109,17 @@ def main():
             step_s = 19 * td_ + 38 * ts_
             sample = (f"{what}: 1 DoubleStreamBlock ({td_:.3f} s) + 1 SingleStreamBlock ({ts_:.3f} s) at L={Li + Lt}, {reps} reps each, "
                       f"extrapolated to 19+38 blocks = {step_s:.1f} s/step")
-    print(json.dumps({"value": 1.0 / step_s, "unit": "it/s", "cores": cores, "kind": kind, "sample": sample}))
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    # `cores` = the threads the timed run used (the contract's field); host_cores = logical CPUs of the box, host_cores_available = the ones
+    # this process may run on (affinity mask / container quota), thread_scan = seconds of one SingleStreamBlock call per candidate count
+    print(json.dumps({"value": 1.0 / step_s, "unit": "it/s", "cores": cores, "threads_used": cores, "host_cores": os.cpu_count(),
+                      "host_cores_available": avail, "cpu_model": model, "thread_scan_s": {str(k): round(v, 3) for k, v in sorted(timing.items())},
+                      "kind": kind, "sample": sample}))
 
 
 if __name__ == "__main__":

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), f"libfluxmi.so does not export {s}"
     assert set(_lib.EXPORTS) == set(syms), f"ctypes table out of sync with the header: {set(_lib.EXPORTS) ^ set(syms)}"
-    assert _lib.lib.fluxmi_abi_version() == 2
+    assert _lib.lib.fluxmi_abi_version() == 3
 
 
 def test_errors_are_returned_not_thrown():
@@ -52,6 +52,40 @@ def test_errors_are_returned_not_thrown():
     assert lib.fluxmi_engine_create(C.byref(d), lin, n, nrm, 6, C.byref(h)) == 1 and b"head_dim" in lib.fluxmi_last_error()
     with pytest.raises(RuntimeError, match="fluxmi"):
         _lib.call("fluxmi_quantize_act", None, None, None, 1, 7, 7, 7, 1, None)
+
+
+def test_tuning_struct_round_trip_and_validation(monkeypatch):
+    """fluxmi_tuning_t (ABI 3): every kernel-selection knob lives in ONE struct that the library resolves once from the FLUXMI_*
+    environment (csrc/tuning.cpp is the only getenv site) and that fluxmi_set_tuning replaces after validating every field."""
+    from fluxmi import _lib
+
+    src = ""
+    for f in glob.glob(os.path.join(ROOT, "flux-fp8-api_amd", "csrc", "*")):
+        if f.endswith((".hip", ".cpp", ".h")) and not f.endswith("tuning.cpp"):
+            src += open(f).read()
+    assert "getenv" not in src, "kernel-selection knobs are read in csrc/tuning.cpp only"
+    # the header's field list == the ctypes struct's
+    hdr = open(os.path.join(ROOT, "include", "fluxmi.h")).read()
+    body = hdr[hdr.index("typedef struct fluxmi_tuning {"):hdr.index("} fluxmi_tuning_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:int|float)\s+([a-z0-9_]+)\s*;", body)
+    assert fields == [f[0] for f in _lib.Tuning._fields_]
+    t = _lib.get_tuning()
+    assert t.struct_size == C.sizeof(_lib.Tuning) and t.gemm_cfg == -1 and t.gemm_persist == 1 and t.ln_variant == 2
+    assert abs(t.attn_defer_log2 - 8.0) < 1e-6 and t.attn_f16k == 1 and t.fuse_kv == 1 and t.qlut == 1
+    with _lib.tuning(gemm_cfg=13, attn_defer_log2=6.5):
+        u = _lib.get_tuning()
+        assert u.gemm_cfg == 13 and abs(u.attn_defer_log2 - 6.5) < 1e-6
+    assert _lib.get_tuning().gemm_cfg == -1
+    for bad in (dict(attn_defer_log2=float("nan")), dict(attn_defer_log2=-1.0), dict(attn_defer_log2=100.0), dict(fuse_kv=7), dict(ln_variant=0)):
+        with pytest.raises(RuntimeError, match="tuning"):
+            _lib.set_tuning(**bad)
+    assert _lib.get_tuning().fuse_kv == 1  # a refused struct changes nothing
+    bad = _lib.get_tuning()
+    bad.struct_size = 4
+    assert _lib.lib.fluxmi_set_tuning(C.byref(bad)) == 1 and b"struct_size" in _lib.lib.fluxmi_last_error()
+    with pytest.raises(KeyError):
+        _lib.set_tuning(no_such_knob=1)
 
 
 def test_struct_layouts_match_the_header():

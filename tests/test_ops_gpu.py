@@ -188,7 +188,7 @@ def test_f8_gemm_production_shapes_auto_dispatch(ops, dev, which):
 @pytest.mark.parametrize("case", ["bf16 linear2 M=512", "bf16 mlp2 txt+img", "bf16 mlp2 ragged M", "fp8 forced S=5"])
 def test_gemm_split_k(ops, dev, case):
     """Small-M launches: `S` workgroups per 256x256 tile, each over its own K range, fp32 partial tiles + a reduce pass that applies the
-    epilogue (gemm_ring.hip).  The shapes the auto dispatch splits (bf16, <= 128 tiles: Flux-schnell 256x256 = BASELINE configs[0], the
+    epilogue (gemm_pp.hip).  The shapes the auto dispatch splits (bf16, <= 128 tiles: Flux-schnell 256x256 = BASELINE configs[0], the
     text encoders) with both epilogues, grouped txt + img launches, a ragged M, and a forced split of an fp8 problem (the per-tensor scales
     are then applied by the reduce pass): every row within 1 bf16 ulp of fp64; 5 launches bit-identical; the auto dispatch == the forced
     split it is expected to choose."""
@@ -272,6 +272,76 @@ def test_bf16_gemm(ops, dev, cfg):
     ref = round_fp64_to_bf16(a.double() @ w.double().T + bias.double())
     out = ops.linear(a.to(dev), w.to(dev), bias.to(dev), tile_cfg=cfg)
     assert_close_mag(out, ref, mag=accum_noise(a, w, 1.0), ulps=1, min_exact=0.99, what=f"bf16 gemm cfg={cfg}")
+
+
+@pytest.mark.parametrize("case", ["bf16", "bf16 ragged + V^T", "gate_resid txt+img", "gelu table", "split + V^T", "split 2 groups ragged"])
+def test_gemm_persistent_matches_ping_pong(ops, dev, case):
+    """Tile config 18 (gemm_persist.hip: one workgroup per CU walks a static tile list, the LDS ring never drains, epilogue through a
+    4 KiB per-wave scratch) runs the K loop of config 13 in the same order with the same rounding points, so every output byte must be
+    IDENTICAL to config 13's -- plain bf16 rows, the fused V^T layout, gate*y+x in place, the table-driven GELU -> fp8 epilogue, the
+    qkv|mlp split of SingleStreamBlock.linear1 -- for ragged M (rows past M read as zero through the buffer descriptor, stores
+    masked), several groups with their own weights, and tile counts from fewer than the 256 CUs (one tile per workgroup) to five tiles
+    per workgroup (table and non-table tiles alternating inside one workgroup's list).          float8_quantize.py:284-292,
+    flux_model.py:301,387-396,471-484"""
+    from fluxmi import _lib
+
+    torch.manual_seed(23)
+    Hh = 512                       # "hidden": q | k | v blocks of 512 columns = 4 heads of 128
+    K = 768
+    one, qs = torch.tensor(1.0, device=dev), torch.tensor(41.0, device=dev)
+    lut = ops.build_quant_lut(qs, E5M2, act=1)
+    spec = {
+        "bf16": (_lib.EPI_BF16, [1300], 2048, False),
+        "bf16 ragged + V^T": (_lib.EPI_BF16, [777, 130], 3 * Hh, True),
+        "gate_resid txt+img": (_lib.EPI_GATE_RESID, [512, 4096], 3072, False),
+        "gelu table": (_lib.EPI_GELU_QUANT, [2100], 8192, False),               # 288 tiles: two per workgroup for some
+        "split + V^T": (_lib.EPI_SPLIT, [4608], 3 * Hh + 16896, True),            # 1296 tiles: five per workgroup, table and plain tiles mixed
+        "split 2 groups ragged": (_lib.EPI_SPLIT, [1000, 333], 3 * Hh + 2048, False),
+    }
+    epi, Ms, N, vt = spec[case]
+    results = {}
+    for cfg in (13, 18):
+        torch.manual_seed(23)
+        groups, keep, outs = [], [], []
+        for gi, M in enumerate(Ms):
+            a = (torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2)
+            w = (torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn)
+            bias = torch.randn(N, device=dev).bfloat16() if gi == 0 else None   # the second group has no bias
+            sar = torch.tensor(0.37 + gi, device=dev)
+            kw = {}
+            if epi == _lib.EPI_BF16:
+                o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            elif epi == _lib.EPI_GELU_QUANT:
+                o = torch.zeros(M, N, dtype=torch.uint8, device=dev).view(torch.float8_e5m2)
+                kw = dict(q_scale=qs.data_ptr(), q_lut=lut.data_ptr())
+            elif epi == _lib.EPI_GATE_RESID:
+                o = torch.randn(M, N, device=dev).bfloat16()
+                gate = torch.randn(N, device=dev).bfloat16()
+                keep.append(gate)
+                kw = dict(gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N)
+            else:
+                o = torch.full((M, 3 * Hh), float("nan"), dtype=torch.bfloat16, device=dev)
+                o2 = torch.zeros(M, Hh + (N - 3 * Hh), dtype=torch.uint8, device=dev).view(torch.float8_e5m2)
+                outs.append(o2)
+                kw = dict(C2=o2.data_ptr(), ldc2=o2.stride(0), split_n=3 * Hh, c2_col0=Hh, q_scale=qs.data_ptr(), q_lut=lut.data_ptr())
+            if vt:
+                Lp = (M + 63) // 64 * 64
+                vt_t = torch.full((Hh, Lp), float("nan"), dtype=torch.bfloat16, device=dev)
+                outs.append(vt_t)
+                kw.update(vt_out=vt_t.data_ptr(), vt_ld=Lp, tok0=0, vt_rows=Lp, kv_col0=Hh, heads=Hh // 128)
+            keep += [a, w, bias, sar]
+            outs.append(o)
+            groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, sar.data_ptr(), one.data_ptr(),
+                                         o.data_ptr(), M, K, o.stride(0), **kw))
+        ops.gemm_grouped(groups, N, K, True, E5M2, epi, cfg)
+        if cfg == 18:  # a second launch on the same buffers (gate*y+x: on a fresh residual) must reproduce itself
+            torch.cuda.synchronize()
+        results[cfg] = [o.clone().view(torch.uint8) for o in outs]
+    for i, (x13, x18) in enumerate(zip(results[13], results[18])):
+        same = (x13 == x18).float().mean().item()
+        assert same == 1.0, f"{case}: output {i} of the persistent kernel differs from config 13 on {1 - same:.2e} of the bytes"
+    if vt:  # the V columns live in vt_out only: both kernels leave those columns of C untouched (NaN fill), everything else is finite
+        assert torch.isfinite(results[18][-1].view(torch.bfloat16).float()[:, :Hh]).all()
 
 
 @pytest.mark.parametrize("cfg", [2, 13, 16, 100])
@@ -363,13 +433,19 @@ def test_gemv(ops, dev, B):
 @pytest.mark.parametrize("variant", ["stream", "row_per_wave"])
 @pytest.mark.parametrize("L,Lt", [(40, 12), (42, 13), (1300, 500)])
 @pytest.mark.parametrize("H", [256, 3072])
-def test_ln_modulate(ops, dev, H, L, Lt, variant, monkeypatch):
+def test_ln_modulate(ops, dev, H, L, Lt, variant):
     """K4(+K2): (1+scale)*LayerNorm(x)+shift with the reference's bf16 rounding points (flux_model.py:367-368).
     (42, 13): a workgroup's rows straddle the txt|img split and the batch boundary (the rows that do not belong to the
     workgroup's LDS-staged table take their modulation vectors from global memory); (1300, 500): 256 workgroups with 10-11 rows each,
     i.e. the streaming kernel's prefetch loop runs (every wave owns two rows, some a single one).
-    Both kernels: the streaming one (default, FLUXMI_LN_V=2) and the one-wave-per-row one (FLUXMI_LN_V=1)."""
-    monkeypatch.setenv("FLUXMI_LN_V", "2" if variant == "stream" else "1")
+    Both kernels: the streaming one (default, fluxmi_tuning_t.ln_variant = 2) and the one-wave-per-row one (1)."""
+    from fluxmi import _lib
+
+    with _lib.tuning(ln_variant=2 if variant == "stream" else 1):
+        _ln_modulate_body(ops, dev, H, L, Lt)
+
+
+def _ln_modulate_body(ops, dev, H, L, Lt):
     torch.manual_seed(9)
     B = 2
     x = (torch.randn(B, L, H) * 2 + 0.3).bfloat16()
@@ -470,7 +546,7 @@ def test_qkv_rope(ops, dev, L, Lt):
 
 
 @pytest.mark.parametrize("B,H,L,Lt", [(1, 2, 320, 64), (2, 1, 200, 40), (1, 2, 33, 8), (1, 1, 97, 32), (1, 1, 4608, 512)])
-def test_attention(ops, dev, B, H, L, Lt, monkeypatch):
+def test_attention(ops, dev, B, H, L, Lt):
     """K7: softmax(QK^T/sqrt(128))V vs fp64 (flux_model.py:41-45); bf16 and fused-fp8 outputs."""
     torch.manual_seed(8)
     q = torch.randn(B, H, L, 128).bfloat16()
@@ -500,24 +576,16 @@ def test_attention(ops, dev, B, H, L, Lt, monkeypatch):
     refq = torch.cat((fo.to_fp8_saturated(out[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float() / s0,
                       fo.to_fp8_saturated(out[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float() / s1), 1)
     assert torch.equal(deq, refq), f"fp8 attention output differs from quantise(bf16 output): {(deq != refq).float().mean().item()}"
-    # fp16 K (the engine's operand format) through both kernels: the 8-wave folded one and the 4-wave one (FLUXMI_ATTN_V=4)
+    # fp16 K (the engine's operand format): the folded kernel
     k16 = torch.where(k.abs() < 6.2e-5, torch.zeros_like(k), k)  # below fp16's normal range a bf16 value is not exact in fp16
     ref16 = fo.attention_fp64(q, k16, v).transpose(1, 2).reshape(B, L, H * 128)
-    outs16 = {}
-    for ver in (None, "3", "4"):  # 8-wave folded (default), the same with the barrier between its MFMA groups, 4-wave
-        monkeypatch.delenv("FLUXMI_ATTN_V", raising=False)
-        if ver:
-            monkeypatch.setenv("FLUXMI_ATTN_V", ver)
-        out4 = ops.attention(d(q), d(k16.half()), d(VT)).cpu()
-        err4 = (out4.double() - ref16).abs().max().item()
-        assert torch.isfinite(out4).all() and err4 <= 2e-2 * v.abs().max().item(), f"attention (fp16 K, FLUXMI_ATTN_V={ver}): max abs err {err4}"
-        got4 = ops.attention(d(q), d(k16.half()), d(VT), q_scale0=d(s0), q_scale1=d(s1), split=Lt).cpu()
-        refq4 = torch.cat((fo.to_fp8_saturated(out4[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float(),
-                           fo.to_fp8_saturated(out4[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float()), 1)
-        assert torch.equal(got4.float(), refq4), f"fp8 output (fp16 K, FLUXMI_ATTN_V={ver}) differs from quantise(its bf16 output)"
-        outs16[ver] = out4
-    monkeypatch.delenv("FLUXMI_ATTN_V", raising=False)
-    assert torch.equal(outs16[None], outs16["3"]), "the mid-barrier variant runs the same arithmetic as the default 8-wave kernel: bit-identical"
+    out4 = ops.attention(d(q), d(k16.half()), d(VT)).cpu()
+    err4 = (out4.double() - ref16).abs().max().item()
+    assert torch.isfinite(out4).all() and err4 <= 2e-2 * v.abs().max().item(), f"attention (fp16 K): max abs err {err4}"
+    got4 = ops.attention(d(q), d(k16.half()), d(VT), q_scale0=d(s0), q_scale1=d(s1), split=Lt).cpu()
+    refq4 = torch.cat((fo.to_fp8_saturated(out4[:, :Lt], s0, 57344.0).to(torch.float8_e5m2).float(),
+                       fo.to_fp8_saturated(out4[:, Lt:], s1, 57344.0).to(torch.float8_e5m2).float()), 1)
+    assert torch.equal(got4.float(), refq4), "fp8 output (fp16 K) differs from quantise(its bf16 output)"
 
 
 def _vt_layout(v, L):
@@ -533,14 +601,15 @@ def _vt_layout(v, L):
 
 
 @pytest.mark.parametrize("L", [448, 1100, 4608])
-def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
-    """Both kernels rescale O / l / the pending P tile only when a row max grew by more than 2^8 (guide T13).  The branch is rare on
+def test_attention_deferred_rescale_branch(ops, dev, L):
+    """The kernel rescales O / l / the pending P tile only when a row max grew by more than 2^8 (guide T13).  The branch is rare on
     random data, so it is FORCED: key rows are spiked against chosen query rows so that the row max jumps by far more than the threshold
     at chosen tiles (first tile, an odd tile, an even tile, the last tile; both 32-key halves of a tile), some rows several times; every
-    row of the full tensor is checked against fp64, and the builds -- the 8-wave kernel (attention2.hip) with bf16 K (unfolded) and fp16
-    K (folded: softmax scale in Q, running max in the accumulator init; the engine's default), the 4-wave kernel (attention4.hip, fp16 K,
-    FLUXMI_ATTN_V=4), each with deferred and with exact running max (FLUXMI_ATTN_VAR=2) -- must agree to rounding.  The fused fp8
-    output through the regrouped 16-byte stores must equal the 4-byte stores bit for bit."""
+    row of the full tensor is checked against fp64, and the builds -- bf16 K (unfolded) and fp16 K (folded: softmax scale in Q, running
+    max in the accumulator init; the engine's default), each with deferred and with exact running max (fluxmi_tuning_t.attn_var = 2) --
+    must agree to rounding.  The fused fp8 output through the regrouped 16-byte stores must equal the 4-byte stores bit for bit."""
+    from fluxmi import _lib
+
     torch.manual_seed(81)
     B, H = 1, 2
     q = torch.randn(B, H, L, 128).bfloat16()
@@ -558,28 +627,19 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     VT = _vt_layout(v, L)
     d = lambda t: t.to(dev)
     outs = {}
-    knobs = ("FLUXMI_ATTN_VAR", "FLUXMI_ATTN_V", "FLUXMI_ATTN_ABL")
-    variants = (("deferred", {}, False), ("exact", {"FLUXMI_ATTN_VAR": "2"}, False), ("fold", {}, True),
-                ("fold_exact", {"FLUXMI_ATTN_VAR": "2"}, True), ("w4", {"FLUXMI_ATTN_V": "4"}, True),
-                ("w4_exact", {"FLUXMI_ATTN_V": "4", "FLUXMI_ATTN_VAR": "2"}, True), ("mb", {"FLUXMI_ATTN_V": "3"}, True),
-                ("mb_exact", {"FLUXMI_ATTN_V": "3", "FLUXMI_ATTN_VAR": "2"}, True))
+    variants = (("deferred", 0, False), ("exact", 2, False), ("fold", 0, True), ("fold_exact", 2, True))
     s0, s1 = torch.tensor(3000.0), torch.tensor(9000.0)
-    for name, env, f16 in variants:
-        for kk in knobs:
-            monkeypatch.delenv(kk, raising=False)
-        for kk, vv in env.items():
-            monkeypatch.setenv(kk, vv)
+    for name, var, f16 in variants:
         kd = d(k.half() if f16 else k)
-        outs[name] = ops.attention(d(q), kd, d(VT)).cpu()
+        with _lib.tuning(attn_var=var, attn_abl=0):
+            outs[name] = ops.attention(d(q), kd, d(VT)).cpu()
+            # fused fp8 output: regrouped 16-byte stores == 4-byte stores
+            f8_new = ops.attention(d(q), kd, d(VT), q_scale0=d(s0), q_scale1=d(s1), split=L // 3).cpu()
         err = (outs[name].double() - ref).abs().max().item()
         assert torch.isfinite(outs[name]).all() and err <= 2e-2 * v.abs().max().item(), f"{name}: max abs err {err:.3e} vs fp64"
-        # fused fp8 output: regrouped 16-byte stores == 4-byte stores
-        f8_new = ops.attention(d(q), kd, d(VT), q_scale0=d(s0), q_scale1=d(s1), split=L // 3).cpu()
-        monkeypatch.setenv("FLUXMI_ATTN_ABL", "8")
-        f8_old = ops.attention(d(q), kd, d(VT), q_scale0=d(s0), q_scale1=d(s1), split=L // 3).cpu()
+        with _lib.tuning(attn_var=var, attn_abl=8):
+            f8_old = ops.attention(d(q), kd, d(VT), q_scale0=d(s0), q_scale1=d(s1), split=L // 3).cpu()
         assert torch.equal(f8_new.view(torch.uint8), f8_old.view(torch.uint8)), f"{name}: fp8 store variants differ"
-    for kk in knobs:
-        monkeypatch.delenv(kk, raising=False)
     for name, _, _ in variants[1:]:
         dd = (outs["deferred"].float() - outs[name].float()).abs().max().item()
         assert dd <= 2e-2 * v.abs().max().item(), f"deferred vs {name}: {dd:.3e}"
@@ -587,16 +647,11 @@ def test_attention_deferred_rescale_branch(ops, dev, L, monkeypatch):
     r = lambda n: ((outs[n].double() - ref).norm() / ref.norm()).item()
     # the fold must not cost accuracy (a bf16 fold did: rel-L2 1.8e-3 -> 3.3e-3 on these inputs)
     assert r("fold") <= 1.15 * r("deferred") + 1e-4 and r("fold_exact") <= 1.15 * r("exact") + 1e-4, (r("fold"), r("deferred"), r("fold_exact"), r("exact"))
-    assert r("w4") <= 1.15 * r("deferred") + 1e-4 and r("w4_exact") <= 1.15 * r("exact") + 1e-4, (r("w4"), r("deferred"), r("w4_exact"), r("exact"))
-    # FLUXMI_ATTN_V=3 moves the 8-wave kernel's barrier between its two MFMA groups: same arithmetic, bit-identical results
-    assert torch.equal(outs["mb"], outs["fold"]) and torch.equal(outs["mb_exact"], outs["fold_exact"])
     same = (outs["deferred"] == outs["exact"]).float().mean().item()
     same_f = (outs["deferred"] == outs["fold"]).float().mean().item()
-    same_4 = (outs["fold"] == outs["w4"]).float().mean().item()
-    print(f"L={L}: max |err| vs fp64 deferred {e('deferred'):.2e} / exact {e('exact'):.2e} / fold {e('fold'):.2e} / fold_exact {e('fold_exact'):.2e} / "
-          f"4-wave {e('w4'):.2e} / 4-wave exact {e('w4_exact'):.2e}; rel-L2 deferred {r('deferred'):.3e} fold {r('fold'):.3e} exact {r('exact'):.3e} "
-          f"fold_exact {r('fold_exact'):.3e} 4-wave {r('w4'):.3e} 4-wave exact {r('w4_exact'):.3e}; deferred == exact on {same:.4f}, == fold on {same_f:.4f}, "
-          f"fold == 4-wave on {same_4:.4f} of the outputs")
+    print(f"L={L}: max |err| vs fp64 deferred {e('deferred'):.2e} / exact {e('exact'):.2e} / fold {e('fold'):.2e} / fold_exact {e('fold_exact'):.2e}; "
+          f"rel-L2 deferred {r('deferred'):.3e} fold {r('fold'):.3e} exact {r('exact'):.3e} fold_exact {r('fold_exact'):.3e}; "
+          f"deferred == exact on {same:.4f}, == fold on {same_f:.4f} of the outputs")
 
 
 @pytest.mark.parametrize("L,Lt", [(320, 64), (200, 40)])

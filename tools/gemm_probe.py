@@ -1,6 +1,10 @@
 """One GEMM shape / tile config / epilogue, launched `iters` times -- the target for rocprofv3 PMC passes and A/B timing:
-    python tools/gemm_probe.py --shape 4608,21504,3072 --cfg 13 --epi bf16 --iters 10 [--fill zero] [--ab 13,16]
-With --ab a,b the two configs are timed interleaved over several rounds (median / min per config)."""
+    python tools/gemm_probe.py --shape 4608,21504,3072 --cfg 13 --epi bf16 --iters 10 [--fill zero] [--ab 13,18]
+With --ab a,b the configs are timed interleaved over several rounds (median / best per config) and, with --check, their outputs are
+compared byte for byte first (the persistent kernel 18 runs the K loop of 13 in the same order: identical bits are the expectation).
+    --epi split       single-block linear1: q|k|v columns as bf16 (V^T fused with --vt), gelu(mlp) columns as fp8 through the table
+    --groups 512,4096 a grouped launch (double-block txt + img streams, one weight matrix each)
+    --timeline        tile config 19 (= 18 with in-kernel timestamps): per-tile K-loop / epilogue durations and the shader clock"""
 import argparse
 import os
 import statistics
@@ -16,43 +20,79 @@ SHAPES = {
     "qkv": (4096, 9216, 3072), "proj": (4096, 3072, 3072), "mlp0": (4096, 12288, 3072), "mlp2": (4096, 3072, 12288),
     "lin1": (4608, 21504, 3072), "lin2": (4608, 3072, 15360), "tqkv": (512, 9216, 3072), "tmlp2": (512, 3072, 12288),
 }
+H = 3072
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="lin1")
     ap.add_argument("--cfg", type=int, default=13)
-    ap.add_argument("--epi", default="bf16", choices=["bf16", "gelu", "gate", "quant"])
+    ap.add_argument("--epi", default="bf16", choices=["bf16", "gelu", "gate", "quant", "split"])
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--fill", default="rand", choices=["rand", "zero"])
     ap.add_argument("--ab", default=None, help="comma list of configs to A/B interleaved")
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--groups", default=None, help="comma list of M per group (grouped launch, one weight matrix per group)")
+    ap.add_argument("--vt", action="store_true", help="bf16 / split epilogue: fused V^T output for the columns [2H, 3H)")
+    ap.add_argument("--no-lut", action="store_true", help="quantising epilogues without the table (VALU GELU)")
+    ap.add_argument("--check", action="store_true", help="with --ab: compare the outputs of the configs byte for byte")
+    ap.add_argument("--timeline", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     M, N, K = SHAPES[args.shape] if args.shape in SHAPES else tuple(int(v) for v in args.shape.split(","))
+    Ms = [int(v) for v in args.groups.split(",")] if args.groups else [M]
     torch.manual_seed(0)
     one = torch.tensor(1.0, device=dev)
-    if args.fill == "zero":
-        a = torch.zeros(M, K, device=dev).to(torch.float8_e5m2)
-        w = torch.zeros(N, K, device=dev).to(torch.float8_e4m3fn)
-    else:
-        a = (torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2)
-        w = (torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn)
-    bias = torch.randn(N, device=dev).bfloat16()
-    gate = torch.randn(N, device=dev).bfloat16()
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    out8 = torch.empty(M, N, dtype=torch.float8_e5m2, device=dev)
-    resid = torch.randn(M, N, device=dev).bfloat16()
+    qs = torch.tensor(3.0, device=dev)
+    lut = None if args.no_lut else ops.build_quant_lut(qs, _lib.E5M2, act=1)
+    epi = {"bf16": _lib.EPI_BF16, "gelu": _lib.EPI_GELU_QUANT, "gate": _lib.EPI_GATE_RESID, "quant": _lib.EPI_QUANT, "split": _lib.EPI_SPLIT}[args.epi]
+
+    def build():
+        groups, keep, outs = [], [], []
+        for Mg in Ms:
+            if args.fill == "zero":
+                a = torch.zeros(Mg, K, device=dev).to(torch.float8_e5m2)
+                w = torch.zeros(N, K, device=dev).to(torch.float8_e4m3fn)
+            else:
+                a = (torch.randn(Mg, K, device=dev) * 2).to(torch.float8_e5m2)
+                w = (torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn)
+            bias = torch.randn(N, device=dev).bfloat16()
+            kw = {}
+            if args.epi == "bf16":
+                o = torch.zeros(Mg, N, dtype=torch.bfloat16, device=dev)
+            elif args.epi in ("quant", "gelu"):
+                o = torch.zeros(Mg, N, dtype=torch.float8_e5m2, device=dev)
+                kw = dict(q_scale=qs.data_ptr(), q_lut=lut.data_ptr() if (lut is not None and args.epi == "gelu") else None)
+            elif args.epi == "gate":
+                o = torch.randn(Mg, N, device=dev).bfloat16()
+                gate = torch.randn(N, device=dev).bfloat16()
+                keep.append(gate)
+                kw = dict(gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N)
+            else:  # split: [q | k | v | mlp]
+                o = torch.zeros(Mg, 3 * H, dtype=torch.bfloat16, device=dev)
+                o2 = torch.zeros(Mg, 5 * H, dtype=torch.float8_e5m2, device=dev)
+                outs.append(o2)
+                kw = dict(C2=o2.data_ptr(), ldc2=5 * H, split_n=3 * H, c2_col0=H, q_scale=qs.data_ptr(), q_lut=lut.data_ptr() if lut is not None else None)
+            if args.vt and args.epi in ("bf16", "split"):
+                Lp = (Mg + 63) // 64 * 64
+                vt = torch.zeros(H, Lp, dtype=torch.bfloat16, device=dev)
+                outs.append(vt)
+                kw.update(vt_out=vt.data_ptr(), vt_ld=Lp, tok0=0, vt_rows=Lp, kv_col0=H, heads=H // 128)
+            keep += [a, w, bias]
+            outs.append(o)
+            groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr(), one.data_ptr(), o.data_ptr(), Mg, K, o.stride(0), **kw))
+        return groups, keep, outs
+
+    groups, keep, outs = build()
+    resid0 = [o.clone() for o in outs] if args.epi == "gate" else None
 
     def run(cfg):
-        if args.epi == "bf16":
-            ops.linear(a, w, bias, one, one, out=out, tile_cfg=cfg)
-        elif args.epi == "quant":
-            ops.linear(a, w, bias, one, one, out=out8, epilogue=_lib.EPI_QUANT, q_scale=one, tile_cfg=cfg)
-        elif args.epi == "gelu":
-            ops.linear(a, w, bias, one, one, out=out8, epilogue=_lib.EPI_GELU_QUANT, q_scale=one, tile_cfg=cfg)
-        else:
-            ops.linear(a, w, bias, one, one, out=resid, resid=resid, gate=gate, epilogue=_lib.EPI_GATE_RESID, tile_cfg=cfg)
+        ops.gemm_grouped(groups, N, K, True, _lib.E5M2, epi, cfg)
+
+    def reset():
+        if resid0 is not None:  # gate*y + x updates the residual stream in place
+            for o, r in zip(outs, resid0):
+                o.copy_(r)
 
     def timed(cfg, iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -64,6 +104,52 @@ def main():
         return e0.elapsed_time(e1) / iters * 1e-3
 
     cfgs = [int(c) for c in args.ab.split(",")] if args.ab else [args.cfg]
+    tag = f"{args.shape} Ms={Ms} N={N} K={K} epi={args.epi}{'+vt' if args.vt else ''}{' no-lut' if args.no_lut else ''} fill={args.fill}"
+    if args.check:
+        ref = None
+        for c in cfgs:
+            reset()
+            for o in outs:
+                if resid0 is None:
+                    o.zero_()
+            run(c)
+            torch.cuda.synchronize()
+            got = [o.clone().view(torch.uint8) for o in outs]
+            if ref is None:
+                ref = got
+            else:
+                same = [float((g == r).float().mean()) for g, r in zip(got, ref)]
+                print(f"check {tag}: cfg {c} vs cfg {cfgs[0]}: identical bytes per output {same}", flush=True)
+                assert all(s == 1.0 for s in same), "outputs differ"
+    if args.timeline:
+        nwg = 256
+        dbg = torch.zeros(nwg * 8 * 4, dtype=torch.int64, device=dev)
+        _lib.call("fluxmi_gemm_debug_buffer", dbg.data_ptr())
+        for _ in range(3):
+            run(19)
+        torch.cuda.synchronize()
+        dbg.zero_()
+        run(19)
+        torch.cuda.synchronize()
+        _lib.call("fluxmi_gemm_debug_buffer", None)
+        d = dbg.cpu().view(nwg, 8, 4)
+        used = d[:, :, 0] != 0
+        t0 = d[:, :, 0][used].min().item()
+        kl = (d[:, :, 1] - d[:, :, 0])[used].float()
+        ep = (d[:, :, 2] - d[:, :, 1])[used].float()
+        gap = (d[:, 1:, 0] - d[:, :-1, 2])[used[:, 1:]].float()
+        end = d[:, :, 2][used].max().item()
+        rt = d[:, :, 3][used]
+        clk = (end - t0) / max(1, (rt.max().item() - rt.min().item())) * 100e6 if rt.numel() > 1 else float("nan")
+        print(f"timeline {tag}: {int(used.sum())} tiles on {int(used.any(1).sum())} workgroups; K loop {kl.mean():.0f} cycles (min {kl.min():.0f} max {kl.max():.0f}), "
+              f"epilogue {ep.mean():.0f} (min {ep.min():.0f} max {ep.max():.0f}), tile-to-tile gap {gap.mean() if gap.numel() else 0:.0f}; "
+              f"kernel span {end - t0} cycles; shader clock over the span ~{clk / 1e9:.2f} GHz", flush=True)
+        for j in range(8):
+            u = used[:, j]
+            if u.any():
+                print(f"   tile #{j}: {int(u.sum())} workgroups, start +{(d[:, j, 0][u] - t0).float().mean():.0f}, K loop {(d[:, j, 1] - d[:, j, 0])[u].float().mean():.0f}, "
+                      f"epilogue {(d[:, j, 2] - d[:, j, 1])[u].float().mean():.0f}", flush=True)
+        return
     for c in cfgs:
         run(c)
     torch.cuda.synchronize()
@@ -71,10 +157,10 @@ def main():
     for _ in range(args.rounds if args.ab else 1):
         for c in cfgs:
             res[c].append(timed(c, args.iters))
+    Mtot = sum(Ms)
     for c in cfgs:
-        tf = [2 * M * N * K / t / 1e12 for t in res[c]]
-        print(f"{args.shape} M={M} N={N} K={K} epi={args.epi} fill={args.fill} cfg={c}: median {statistics.median(tf):7.1f} TF/s  max {max(tf):7.1f}  "
-              f"({statistics.median(res[c]) * 1e6:.1f} us)", flush=True)
+        tf = [2 * Mtot * N * K / t / 1e12 for t in res[c]]
+        print(f"{tag} cfg={c}: median {statistics.median(tf):7.1f} TF/s  max {max(tf):7.1f}  ({statistics.median(res[c]) * 1e6:.1f} us)", flush=True)
 
 
 if __name__ == "__main__":
