@@ -55,6 +55,23 @@ __device__ __forceinline__ void ps_setup(const FluxmiGemmParams& P, int lid, int
 // knows that nothing older is pending -- with the asm form it kept every epilogue load "in flight" in its model and drained vmcnt (i.e.
 // the epilogue's stores) at the first register reuse of the next tile
 __device__ __forceinline__ void ps_wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// 16-byte store through a buffer descriptor: per-lane byte offset in a VGPR and NO guard -- an offset at or past the descriptor's size
+// (a row past M, or 0xffffffff for a lane that must not store) is dropped by the hardware.  With the row guard as a branch hipcc put
+// every store of the epilogue into its own basic block: ds_read -> lgkmcnt(0) -> 64-bit address multiply -> store, sixteen LDS round
+// trips in a row.
+// The wave's tile origin goes into the descriptor BASE, not into the instruction's SGPR offset: with a register in the soffset field
+// hipcc (ROCm 7.2) assumes that a 128-bit MUBUF store has no "data VGPR overwritten before the store has read it" hazard and emits
+//     buffer_store_dwordx4 v[138:141], v152, s[4:7], s17 offen ; v_add_u32 v138, s16, v152
+// back to back -- on gfx950 the store then picks up the NEW v138 now and then (measured: 300 - 35000 wrong bytes per launch).  With the
+// field hard-wired to 0 the compiler pads the hazard itself.
+__device__ __forceinline__ void ps_store16(__amdgpu_buffer_rsrc_t rsrc, v4i data, unsigned voff) {
+  __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voff, 0, 0);
+}
+// descriptor of the wave's part of an output: `base + origin` .. `base + bytes` (empty if the origin lies past the end)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ps_out_rsrc(void* base, long long bytes, long long origin) {
+  const long long left = bytes - origin;
+  return make_rsrc((char*)base + origin, (unsigned)(left > 0 ? min(left, 0xffffffffLL) : 0));
+}
 __device__ __forceinline__ unsigned long long ps_clock() { return __builtin_amdgcn_s_memtime(); }
 __device__ __forceinline__ unsigned long long ps_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 
@@ -168,31 +185,30 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave is done with the table: its slots go back to the ring
       after_table();
-      const fluxmi_gptr<unsigned char> c8 = EPI == FLUXMI_EPI_SPLIT ? uni_ptr((unsigned char*)G.C2) : uni_ptr((unsigned char*)G.C);
-      const long long ld8 = EPI == FLUXMI_EPI_SPLIT ? uni_i64(G.ldc2) : uni_i64(G.ldc);
+      const unsigned ld8 = EPI == FLUXMI_EPI_SPLIT ? uni_u32((unsigned)G.ldc2) : uni_u32((unsigned)G.ldc);
       const int col0 = EPI == FLUXMI_EPI_SPLIT ? (int)uni_u32((unsigned)(G.c2_col0 - G.split_n)) : 0;
+      const __amdgpu_buffer_rsrc_t c8 = ps_out_rsrc(EPI == FLUXMI_EPI_SPLIT ? G.C2 : G.C, (long long)M * ld8, (long long)m_wave0 * ld8 + (col0 + n_wave0));
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int ml = it * 16 + (lane >> 2), c = lane & 3;
-          const int m = m_wave0 + i * 32 + ml;
-          if (m < M) *(fluxmi_gptr<v4i>)(c8 + (long long)m * ld8 + col0 + n_wave0 + c * 16) = __builtin_bit_cast(v4i, raw[i][it]);
+          ps_store16(c8, __builtin_bit_cast(v4i, raw[i][it]), (unsigned)(i * 32 + ml) * ld8 + c * 16);
         }
       return;
     }
   }
 
-  const fluxmi_gptr<u16> c_p = uni_ptr((u16*)G.C);
-  const long long ldc_u = uni_i64(G.ldc);
+  const unsigned ldc_b = uni_u32((unsigned)G.ldc) * 2;  // row stride in bytes
+  const __amdgpu_buffer_rsrc_t c_rs = ps_out_rsrc(G.C, (long long)M * ldc_b, (long long)m_wave0 * ldc_b + (long long)n_wave0 * 2);
   if constexpr (EPI == FLUXMI_EPI_BF16 || EPI == FLUXMI_EPI_SPLIT) {
     // ---- fused V^T (wave-uniform): [32 keys][64 d] of one head's V per block -> LDS as [64 d][32 keys] (keys in the PV MFMA's k-slot
     // order: bits 2 and 3 swapped inside a 16-key group), leaves as 64-byte runs of one d-row of vt_out
     const int vcol0 = G.kv_col0 + G.heads * 128;
     if (G.vt_out && n_wave0 >= vcol0 && n_wave0 < vcol0 + G.heads * 128) {
-      const fluxmi_gptr<u16> vt_p = uni_ptr((u16*)G.vt_out);
-      const long long vt_ld = uni_i64(G.vt_ld);
+      const unsigned vt_ld_b = uni_u32((unsigned)G.vt_ld) * 2;
       const int d0 = n_wave0 - vcol0, tok0 = (int)uni_u32((unsigned)G.tok0), vt_rows = (int)uni_u32((unsigned)G.vt_rows);
+      const __amdgpu_buffer_rsrc_t vt_rs = ps_out_rsrc(G.vt_out, (long long)(G.heads * 128) * vt_ld_b, (long long)d0 * vt_ld_b + (long long)(tok0 + m_wave0) * 2);
       const int posl = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
       convert_all();
       ps_wait_all_vmem();  // the ONE vmcnt(0) of this path: from here on hipcc's wait-count model holds no LDS-DMA a scratch access could alias
@@ -216,7 +232,7 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
           const int dl = it * 16 + (lane >> 2), c = lane & 3;
           const uint4 raw = *(const uint4*)(wbuf + dl * 64 + c * 16);
           const int key = m_wave0 + i * 32 + c * 8;  // group-relative position of the 8 keys
-          if (key < vt_rows) *(fluxmi_gptr<v4i>)(vt_p + (long long)(d0 + dl) * vt_ld + tok0 + key) = __builtin_bit_cast(v4i, raw);
+          ps_store16(vt_rs, __builtin_bit_cast(v4i, raw), key < vt_rows ? (unsigned)dl * vt_ld_b + (unsigned)(i * 32 + c * 8) * 2 : 0xffffffffu);
         }
       }
       return;
@@ -270,7 +286,6 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int ml = it * 8 + rl;
-      const int m = m_wave0 + i * 32 + ml;
       const uint4 raw = *(const uint4*)(wbuf + ml * 128 + ((c ^ (ml & 7)) * 16));
       if constexpr (GR) {
         float h[8], r[8], o[8];
@@ -278,9 +293,9 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
         unpack8(rres[i & 1][it], r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = r[e] + rbf(g[e] * h[e]);
-        if (m < M) *(fluxmi_gptr<v4i>)(c_p + (long long)m * ldc_u + n_wave0 + c * 8) = __builtin_bit_cast(v4i, pack8(o));
+        ps_store16(c_rs, __builtin_bit_cast(v4i, pack8(o)), (unsigned)(i * 32 + ml) * ldc_b + c * 16);
       } else {
-        if (m < M) *(fluxmi_gptr<v4i>)(c_p + (long long)m * ldc_u + n_wave0 + c * 8) = __builtin_bit_cast(v4i, raw);
+        ps_store16(c_rs, __builtin_bit_cast(v4i, raw), (unsigned)(i * 32 + ml) * ldc_b + c * 16);
       }
     }
   }

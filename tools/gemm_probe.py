@@ -118,9 +118,9 @@ def main():
             if ref is None:
                 ref = got
             else:
-                same = [float((g == r).float().mean()) for g, r in zip(got, ref)]
-                print(f"check {tag}: cfg {c} vs cfg {cfgs[0]}: identical bytes per output {same}", flush=True)
-                assert all(s == 1.0 for s in same), "outputs differ"
+                diff = [int((g != r).sum().item()) for g, r in zip(got, ref)]  # integer count (a float32 mean of 2e8 ones is not exact)
+                print(f"check {tag}: cfg {c} vs cfg {cfgs[0]}: differing bytes per output {diff} of {[g.numel() for g in got]}", flush=True)
+                assert all(d == 0 for d in diff), "outputs differ"
     if args.timeline:
         nwg = 256
         dbg = torch.zeros(nwg * 8 * 4, dtype=torch.int64, device=dev)
@@ -134,20 +134,26 @@ def main():
         _lib.call("fluxmi_gemm_debug_buffer", None)
         d = dbg.cpu().view(nwg, 8, 4)
         used = d[:, :, 0] != 0
-        t0 = d[:, :, 0][used].min().item()
         kl = (d[:, :, 1] - d[:, :, 0])[used].float()
         ep = (d[:, :, 2] - d[:, :, 1])[used].float()
         gap = (d[:, 1:, 0] - d[:, :-1, 2])[used[:, 1:]].float()
-        end = d[:, :, 2][used].max().item()
-        rt = d[:, :, 3][used]
-        clk = (end - t0) / max(1, (rt.max().item() - rt.min().item())) * 100e6 if rt.numel() > 1 else float("nan")
+        # the shader-clock counters of different XCDs are not aligned: spans and the clock are taken per workgroup (tile 0 start .. last
+        # tile end against the 100 MHz real-time stamps of its first and last tile ends)
+        ntile = used.sum(1)
+        wg = torch.nonzero(ntile >= 2).flatten()
+        last = (ntile[wg] - 1).clamp(max=7)
+        cyc = d[wg, last, 2] - d[wg, 0, 2]
+        rt = (d[wg, last, 3] - d[wg, 0, 3]).float() * 10e-9
+        clk = (cyc.float() / rt)[rt > 0]
+        span = (d[wg, last, 2] - d[wg, 0, 0]).float()
         print(f"timeline {tag}: {int(used.sum())} tiles on {int(used.any(1).sum())} workgroups; K loop {kl.mean():.0f} cycles (min {kl.min():.0f} max {kl.max():.0f}), "
               f"epilogue {ep.mean():.0f} (min {ep.min():.0f} max {ep.max():.0f}), tile-to-tile gap {gap.mean() if gap.numel() else 0:.0f}; "
-              f"kernel span {end - t0} cycles; shader clock over the span ~{clk / 1e9:.2f} GHz", flush=True)
+              f"per-workgroup span {span.mean() if span.numel() else 0:.0f} cycles; shader clock {clk.median().item() / 1e9 if clk.numel() else float('nan'):.3f} GHz "
+              f"(min {clk.min().item() / 1e9 if clk.numel() else float('nan'):.3f} max {clk.max().item() / 1e9 if clk.numel() else float('nan'):.3f})", flush=True)
         for j in range(8):
             u = used[:, j]
             if u.any():
-                print(f"   tile #{j}: {int(u.sum())} workgroups, start +{(d[:, j, 0][u] - t0).float().mean():.0f}, K loop {(d[:, j, 1] - d[:, j, 0])[u].float().mean():.0f}, "
+                print(f"   tile #{j}: {int(u.sum())} workgroups, K loop {(d[:, j, 1] - d[:, j, 0])[u].float().mean():.0f}, "
                       f"epilogue {(d[:, j, 2] - d[:, j, 1])[u].float().mean():.0f}", flush=True)
         return
     for c in cfgs:
