@@ -95,7 +95,9 @@ __device__ __forceinline__ void ps_load_bias(const FluxmiGemmGroup& G, int n_wav
 template <int EPI, int FMT, class AfterTable>
 __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc)[4][2], uint2 (&braw)[2][4], float s, unsigned char* wbuf,
                                             unsigned char* table, int m_wave0, int n_wave0, int M, int lane, int wave, bool lut,
-                                            AfterTable after_table) {
+                                            AfterTable after_table, unsigned long long* stamps = nullptr) {
+  // timing build only: phase stamps of the table path (stamps[0..3]) by the workgroup's first lane
+  auto stamp = [&](int k) { if (stamps) stamps[k] = ps_clock(); };
   constexpr int TM = 4, TN = 2;
   const int l31 = lane & 31, hi = lane >> 5;
   const bool has_bias = uni_ptr((const u16*)G.bias) != nullptr;
@@ -135,28 +137,30 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
 
   if constexpr (EPI == FLUXMI_EPI_GELU_QUANT || EPI == FLUXMI_EPI_SPLIT) {
     if (lut) {
-      // ---- table path (see gemm_epilogue.h, lds_epilogue): fp8 = table[bf16(acc * s + bias)] ------------------------------------
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // every wave has read the last K-steps out of ring slots 2 and 3
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int piece = wave * 8 + q;
-        glds16((const unsigned char*)G.q_lut + piece * 1024 + lane * 16, table + piece * 1024);
-      }
+      // ---- quantising path: fp8 = quantise(gelu(bf16(acc * s + bias))) -------------------------------------------------------------
+      // The 64 KiB table (gemm_epilogue.h) sits in ring slots 2 and 3; its LDS-DMA was issued inside the last K-step (kernel: behind a
+      // barrier in the middle of that step, when both slots were dead), so it lands under the step's last MFMAs and the conversion.
+      // The byte gather runs at the speed of its LDS bank conflicts (64 random addresses per ds_read_u8: ~10 K cycles per tile for the
+      // 1024 gather instructions of the eight waves); quantising half of the blocks on the VALU instead, the two waves of a SIMD in
+      // opposite order, was measured SLOWER (the exact GELU chain costs ~14 VALU instructions per element, two of them
+      // transcendental: profiles/r04_gemm_persist.txt) and is not in the tree.
       convert_all();
+      stamp(1);
       ps_wait_all_vmem();  // the table (and the next tile's two K-steps) landed
       __builtin_amdgcn_s_barrier();
-      unsigned qw[TM][TN][4];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+      stamp(2);
+      auto gather_block = [&](int i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const unsigned a = hp[i][j][g4][0], b = hp[i][j][g4][1];
             const unsigned q0 = table[a & 0xffffu], q1 = table[a >> 16], q2 = table[b & 0xffffu], q3 = table[b >> 16];
-            qw[i][j][g4] = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+            hp[i][j][g4][0] = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);  // in place: the packed pair is dead
           }
+      };
+#pragma unroll
+      for (int i = 0; i < TM; ++i) gather_block(i);
       // 32 rows x 64 B of fp8 per block through the wave's scratch: lane owns 4 consecutive columns of row l31 -> one dword, 16-B chunks
       // XOR-swizzled by row; read back as (row, 16-B chunk) per lane.  ALL of it happens before the successor's third K-step is issued:
       // hipcc orders every LDS read behind a pending LDS-DMA it cannot prove disjoint (vmcnt(0) in front of each read, and with it a full
@@ -170,7 +174,7 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
           for (int g4 = 0; g4 < 4; ++g4) {
             const int nl = j * 32 + g4 * 8 + hi * 4;
             const int chunk = (nl >> 4) ^ ((l31 >> 1) & 3);
-            *(unsigned*)(wbuf + l31 * 64 + chunk * 16 + (nl & 12)) = qw[i][j][g4];
+            *(unsigned*)(wbuf + l31 * 64 + chunk * 16 + (nl & 12)) = hp[i][j][g4][0];
           }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -183,6 +187,7 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
 #pragma unroll
         for (int it = 0; it < 2; ++it) asm volatile("" : "+v"(raw[i][it].x), "+v"(raw[i][it].y), "+v"(raw[i][it].z), "+v"(raw[i][it].w));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(3);
       __builtin_amdgcn_s_barrier();  // every wave is done with the table: its slots go back to the ring
       after_table();
       const unsigned ld8 = EPI == FLUXMI_EPI_SPLIT ? uni_u32((unsigned)G.ldc2) : uni_u32((unsigned)G.ldc);
@@ -368,9 +373,11 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       n_ars = c_ars; n_wrs = c_wrs; n_asoff = c_asoff; n_wsoff = c_wsoff; n_gi = c_gi; n_m0 = c_m0; n_n0 = c_n0;
     }
     const FluxmiGemmGroup& G = P.g[c_gi];
-    bool lut_tile = false;
-    if constexpr (ESEL == FLUXMI_EPI_GELU_QUANT) lut_tile = true;
-    if constexpr (ESEL == FLUXMI_EPI_SPLIT) lut_tile = c_n0 >= (int)uni_u32((unsigned)G.split_n);
+    // K loop + epilogue of one tile, compiled ONCE PER KIND of tile (table tile or not): as a run-time flag inside one body the table
+    // tile's extra barrier / table DMA in the last K-step made hipcc spill ~230 VGPRs -- with reloads inside the K loop, each a VMEM
+    // operation that drains vmcnt (linear1: 268 -> 414 us)
+    auto tile_body = [&](auto LUT_TILE) {
+    constexpr bool lut_tile = decltype(LUT_TILE)::value;
 
     // everything derived from the lane index is recomputed per tile from an opaque copy: values that stay live across the epilogue (the
     // point of highest register pressure) are what hipcc spills, and a reload inside the K loop is a VMEM operation that drains vmcnt
@@ -441,6 +448,18 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       if constexpr (decltype(NXT)::value) dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, kt_src, SLOT);
       else dma_stage(c_ars, c_wrs, c_asoff, c_wsoff, kt_src, SLOT);
     };
+    // table tiles, last K-step only: once group 1 holds its fragments of that step (group 0 took them a step earlier) ring slots 2 and 3
+    // are dead -- one extra barrier there, then the 64 pieces of the table are issued under the step's remaining MFMAs
+    // (through a descriptor: one VGPR of per-lane offset instead of eight 64-bit addresses at the point of highest register pressure)
+    auto table_dma = [&]() {
+      const __amdgpu_buffer_rsrc_t trs = make_rsrc(G.q_lut, 65536u);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int piece = wave * 8 + q;
+        dma16_buf(trs, smem + 2 * STAGE + piece * 1024, (unsigned)lane * 16, (unsigned)piece * 1024);
+      }
+    };
+    constexpr bool MAY_LUT = ESEL == FLUXMI_EPI_GELU_QUANT || ESEL == FLUXMI_EPI_SPLIT;
     auto step_g0 = [&](auto SLOT, auto WAIT, auto ZERO, auto READ_NEXT, auto DMA, auto NXT, int kt_src) {
       constexpr int S = decltype(SLOT)::value, W = decltype(WAIT)::value;
       if constexpr (W == 1) wait_vmcnt<LPT>();
@@ -448,12 +467,18 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       fence();
       mma_all(ZERO);
       fence();
+      if constexpr (MAY_LUT && !decltype(READ_NEXT)::value) {  // (READ_NEXT = false marks the last step of a tile)
+        if constexpr (lut_tile) {
+          __builtin_amdgcn_s_barrier();
+          table_dma();
+        }
+      }
       if constexpr (decltype(DMA)::value) refill(ic<(S + 3) & 3>{}, NXT, kt_src);
       fence();
       if constexpr (decltype(READ_NEXT)::value) read_frags(ic<(S + 1) & 3>{});
       fence();
     };
-    auto step_g1 = [&](auto SLOT, auto WAIT, auto ZERO, auto DMA, auto NXT, int kt_src) {
+    auto step_g1 = [&](auto SLOT, auto WAIT, auto ZERO, auto DMA, auto NXT, int kt_src, auto LAST) {
       constexpr int S = decltype(SLOT)::value, W = decltype(WAIT)::value;
       if constexpr (W == 1) wait_vmcnt<LPT>();
       __builtin_amdgcn_s_barrier();
@@ -462,8 +487,17 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       fence();
       if constexpr (decltype(DMA)::value) refill(ic<(S + 3) & 3>{}, NXT, kt_src);
       fence();
+      if constexpr (MAY_LUT && decltype(LAST)::value) {
+        if constexpr (lut_tile) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments of the last K-step are in registers
+          __builtin_amdgcn_s_barrier();
+        }
+      }
       mma_all(ZERO);
       fence();
+      if constexpr (MAY_LUT && decltype(LAST)::value) {
+        if constexpr (lut_tile) table_dma();
+      }
     };
     using T = std::true_type;
     using F = std::false_type;
@@ -493,24 +527,24 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       step_g0(ic<2>{}, ic<1>{}, F{}, T{}, T{}, T{}, 1);
       step_g0(ic<3>{}, ic<1>{}, F{}, F{}, LASTDMA{}, T{}, 2);
     } else {
-      step_g1(ic<0>{}, ic<0>{}, T{}, T{}, F{}, 3);
-      step_g1(ic<1>{}, W1{}, F{}, T{}, F{}, 4);
-      step_g1(ic<2>{}, ic<1>{}, F{}, T{}, F{}, 5);
-      step_g1(ic<3>{}, ic<1>{}, F{}, T{}, F{}, 6);
+      step_g1(ic<0>{}, ic<0>{}, T{}, T{}, F{}, 3, F{});
+      step_g1(ic<1>{}, W1{}, F{}, T{}, F{}, 4, F{});
+      step_g1(ic<2>{}, ic<1>{}, F{}, T{}, F{}, 5, F{});
+      step_g1(ic<3>{}, ic<1>{}, F{}, T{}, F{}, 6, F{});
       for (int kt = 4; kt < nk - 4; kt += 4) {
-        step_g1(ic<0>{}, ic<1>{}, F{}, T{}, F{}, kt + 3);
-        step_g1(ic<1>{}, ic<1>{}, F{}, T{}, F{}, kt + 4);
-        step_g1(ic<2>{}, ic<1>{}, F{}, T{}, F{}, kt + 5);
-        step_g1(ic<3>{}, ic<1>{}, F{}, T{}, F{}, kt + 6);
+        step_g1(ic<0>{}, ic<1>{}, F{}, T{}, F{}, kt + 3, F{});
+        step_g1(ic<1>{}, ic<1>{}, F{}, T{}, F{}, kt + 4, F{});
+        step_g1(ic<2>{}, ic<1>{}, F{}, T{}, F{}, kt + 5, F{});
+        step_g1(ic<3>{}, ic<1>{}, F{}, T{}, F{}, kt + 6, F{});
       }
       ps_load_bias(G, c_n0 + wn * 64, hi, braw);
-      step_g1(ic<0>{}, ic<1>{}, F{}, T{}, F{}, nk - 1);
-      step_g1(ic<1>{}, ic<1>{}, F{}, T{}, T{}, 0);
-      step_g1(ic<2>{}, ic<1>{}, F{}, T{}, T{}, 1);
-      step_g1(ic<3>{}, ic<1>{}, F{}, LASTDMA{}, T{}, 2);
+      step_g1(ic<0>{}, ic<1>{}, F{}, T{}, F{}, nk - 1, F{});
+      step_g1(ic<1>{}, ic<1>{}, F{}, T{}, T{}, 0, F{});
+      step_g1(ic<2>{}, ic<1>{}, F{}, T{}, T{}, 1, F{});
+      step_g1(ic<3>{}, ic<1>{}, F{}, LASTDMA{}, T{}, 2, T{});
     }
     if constexpr (ESEL == FLUXMI_EPI_SPLIT) {
-      if (!lut_tile) dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, ic<2>{});
+      if constexpr (!lut_tile) dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, ic<2>{});
     }
     if constexpr (TIMING) t_kend = ps_clock();
 
@@ -520,13 +554,25 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
     const float s = load_scale_u(G.sa_recip) * load_scale_u(G.sb_recip);
     const int M = (int)uni_u32((unsigned)G.M);
     unsigned char* wbuf = smem + RING + wave * 4096;
+    unsigned long long* stamps = nullptr;
+    if constexpr (TIMING) {
+      if (threadIdx.x == 0 && P.dbg) stamps = P.dbg + ((size_t)blockIdx.x * 8 + (jt < 8 ? jt : 7)) * 8 + 4;
+    }
     ps_epilogue<ESEL, ACT_FMT>(G, acc, braw, s, wbuf, smem + 2 * STAGE, c_m0 + wm * 128, c_n0 + wn * 64, M, lane_e, wave, lut_tile,
-                               [&]() { dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, ic<2>{}); });
+                               [&]() { dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, ic<2>{}); }, stamps);
     if constexpr (TIMING) {
       if (threadIdx.x == 0 && P.dbg) {
-        unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 8 + (jt < 8 ? jt : 7)) * 4;
+        unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 8 + (jt < 8 ? jt : 7)) * 8;
         d[0] = t_start; d[1] = t_kend; d[2] = ps_clock(); d[3] = ps_realtime();
       }
+    }
+    };  // tile_body
+    if constexpr (ESEL == FLUXMI_EPI_GELU_QUANT) {
+      tile_body(std::true_type{});
+    } else if constexpr (ESEL == FLUXMI_EPI_SPLIT) {
+      if (c_n0 >= (int)uni_u32((unsigned)G.split_n)) tile_body(std::true_type{}); else tile_body(std::false_type{});
+    } else {
+      tile_body(std::false_type{});
     }
     if (!has_next) break;
     c_ars = n_ars; c_wrs = n_wrs; c_asoff = n_asoff; c_wsoff = n_wsoff; c_gi = n_gi; c_m0 = n_m0; c_n0 = n_n0;
@@ -569,7 +615,8 @@ unsigned long long* g_ps_dbg = nullptr;
 
 }  // namespace
 
-// timing probe (tools/ps_timeline.py): device buffer of [workgroup][tile < 8][t_start, t_k_end, t_end (shader clock), realtime (100 MHz)]
+// timing probe (tools/gemm_probe.py --timeline): device buffer of [workgroup][tile < 8][t_start, t_k_end, t_end (shader clock), realtime (100 MHz),
+// table path: table DMA issued, accumulators converted, table landed (barrier), gathers done]
 extern "C" int fluxmi_gemm_debug_buffer(void* dev_u64) {
   g_ps_dbg = (unsigned long long*)dev_u64;
   return 0;

@@ -114,8 +114,9 @@ typedef struct fluxmi_tuning {
 int fluxmi_get_tuning(fluxmi_tuning_t* out);
 int fluxmi_set_tuning(const fluxmi_tuning_t* in); /* validates every field (non-zero + fluxmi_last_error on a bad value) */
 
-/* Probes (tools/): a device buffer of [workgroup][tile < 8][4] uint64 that the timing build of the persistent GEMM (tile config 19)
- * fills with {tile start, K loop end, epilogue end} shader-clock stamps + the 100 MHz real-time counter; NULL switches it off.
+/* Probes (tools/): a device buffer of [workgroup][tile < 8][8] uint64 that the timing build of the persistent GEMM (tile config 19)
+ * fills with {tile start, K loop end, epilogue end} shader-clock stamps, the 100 MHz real-time counter and four phase stamps of the
+ * table epilogue; NULL switches it off.
  * fluxmi_clock_sample writes {XCC id, s_memtime, s_memrealtime} of one wave per XCD to out[0..23] (24 uint64) on `stream`: two samples
  * around a timed region, paired by XCC id, give the average shader clock the chip sustained over it (bench.py). */
 int fluxmi_gemm_debug_buffer(void* dev_u64);

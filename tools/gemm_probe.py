@@ -123,7 +123,7 @@ def main():
                 assert all(d == 0 for d in diff), "outputs differ"
     if args.timeline:
         nwg = 256
-        dbg = torch.zeros(nwg * 8 * 4, dtype=torch.int64, device=dev)
+        dbg = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
         _lib.call("fluxmi_gemm_debug_buffer", dbg.data_ptr())
         for _ in range(3):
             run(19)
@@ -132,7 +132,7 @@ def main():
         run(19)
         torch.cuda.synchronize()
         _lib.call("fluxmi_gemm_debug_buffer", None)
-        d = dbg.cpu().view(nwg, 8, 4)
+        d = dbg.cpu().view(nwg, 8, 8)
         used = d[:, :, 0] != 0
         kl = (d[:, :, 1] - d[:, :, 0])[used].float()
         ep = (d[:, :, 2] - d[:, :, 1])[used].float()
@@ -150,6 +150,11 @@ def main():
               f"epilogue {ep.mean():.0f} (min {ep.min():.0f} max {ep.max():.0f}), tile-to-tile gap {gap.mean() if gap.numel() else 0:.0f}; "
               f"per-workgroup span {span.mean() if span.numel() else 0:.0f} cycles; shader clock {clk.median().item() / 1e9 if clk.numel() else float('nan'):.3f} GHz "
               f"(min {clk.min().item() / 1e9 if clk.numel() else float('nan'):.3f} max {clk.max().item() / 1e9 if clk.numel() else float('nan'):.3f})", flush=True)
+        lutm = used & (d[:, :, 5] != 0)
+        if lutm.any():
+            ph = lambda a, b: (d[:, :, a] - d[:, :, b])[lutm].float().mean().item()
+            print(f"   table tiles ({int(lutm.sum())}): K-loop end -> accumulators converted {ph(5, 1):.0f}, table landed + barrier {ph(6, 5):.0f}, "
+                  f"gathers + transposition {ph(7, 6):.0f}, barrier + third K-step + stores {ph(2, 7):.0f} cycles", flush=True)
         for j in range(8):
             u = used[:, j]
             if u.any():
