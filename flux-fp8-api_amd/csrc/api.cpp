@@ -102,7 +102,7 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
     long long t256 = 0;
     for (int i = 0; i < n; ++i) t256 += (gs[i].M + 255) / 256;
     t256 *= N / 256;
-    if (t256 > 256) cfg = 18;
+    if (t256 > 256) cfg = fluxmi_tuning().gemm_persist == 2 ? 19 : 18;  // 2: the timing build (probes: fluxmi_gemm_debug_buffer)
   }
   const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0);
   if (cfg < 0 || !split_ok) return fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, s);

@@ -28,6 +28,8 @@ int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, 
   a.scale_log2 = 0.08838834764831845f * 1.4426950408889634f;  // 128^-0.5 * log2(e)
   a.k_f16 = k_f16;
   const fluxmi_tuning_t tun = fluxmi_tuning();
+  a.pf = fluxmi_take_prefetch();
+  if (!tun.prefetch) a.pf.n = 0;
   // Deferred running max (guide T13): P is bounded by 2^defer_log2 instead of 1, O and l carry the same factor, so the quotient is
   // unchanged; fp32 holds 4608 keys x 2^24 x |V| with a hundred binades to spare.  fluxmi_tuning_t.attn_defer_log2, validated to [0, 16].
   a.defer_log2 = tun.attn_defer_log2;

@@ -68,6 +68,10 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int nqb = (a.L + QB - 1) / QB;
+  if ((int)blockIdx.x >= nqb * a.H * a.B) {  // extra workgroups behind the grid: weight prefetch for the launches that follow
+    fluxmi_prefetch_ranges(a.pf, (int)blockIdx.x - nqb * a.H * a.B, a.pf.wgs, tid, NW2 * 64);
+    return;
+  }
   const int lid = xcd_remap(blockIdx.x, nqb * a.H * a.B);  // whole heads per XCD: a head's K / V^T (2.4 MB at L = 4608) is fetched into one 4 MiB L2 once and shared by its q-blocks
   const int bhid = lid / nqb;
   const int h = bhid % a.H, b = bhid / a.H;
@@ -425,7 +429,7 @@ template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(const A
     FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, MIDBAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
     attr = true;
   }
-  const dim3 grid(((a.L + 255) / 256) * a.H * a.B);
+  const dim3 grid(((a.L + 255) / 256) * a.H * a.B + (a.pf.n > 0 ? a.pf.wgs : 0));
   if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, a);
   else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, a);
   FLUXMI_LAUNCH_CHECK();

@@ -18,6 +18,7 @@ struct AttnArgs {
   float scale_log2;
   float defer_log2;  // the running max is updated (O, l, pending P rescaled) only when a row max grew by more than 2^defer_log2 (exp2 domain)
   int k_f16;  // K holds fp16: the folded kernel (scale * log2 e in Q, -max in the accumulator init), f16 MFMAs for QK^T
+  FluxmiPrefetch pf;  // weights of the following GEMMs, read by pf.wgs extra workgroups behind the attention grid (fluxmi_internal.h)
   int abl;  // A/B knobs (FLUXMI_ATTN_ABL, read per call): 2 = no barrier in the 8-wave kernel (timing only), 8 = fp8 output through 16 x 4 B
             // stores per lane (also taken when the output rows are not 16-byte aligned)
 };

@@ -164,3 +164,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
+
+// ---- weight prefetch (FluxmiPrefetch, fluxmi_internal.h): workgroup `wg` of `nwg` reads its contiguous share of every range, 16 B per
+// lane, eight loads in flight per lane, results discarded.  Default cache policy on purpose: the lines are to stay in the memory-side
+// cache (and may stay in this XCD's L2).
+template <class PF>
+__device__ __forceinline__ void fluxmi_prefetch_ranges(const PF& pf, int wg, int nwg, int tid, int nthreads) {
+  typedef int pf_v4i __attribute__((ext_vector_type(4)));
+  for (int r = 0; r < pf.n; ++r) {
+    const long long n16 = pf.bytes[r] >> 4;
+    const long long per = (n16 + nwg - 1) / nwg;
+    const long long lo = per * wg, hi = lo + per < n16 ? lo + per : n16;
+    const pf_v4i* base = (const pf_v4i*)pf.ptr[r];
+    for (long long i = lo + tid; i < hi; i += (long long)nthreads * 8) {
+      pf_v4i x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long j = i + (long long)u * nthreads;
+        x[u] = base[j < hi ? j : lo];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(x[u]));
+    }
+  }
+}

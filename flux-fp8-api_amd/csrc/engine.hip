@@ -113,6 +113,10 @@ int attn_f16k() {
   return t.attn_f16k && t.fuse_kv < 2;
 }
 
+// weight prefetch riding on launches with idle CUs (fluxmi_internal.h, FluxmiPrefetch): the fp8 weights of up to six linears, for the next
+// launch that supports it; `wgs` = the CUs that launch leaves idle in its last round
+void set_pf(fluxmi_engine* e, std::initializer_list<int> lins, int wgs);
+
 int lin_count(const fluxmi_model_desc_t& d) { return 6 + (d.guidance_embed ? 2 : 0) + d.depth * 10 + d.depth_single * 3 + 2; }
 
 // double-block linear slots / single-block linear slots
@@ -123,6 +127,23 @@ const fluxmi_linear_t& DL(E* e, int blk, int slot) { return e->lin[e->i_double0 
 const fluxmi_linear_t& SL(E* e, int blk, int slot) { return e->lin[e->i_single0 + blk * 3 + slot]; }
 int DLi(E* e, int blk, int slot) { return e->i_double0 + blk * 10 + slot; }
 int SLi(E* e, int blk, int slot) { return e->i_single0 + blk * 3 + slot; }
+
+void set_pf(fluxmi_engine* e, std::initializer_list<int> lins, int wgs) {
+  FluxmiPrefetch pf;
+  memset(&pf, 0, sizeof(pf));
+  if (fluxmi_tuning().prefetch && wgs > 0)
+    for (int li : lins) {
+      if (li < 0 || li >= (int)e->lin.size() || pf.n >= 6) continue;
+      const fluxmi_linear_t& l = e->lin[li];
+      if (!l.kind || !l.weight) continue;  // fp8 weights only (N * K bytes)
+      pf.ptr[pf.n] = l.weight;
+      pf.bytes[pf.n] = ((long long)l.N * l.K) & ~15LL;
+      ++pf.n;
+    }
+  pf.wgs = wgs;
+  fluxmi_set_prefetch(pf.n ? &pf : nullptr);
+}
+int idle_cus(long long wgs) { return (int)((256 - wgs % 256) % 256); }
 
 FluxmiGemmGroup mk_group(const fluxmi_linear_t& l, const void* A, long long lda, void* C, long long ldc, int M) {
   FluxmiGemmGroup g;
@@ -495,8 +516,14 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
         FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[2], ns[3], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, Lt, attn_f16k(), s));
       if (on(3)) {
         if (fused) {
+          // attention's last round leaves CUs idle (432 workgroups = 1.69 rounds at L = 4608): they pull in the weights this block needs
+          // next -- proj and mlp.0 (94 MB); fluxmi_tuning_t.prefetch = 2: mlp.2 as well (170 MB, as much as the idle CUs read in that time)
+          if (fluxmi_tuning().prefetch >= 2)
+            set_pf(e, {li_p[0], li_p[1], li_m0[0], li_m0[1], li_m2[0], li_m2[1]}, idle_cus((long long)B * heads * ((L + 255) / 256)));
+          else set_pf(e, {li_p[0], li_p[1], li_m0[0], li_m0[1]}, idle_cus((long long)B * heads * ((L + 255) / 256)));
           FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attn8, H, 0, 1, e->lin[li_p[0]].in_scale, e->lin[li_p[1]].in_scale, Lt, B, L, e->Lp,
                                         heads, e->lin[li_p[0]].in_fmt, s, qkv, 3 * H, pe, ns[2], ns[0], attn_f16k()));
+          fluxmi_set_prefetch(nullptr);
         } else {
           FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attnbf, H, 0, 0, nullptr, nullptr, Lt, B, L, e->Lp, heads, 0, s, qkv, 3 * H, pe,
                                         ns[2], ns[0], attn_f16k()));
@@ -548,7 +575,13 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
             g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 5 * H;
             gs.push_back(g);
           }
+        if (fused) {  // the 216-tile launch leaves 40 CUs idle: they pull in the first weights of the NEXT block
+          const long long tiles = (long long)B * (((Lt + 255) / 256) + ((Li + 255) / 256)) * (H / 256);
+          if (i + 1 < e->d.depth) set_pf(e, {DLi(e, i + 1, D_TXT_QKV), DLi(e, i + 1, D_IMG_QKV)}, idle_cus(tiles));
+          else set_pf(e, {SLi(e, 0, S_LIN1)}, idle_cus(tiles));
+        }
         FLUXMI_TRY(run_gemm(gs, H, Hm, e->lin[li_m2[0]].kind, e->lin[li_m2[0]].in_fmt, FLUXMI_EPI_GATE_RESID, s));
+        fluxmi_set_prefetch(nullptr);
       }
     }
   }
@@ -594,9 +627,12 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
     }
     if (on(2) && !fuse_k)
       FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, L, attn_f16k(), s));
-    if (on(3))
+    if (on(3)) {
+      set_pf(e, {l2}, idle_cus((long long)B * heads * ((L + 255) / 256)));  // attention's idle CUs pull in linear2's weights
       FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s, qkv,
                                     3 * H, pe, ns[0], ns[0], attn_f16k()));
+      fluxmi_set_prefetch(nullptr);
+    }
   } else {
     if (on(0)) {
       FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, ms, ms + H, ms, ms + H, MC, nullptr, nullptr, B, L, L, H, 0, 0, s));
@@ -623,7 +659,13 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
       g.resid = x + r0 * H; g.ldr = H; g.gate = ms + (long long)b * MC + 2 * H;
       gs.push_back(g);
     }
+    if (fused) {  // linear2's 216 tiles leave 40 CUs idle: they pull in the next block's linear1 (after the last block: the next step's first qkv)
+      const long long tiles = (long long)B * ((L + 255) / 256) * (H / 256);
+      if (i + 1 < e->d.depth_single) set_pf(e, {SLi(e, i + 1, S_LIN1)}, idle_cus(tiles));
+      else set_pf(e, {DLi(e, 0, D_TXT_QKV), DLi(e, 0, D_IMG_QKV)}, idle_cus(tiles));
+    }
     FLUXMI_TRY(run_gemm(gs, H, HC, L2.kind, L2.in_fmt, FLUXMI_EPI_GATE_RESID, s));
+    fluxmi_set_prefetch(nullptr);
   }
   return 0;
 }

@@ -6,6 +6,23 @@
 
 typedef fluxmi_gemm_group_t FluxmiGemmGroup;
 
+// ---- weight prefetch riding on another launch -------------------------------------------------------------------------------------
+// Inside the denoise step every F8Linear weight is read ONCE per step: 11.9 GB stream through the 256 MB Infinity Cache, so a GEMM's
+// first tiles find their W panels in HBM and run their K loops ~20 % longer than the later tiles, whose panels another XCD has
+// already pulled on chip (profiles/r04_gemm_persist.txt: in-step timeline 78 K -> 60 K cycles per tile; the back-to-back probe never
+// shows it).  Launches that leave CUs idle -- attention's 432 workgroups = 1.69 rounds of the 256 CUs, the 216-tile GEMMs -- therefore
+// carry a few EXTRA workgroups behind their own that do nothing but read the weights of the launches that follow (16 B per lane,
+// results discarded): the lines land in the memory-side cache, where every XCD finds them.  Purely a hint: no output depends on it.
+struct FluxmiPrefetch {
+  const void* ptr[6];
+  long long bytes[6];  // multiples of 16
+  int n;               // ranges in use
+  int wgs;             // extra workgroups the launch appends for it (0 = off)
+};
+// engine -> next launch that supports it (attention, the 256x256 one-tile-per-workgroup GEMMs); consumed by that launch.  Thread-local.
+void fluxmi_set_prefetch(const FluxmiPrefetch* pf);
+FluxmiPrefetch fluxmi_take_prefetch();
+
 #define FLUXMI_MAX_GROUPS 16
 struct FluxmiGemmParams {
   FluxmiGemmGroup g[FLUXMI_MAX_GROUPS];
@@ -15,6 +32,7 @@ struct FluxmiGemmParams {
   int split_k;
   float* partial;
   unsigned long long* dbg;  // per-tile timestamps of the persistent kernel's timing build (tile config 19), else null
+  FluxmiPrefetch pf;        // weights of later launches, read by pf.wgs extra workgroups behind the tiles (see FluxmiPrefetch)
 };
 
 // ---- batched skinny GEMV (modulations + embedders, M = batch <= 8) ----------------------------

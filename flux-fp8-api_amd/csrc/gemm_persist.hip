@@ -7,13 +7,17 @@
 //  * the drain: the epilogue's stores have to reach L2 before the CU takes the next workgroup.
 // Here the LDS ring never drains: the refill slots of a tile's last three K-steps take the FIRST three K-steps of the workgroup's next
 // tile, so when the epilogue ends the next tile's operands are already in LDS, and the epilogue's stores retire under the next K loop.
-// That needs the ring to stay untouched by the epilogue: the bf16 transposition goes through a 4 KiB per-wave scratch beside the ring
-// (160 KiB of LDS = 4 x 32 KiB ring + 8 x 4 KiB), one 32-row block of the wave's 128 x 64 tile at a time.  The table-driven
-// GELU -> fp8 epilogue (64 KiB table, gemm_epilogue.h) borrows ring slots 2 and 3 -- a table tile therefore prefetches only two K-steps
-// of its successor and issues the third right after its table reads.
+// That needs most of the ring to stay untouched by the epilogue: the bf16 transposition goes through 4 KiB per wave of the ONE slot that
+// is dead when the K loop ends (the last step's), one 32-row block of the wave's 128 x 64 tile at a time.  The table-driven
+// GELU -> fp8 epilogue (64 KiB table, gemm_epilogue.h) needs two more slots -- a table tile therefore prefetches only two K-steps of its
+// successor and issues the third and fourth right after its table reads.
 //
-// K loop = gemm_pp.hip's (4-slot ring of 64-byte K-steps filled three steps ahead by `buffer_load ... lds`, ONE raw s_barrier per step,
-// counted vmcnt, the two waves of a SIMD in opposite phase), unrolled by four so that ring slots are immediates (K bytes % 256 == 0).
+// K loop = gemm_pp.hip's (ring of 64-byte K-steps filled by `buffer_load ... lds`, ONE raw s_barrier per step, counted vmcnt, the two
+// waves of a SIMD in opposite phase) with two changes.  (1) FIVE slots, filled FOUR steps ahead -- all 160 KiB of LDS: the loop is bound
+// by the round trip of its LDS-DMA, not by the matrix pipes (with 3 steps in flight a step takes 0.77 us, with 2 steps 0.91 us, the MFMAs
+// of a step 0.59 us at the clock the chip holds: profiles/r04_gemm_persist.txt; Little's law puts the loaded L2 / Infinity-Cache round
+// trip at ~1.8 us).  Ring slots are run-time values (48 K-steps per tile do not divide by five).  (2) The refill pieces and group 0's
+// next fragments are interleaved with the MFMAs instead of following them as a block.
 // vmcnt protocol across tiles: every path of the epilogue converts its accumulators (VALU only), then waits vmcnt(0) ONCE -- as the
 // builtin, so that hipcc's own wait-count pass knows it: with LDS-DMA pending in its model it puts vmcnt(0) in front of every scratch
 // access it cannot prove disjoint, i.e. drains the epilogue's stores block by block -- and only then touches LDS and stores.  The
@@ -138,8 +142,8 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
   if constexpr (EPI == FLUXMI_EPI_GELU_QUANT || EPI == FLUXMI_EPI_SPLIT) {
     if (lut) {
       // ---- quantising path: fp8 = quantise(gelu(bf16(acc * s + bias))) -------------------------------------------------------------
-      // The 64 KiB table (gemm_epilogue.h) sits in ring slots 2 and 3; its LDS-DMA was issued inside the last K-step (kernel: behind a
-      // barrier in the middle of that step, when both slots were dead), so it lands under the step's last MFMAs and the conversion.
+      // The 64 KiB table (gemm_epilogue.h) sits in two adjacent dead ring slots; its LDS-DMA was issued inside the last K-step (kernel:
+      // behind the barrier in the middle of that step, when the slots were dead), so it lands under the step's last MFMAs and the conversion.
       // The byte gather runs at the speed of its LDS bank conflicts (64 random addresses per ds_read_u8: ~10 K cycles per tile for the
       // 1024 gather instructions of the eight waves); quantising half of the blocks on the VALU instead, the two waves of a SIMD in
       // opposite order, was measured SLOWER (the exact GELU chain costs ~14 VALU instructions per element, two of them
@@ -306,13 +310,17 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
   }
 }
 
-template <int V> using ic = std::integral_constant<int, V>;
+// compile-time switches of a K-step
+struct PsNone {}; struct PsCur {}; struct PsNxt {};   // what the step's refill takes: nothing / a K-step of this tile / of the next tile
 
 template <bool FP8, int ACT_FMT, int ESEL, bool TIMING>
 __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams P) {
-  constexpr int NT = 512, TM = 4, TN = 2, STAGE = 32768, A_BYTES = 16384, LPT = 4, RING = 4 * STAGE;
+  constexpr int NT = 512, TM = 4, TN = 2, STAGE = 32768, A_BYTES = 16384, LPT = 4, NS = 5, D = 4;
   constexpr int EB = FP8 ? 1 : 2;
+  constexpr bool MAY_LUT = ESEL == FLUXMI_EPI_GELU_QUANT || ESEL == FLUXMI_EPI_SPLIT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using T = std::true_type;
+  using F = std::false_type;
 
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -328,6 +336,8 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
   const int nk = (P.K * EB) / 64;
   const unsigned a_row_b = (unsigned)(P.g[0].lda * EB), w_row_b = (unsigned)(P.K * EB);  // one lda for every group (host check)
 
+  // ring slot arithmetic (slots 0 .. NS-1; d <= NS)
+  auto nslot = [](int sl, int d) { const int t = sl + d; return t >= NS ? t - NS : t; };
   // per-lane LDS-DMA source offsets of the lane's two A and two W pieces of a K-step (XOR swizzle on the source side)
   auto lane_voffs = [&](int tid, unsigned (&a_voff)[2], unsigned (&w_voff)[2]) {
 #pragma unroll
@@ -350,7 +360,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
     unsigned a_voff[2], w_voff[2];
     lane_voffs(threadIdx.x, a_voff, w_voff);
 #pragma unroll
-    for (int st = 0; st < 3; ++st) {
+    for (int st = 0; st < D; ++st) {
       unsigned char* dA = smem + st * STAGE + wave * 1024;
 #pragma unroll
       for (int i = 0; i < 2; ++i) dma16_buf(c_ars, dA + NT * 16 * i, a_voff[i], c_asoff + st * 64);
@@ -361,6 +371,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
+  int slot0 = 0;  // ring slot of the current tile's K-step 0
   for (int jt = 0;; ++jt) {
     unsigned long long t_start = 0, t_kend = 0;
     if constexpr (TIMING) t_start = ps_clock();
@@ -373,9 +384,15 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       n_ars = c_ars; n_wrs = c_wrs; n_asoff = c_asoff; n_wsoff = c_wsoff; n_gi = c_gi; n_m0 = c_m0; n_n0 = c_n0;
     }
     const FluxmiGemmGroup& G = P.g[c_gi];
+    // slots of the tile's last three K-steps: dead when the K loop ends.  A plain tile keeps its successor's first FOUR K-steps in the
+    // other four slots and transposes through the slot of step nk - 1; a table tile keeps TWO, puts the 64 KiB table into two adjacent
+    // dead slots and transposes through the third.
+    const int s_m3 = nslot(slot0, (nk - 3) % NS), s_m1 = nslot(s_m3, 2);
+    const int tbl_slot = s_m3 == NS - 1 ? 0 : s_m3, lut_scratch = s_m3 == NS - 1 ? NS - 1 : s_m1;
+
     // K loop + epilogue of one tile, compiled ONCE PER KIND of tile (table tile or not): as a run-time flag inside one body the table
-    // tile's extra barrier / table DMA in the last K-step made hipcc spill ~230 VGPRs -- with reloads inside the K loop, each a VMEM
-    // operation that drains vmcnt (linear1: 268 -> 414 us)
+    // tile's extra work in the last K-step made hipcc spill ~230 VGPRs -- with reloads inside the K loop, each a VMEM operation that
+    // drains vmcnt (linear1: 268 -> 414 us)
     auto tile_body = [&](auto LUT_TILE) {
     constexpr bool lut_tile = decltype(LUT_TILE)::value;
 
@@ -395,171 +412,161 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       w_lo = A_BYTES + rw * 64 + (((hi * 2) ^ kw) << 4);
       w_hi = A_BYTES + rw * 64 + (((hi * 2 + 1) ^ kw) << 4);
     }
-    auto dma_stage = [&](__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t wrs, unsigned asoff, unsigned wsoff, int kt, auto SLOT) {
-      constexpr int S = decltype(SLOT)::value;
-      unsigned char* dA = smem + S * STAGE + wave * 1024;
+    // piece q of a K-step's refill into ring slot sl: 0, 1 = the lane's two A pieces, 2, 3 = its two W pieces
+    auto dma_piece = [&](__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t wrs, unsigned asoff, unsigned wsoff, int kt, int sl, int q) {
+      unsigned char* dA = smem + sl * STAGE + wave * 1024;
+      if (q < 2) dma16_buf(ars, dA + NT * 16 * q, a_voff[q], asoff + kt * 64);
+      else dma16_buf(wrs, dA + A_BYTES + NT * 16 * (q - 2), w_voff[q - 2], wsoff + kt * 64);
+    };
+    auto dma_stage = [&](__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t wrs, unsigned asoff, unsigned wsoff, int kt, int sl) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) dma16_buf(ars, dA + NT * 16 * i, a_voff[i], asoff + kt * 64);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) dma16_buf(wrs, dA + A_BYTES + NT * 16 * i, w_voff[i], wsoff + kt * 64);
+      for (int q = 0; q < 4; ++q) dma_piece(ars, wrs, asoff, wsoff, kt, sl, q);
     };
     v8i fa[TM], fw[TN];
-    auto read_frags = [&](auto SLOT) {
-      constexpr int S = decltype(SLOT)::value;
-      const unsigned char* sb = smem + S * STAGE;
+    auto read_fa = [&](int sl, int i) {
+      const unsigned char* sb = smem + sl * STAGE;
+      const v4i lo = *(const v4i*)(sb + i * 2048 + a_lo), h4 = *(const v4i*)(sb + i * 2048 + a_hi);
+      fa[i] = (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
+    };
+    auto read_fw = [&](int sl, int j) {
+      const unsigned char* sb = smem + sl * STAGE;
+      const v4i lo = *(const v4i*)(sb + j * 2048 + w_lo), h4 = *(const v4i*)(sb + j * 2048 + w_hi);
+      fw[j] = (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
+    };
+    auto read_frags = [&](int sl) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const v4i lo = *(const v4i*)(sb + j * 2048 + w_lo), h4 = *(const v4i*)(sb + j * 2048 + w_hi);
-        fw[j] = (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
-      }
+      for (int j = 0; j < TN; ++j) read_fw(sl, j);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const v4i lo = *(const v4i*)(sb + i * 2048 + a_lo), h4 = *(const v4i*)(sb + i * 2048 + a_hi);
-        fa[i] = (v8i){lo[0], lo[1], lo[2], lo[3], h4[0], h4[1], h4[2], h4[3]};
-      }
+      for (int i = 0; i < TM; ++i) read_fa(sl, i);
     };
     v16f acc[TM][TN];
-    auto mma_all = [&](auto ZERO) {
+    auto mma_row = [&](auto ZERO, int i) {  // the two MFMAs that take activation fragment i
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) {
+        v16f c0;
+        if constexpr (decltype(ZERO)::value) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          v16f c0;
-          if constexpr (decltype(ZERO)::value) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c0[r] = 0.f;
-          } else {
-            c0 = acc[i][j];
-          }
-          if constexpr (FP8) {
-            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[j], fa[i], c0, FLUXMI_FMT_E4M3, ACT_FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-          } else {
-            const v4i alo = (v4i){fa[i][0], fa[i][1], fa[i][2], fa[i][3]}, ahi = (v4i){fa[i][4], fa[i][5], fa[i][6], fa[i][7]};
-            const v4i wlo = (v4i){fw[j][0], fw[j][1], fw[j][2], fw[j][3]}, whi = (v4i){fw[j][4], fw[j][5], fw[j][6], fw[j][7]};
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, wlo), __builtin_bit_cast(v8bf, alo), c0, 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, whi), __builtin_bit_cast(v8bf, ahi), c0, 0, 0, 0);
-          }
+          for (int r = 0; r < 16; ++r) c0[r] = 0.f;
+        } else {
+          c0 = acc[i][j];
         }
+        if constexpr (FP8) {
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[j], fa[i], c0, FLUXMI_FMT_E4M3, ACT_FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        } else {
+          const v4i alo = (v4i){fa[i][0], fa[i][1], fa[i][2], fa[i][3]}, ahi = (v4i){fa[i][4], fa[i][5], fa[i][6], fa[i][7]};
+          const v4i wlo = (v4i){fw[j][0], fw[j][1], fw[j][2], fw[j][3]}, whi = (v4i){fw[j][4], fw[j][5], fw[j][6], fw[j][7]};
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, wlo), __builtin_bit_cast(v8bf, alo), c0, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, whi), __builtin_bit_cast(v8bf, ahi), c0, 0, 0, 0);
+        }
+      }
     };
-    // one K-step in ring slot S; the refill (slot S + 3) takes K-step `kt_src` of the current (NXT = 0) or the next (NXT = 1) tile,
-    // DMA = 0: no refill.  WAIT: 1 = counted wait, 0 = none.
-    // Group 0: barrier | 8 MFMA | refill | fragments of the next step;  group 1: barrier | fragments | refill | 8 MFMA.
-    auto refill = [&](auto SLOT, auto NXT, int kt_src) {
-      if constexpr (decltype(NXT)::value) dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, kt_src, SLOT);
-      else dma_stage(c_ars, c_wrs, c_asoff, c_wsoff, kt_src, SLOT);
-    };
-    // table tiles, last K-step only: once group 1 holds its fragments of that step (group 0 took them a step earlier) ring slots 2 and 3
-    // are dead -- one extra barrier there, then the 64 pieces of the table are issued under the step's remaining MFMAs
-    // (through a descriptor: one VGPR of per-lane offset instead of eight 64-bit addresses at the point of highest register pressure)
+    // table tiles: the 64 pieces of the table into the two dead slots (through a descriptor: one VGPR of per-lane offset instead of eight
+    // 64-bit addresses at the point of highest register pressure)
     auto table_dma = [&]() {
       const __amdgpu_buffer_rsrc_t trs = make_rsrc(G.q_lut, 65536u);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int piece = wave * 8 + q;
-        dma16_buf(trs, smem + 2 * STAGE + piece * 1024, (unsigned)lane * 16, (unsigned)piece * 1024);
+        dma16_buf(trs, smem + tbl_slot * STAGE + piece * 1024, (unsigned)lane * 16, (unsigned)piece * 1024);
       }
     };
-    constexpr bool MAY_LUT = ESEL == FLUXMI_EPI_GELU_QUANT || ESEL == FLUXMI_EPI_SPLIT;
-    auto step_g0 = [&](auto SLOT, auto WAIT, auto ZERO, auto READ_NEXT, auto DMA, auto NXT, int kt_src) {
-      constexpr int S = decltype(SLOT)::value, W = decltype(WAIT)::value;
-      if constexpr (W == 1) wait_vmcnt<LPT>();
-      __builtin_amdgcn_s_barrier();
-      fence();
-      mma_all(ZERO);
-      fence();
-      if constexpr (MAY_LUT && !decltype(READ_NEXT)::value) {  // (READ_NEXT = false marks the last step of a tile)
-        if constexpr (lut_tile) {
-          __builtin_amdgcn_s_barrier();
-          table_dma();
-        }
-      }
-      if constexpr (decltype(DMA)::value) refill(ic<(S + 3) & 3>{}, NXT, kt_src);
-      fence();
-      if constexpr (decltype(READ_NEXT)::value) read_frags(ic<(S + 1) & 3>{});
-      fence();
+    auto refill_piece = [&](auto SRC, int kt_src, int sl, int q) {
+      if constexpr (std::is_same<decltype(SRC), PsNxt>::value) dma_piece(n_ars, n_wrs, n_asoff, n_wsoff, kt_src, sl, q);
+      if constexpr (std::is_same<decltype(SRC), PsCur>::value) dma_piece(c_ars, c_wrs, c_asoff, c_wsoff, kt_src, sl, q);
     };
-    auto step_g1 = [&](auto SLOT, auto WAIT, auto ZERO, auto DMA, auto NXT, int kt_src, auto LAST) {
-      constexpr int S = decltype(SLOT)::value, W = decltype(WAIT)::value;
-      if constexpr (W == 1) wait_vmcnt<LPT>();
+    // One K-step in ring slot sl.  Behind the two MFMAs of activation fragment p: one piece of the refill of slot sl + 4 (K-step kt_src
+    // of the current / the next tile) and, group 0, the reads of fragment p of the NEXT step (its registers are free: both MFMAs that
+    // take it are issued) -- an LDS-DMA piece issues in ~60 cycles in the shadow of an MFMA and in 100 - 185 behind the block.
+    // WAIT: counted wait for this wave's pieces of the NEXT step (two younger steps may stay in flight).  LAST (last step of a tile):
+    // group 0 skips the next fragments; both groups meet at one more barrier once every fragment of the step is in registers, after
+    // which the slots of the tile's last three steps are dead (epilogue scratch, table).
+    // Group 0: barrier | 8 MFMA + refill + next fragments;  group 1: barrier | fragments | 8 MFMA + refill.
+    auto step_g0 = [&](auto ZERO, auto WAIT, auto SRC, auto LAST, int kt_src, int sl) {
+      if constexpr (decltype(WAIT)::value) wait_vmcnt<LPT * (D - 2)>();
       __builtin_amdgcn_s_barrier();
       fence();
-      read_frags(SLOT);
-      fence();
-      if constexpr (decltype(DMA)::value) refill(ic<(S + 3) & 3>{}, NXT, kt_src);
-      fence();
-      if constexpr (MAY_LUT && decltype(LAST)::value) {
-        if constexpr (lut_tile) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments of the last K-step are in registers
-          __builtin_amdgcn_s_barrier();
-        }
+      const int rs = nslot(sl, D), ns = nslot(sl, 1);
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        mma_row(ZERO, pp);
+        fence();
+        refill_piece(SRC, kt_src, rs, pp);
+        if constexpr (!decltype(LAST)::value) read_fa(ns, pp);
+        fence();
       }
-      mma_all(ZERO);
-      fence();
-      if constexpr (MAY_LUT && decltype(LAST)::value) {
+      if constexpr (!decltype(LAST)::value) {
+        read_fw(ns, 0);
+        read_fw(ns, 1);
+      } else {
+        __builtin_amdgcn_s_barrier();
         if constexpr (lut_tile) table_dma();
       }
+      fence();
     };
-    using T = std::true_type;
-    using F = std::false_type;
-    // the successor's third K-step goes into slot 2 (last read before barrier nk - 1): inside the last step where the epilogue never takes
-    // the table, behind the K loop for the non-table tiles of the split epilogue, after the table reads otherwise
-    using LASTDMA = std::integral_constant<bool, ESEL == FLUXMI_EPI_BF16 || ESEL == FLUXMI_EPI_GATE_RESID>;
-    // steps 0 and 1 of a tile: their operands landed before the epilogue's vmcnt(0) (the first tile: before the prologue's), and all
-    // that is in flight are the epilogue's stores -- no wait, they retire under the K loop.  A table tile issues its successor's third
-    // K-step AFTER that vmcnt(0): there step 1 keeps the counted wait.
-    using W1 = ic<(ESEL == FLUXMI_EPI_BF16 || ESEL == FLUXMI_EPI_GATE_RESID) ? 0 : 1>;
+    auto step_g1 = [&](auto ZERO, auto WAIT, auto SRC, auto LAST, int kt_src, int sl) {
+      if constexpr (decltype(WAIT)::value) wait_vmcnt<LPT * (D - 2)>();
+      __builtin_amdgcn_s_barrier();
+      fence();
+      read_frags(sl);
+      fence();
+      if constexpr (decltype(LAST)::value) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments of the last K-step are in registers
+        __builtin_amdgcn_s_barrier();
+      }
+      const int rs = nslot(sl, D);
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        mma_row(ZERO, pp);
+        fence();
+        refill_piece(SRC, kt_src, rs, pp);
+        fence();
+      }
+      if constexpr (decltype(LAST)::value && lut_tile) table_dma();
+    };
+    // steps 0 .. 2 of a tile: their operands landed before the epilogue's vmcnt(0) (the first tile: before the prologue's), and all that
+    // is in flight are the epilogue's stores -- no wait, they retire under the K loop.  A table tile issues its successor's third and
+    // fourth K-step AFTER that vmcnt(0): where a predecessor may have been one, steps 1 and 2 keep the counted wait.
+    using WE = std::integral_constant<bool, MAY_LUT>;
+    using SRC23 = typename std::conditional<lut_tile, PsNone, PsNxt>::type;
     uint2 braw[2][4];
+    int sl = slot0;
+    auto run = [&](auto step) {
+      step(T{}, F{}, PsCur{}, F{}, D, sl); sl = nslot(sl, 1);
+      step(F{}, WE{}, PsCur{}, F{}, D + 1, sl); sl = nslot(sl, 1);
+      step(F{}, WE{}, PsCur{}, F{}, D + 2, sl); sl = nslot(sl, 1);
+      for (int kt = 3; kt < nk - 4; ++kt) {
+        step(F{}, T{}, PsCur{}, F{}, kt + D, sl);
+        sl = nslot(sl, 1);
+      }
+      ps_load_bias(G, c_n0 + wn * 64, hi, braw);
+      step(F{}, T{}, PsNxt{}, F{}, 0, sl); sl = nslot(sl, 1);
+      step(F{}, T{}, PsNxt{}, F{}, 1, sl); sl = nslot(sl, 1);
+      step(F{}, T{}, SRC23{}, F{}, 2, sl); sl = nslot(sl, 1);
+      step(F{}, T{}, SRC23{}, T{}, 3, sl);
+    };
     if (wm == 0) {
-      read_frags(ic<0>{});
-      step_g0(ic<0>{}, ic<0>{}, T{}, T{}, T{}, F{}, 3);
-      step_g0(ic<1>{}, W1{}, F{}, T{}, T{}, F{}, 4);
-      step_g0(ic<2>{}, ic<1>{}, F{}, T{}, T{}, F{}, 5);
-      step_g0(ic<3>{}, ic<1>{}, F{}, T{}, T{}, F{}, 6);
-      for (int kt = 4; kt < nk - 4; kt += 4) {
-        step_g0(ic<0>{}, ic<1>{}, F{}, T{}, T{}, F{}, kt + 3);
-        step_g0(ic<1>{}, ic<1>{}, F{}, T{}, T{}, F{}, kt + 4);
-        step_g0(ic<2>{}, ic<1>{}, F{}, T{}, T{}, F{}, kt + 5);
-        step_g0(ic<3>{}, ic<1>{}, F{}, T{}, T{}, F{}, kt + 6);
-      }
-      ps_load_bias(G, c_n0 + wn * 64, hi, braw);
-      step_g0(ic<0>{}, ic<1>{}, F{}, T{}, T{}, F{}, nk - 1);
-      step_g0(ic<1>{}, ic<1>{}, F{}, T{}, T{}, T{}, 0);
-      step_g0(ic<2>{}, ic<1>{}, F{}, T{}, T{}, T{}, 1);
-      step_g0(ic<3>{}, ic<1>{}, F{}, F{}, LASTDMA{}, T{}, 2);
+      read_frags(sl);
+      run(step_g0);
     } else {
-      step_g1(ic<0>{}, ic<0>{}, T{}, T{}, F{}, 3, F{});
-      step_g1(ic<1>{}, W1{}, F{}, T{}, F{}, 4, F{});
-      step_g1(ic<2>{}, ic<1>{}, F{}, T{}, F{}, 5, F{});
-      step_g1(ic<3>{}, ic<1>{}, F{}, T{}, F{}, 6, F{});
-      for (int kt = 4; kt < nk - 4; kt += 4) {
-        step_g1(ic<0>{}, ic<1>{}, F{}, T{}, F{}, kt + 3, F{});
-        step_g1(ic<1>{}, ic<1>{}, F{}, T{}, F{}, kt + 4, F{});
-        step_g1(ic<2>{}, ic<1>{}, F{}, T{}, F{}, kt + 5, F{});
-        step_g1(ic<3>{}, ic<1>{}, F{}, T{}, F{}, kt + 6, F{});
-      }
-      ps_load_bias(G, c_n0 + wn * 64, hi, braw);
-      step_g1(ic<0>{}, ic<1>{}, F{}, T{}, F{}, nk - 1, F{});
-      step_g1(ic<1>{}, ic<1>{}, F{}, T{}, T{}, 0, F{});
-      step_g1(ic<2>{}, ic<1>{}, F{}, T{}, T{}, 1, F{});
-      step_g1(ic<3>{}, ic<1>{}, F{}, LASTDMA{}, T{}, 2, T{});
-    }
-    if constexpr (ESEL == FLUXMI_EPI_SPLIT) {
-      if constexpr (!lut_tile) dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, ic<2>{});
+      run(step_g1);
     }
     if constexpr (TIMING) t_kend = ps_clock();
 
-    // ---- epilogue (the ring is not touched, except by the table path) ----------------------------------------------------------
+    // ---- epilogue (through the dead slot(s) of the ring) -------------------------------------------------------------------------
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const float s = load_scale_u(G.sa_recip) * load_scale_u(G.sb_recip);
     const int M = (int)uni_u32((unsigned)G.M);
-    unsigned char* wbuf = smem + RING + wave * 4096;
+    unsigned char* wbuf = smem + (lut_tile ? lut_scratch : s_m1) * STAGE + wave * 4096;
     unsigned long long* stamps = nullptr;
     if constexpr (TIMING) {
       if (threadIdx.x == 0 && P.dbg) stamps = P.dbg + ((size_t)blockIdx.x * 8 + (jt < 8 ? jt : 7)) * 8 + 4;
     }
-    ps_epilogue<ESEL, ACT_FMT>(G, acc, braw, s, wbuf, smem + 2 * STAGE, c_m0 + wm * 128, c_n0 + wn * 64, M, lane_e, wave, lut_tile,
-                               [&]() { dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, ic<2>{}); }, stamps);
+    ps_epilogue<ESEL, ACT_FMT>(G, acc, braw, s, wbuf, smem + tbl_slot * STAGE, c_m0 + wm * 128, c_n0 + wn * 64, M, lane_e, wave, lut_tile,
+                               [&]() {  // table tiles: the successor's third and fourth K-step, into the slots the table vacates
+                                 dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, s_m3);
+                                 dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 3, nslot(s_m3, 1));
+                               }, stamps);
     if constexpr (TIMING) {
       if (threadIdx.x == 0 && P.dbg) {
         unsigned long long* d = P.dbg + ((size_t)blockIdx.x * 8 + (jt < 8 ? jt : 7)) * 8;
@@ -575,6 +582,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       tile_body(std::false_type{});
     }
     if (!has_next) break;
+    slot0 = nslot(slot0, nk % NS);
     c_ars = n_ars; c_wrs = n_wrs; c_asoff = n_asoff; c_wsoff = n_wsoff; c_gi = n_gi; c_m0 = n_m0; c_n0 = n_n0;
   }
   wait_vmcnt<0>();  // the trailing refills must land before the wave ends
@@ -590,7 +598,7 @@ int launch_ps(FluxmiGemmParams& p, hipStream_t s) {
   }
   p.tiles_m_total = t;
   p.group_m = 8;
-  constexpr int SMEM = 4 * (BM + BN) * 64 + 8 * 4096;  // ring + per-wave epilogue scratch = all 160 KiB
+  constexpr int SMEM = 5 * (BM + BN) * 64;  // five ring slots = all 160 KiB (the epilogue borrows the dead ones)
   auto kern = gemm_ps_kernel<FP8, ACT, ESEL, TIMING>;
   static bool attr_set = false;
   if (!attr_set) {

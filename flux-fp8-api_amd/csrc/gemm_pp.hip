@@ -11,6 +11,7 @@
 // LDS rows are 64 B (4 x 16 B slots); bank-conflict-free ds_read_b128 needs slot ^= (row >> 2) & 3, applied on the DMA source address
 // and on the read address.  (Rounds 1-2 also carried a lock-step ring kernel in five tile shapes, a two-workgroups-per-CU variant and
 // timing-only ablations of it: measured slower everywhere -- profiles/r01_gemm_ablation*.txt, r02_gemm_ab.txt -- and removed in round 3.)
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -51,6 +52,12 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
 
   const int tiles_n = P.N / BN;
   const int nblk = P.tiles_m_total * tiles_n;
+  if constexpr (!SPLITK) {
+    if ((int)blockIdx.x >= nblk) {  // extra workgroups behind the tiles: weight prefetch for the launches that follow (FluxmiPrefetch)
+      fluxmi_prefetch_ranges(P.pf, (int)blockIdx.x - nblk, (int)gridDim.x - nblk, tid, NT);
+      return;
+    }
+  }
   const int split = SPLITK ? (int)blockIdx.x / nblk : 0;
   const int lid = xcd_remap(SPLITK ? (int)blockIdx.x % nblk : (int)blockIdx.x, nblk);
   const int width = P.group_m * tiles_n;
@@ -275,7 +282,10 @@ int launch_pp(FluxmiGemmParams& p, hipStream_t s) {
   }
   const int nblk = t * (p.N / BN);
   if (nblk == 0) return 0;
-  hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), SMEM, s, p);
+  const int idle = (256 - nblk % 256) % 256;
+  const int extra = p.pf.n > 0 ? std::min(p.pf.wgs, idle) : 0;
+  if (!extra) p.pf.n = 0;
+  hipLaunchKernelGGL(kern, dim3(nblk + extra), dim3(512), SMEM, s, p);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }
@@ -366,6 +376,7 @@ int launch_pp_splitk(FluxmiGemmParams& p, int split_k, hipStream_t s) {
   FLUXMI_TRY(splitk_workspace(s, &ws));
   p.split_k = split_k;
   p.partial = ws;
+  p.pf.n = 0;
   constexpr int SMEM = 4 * (BM + BN) * 64 + 8 * 128 * 4;
   auto kern = gemm_pp_kernel<FP8, ACT, 2, -1, true>;
   static bool attr_set = false;
@@ -411,6 +422,8 @@ int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int 
 
 // config 13 = 256x256 ping-pong ring (8 waves)
 int fluxmi_launch_gemm_pp(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s) {
+  p.pf = fluxmi_take_prefetch();
+  if (!fluxmi_tuning().prefetch) p.pf.n = 0;
   FLUXMI_REQUIRE(cfg == 13, "gemm_pp: unknown tile config %d", cfg);
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) return launch_pp_cfg<true, FLUXMI_FMT_E5M2>(p, s);

@@ -17,6 +17,8 @@
 // Requires K*bytes % 256 == 0 (four K-steps per unrolled iteration).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "gemm_epilogue.h"
 
 namespace {
@@ -41,6 +43,10 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
 
   const int tiles_n = P.N / BN;
   const int nblk = P.tiles_m_total * tiles_n;
+  if ((int)blockIdx.x >= nblk) {  // extra workgroups behind the tiles: weight prefetch for the launches that follow (FluxmiPrefetch)
+    fluxmi_prefetch_ranges(P.pf, (int)blockIdx.x - nblk, (int)gridDim.x - nblk, tid, NT);
+    return;
+  }
   const int lid = xcd_remap(blockIdx.x, nblk);
   const int width = P.group_m * tiles_n;
   const int first_m = (lid / width) * P.group_m;
@@ -201,7 +207,11 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
   }
   const int nblk = t * (p.N / BN);
   if (nblk == 0) return 0;
-  hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), SMEM, s, p);
+  // a launch that leaves CUs idle in its last round carries the pending weight prefetch on them (fluxmi_internal.h, FluxmiPrefetch)
+  const int idle = (256 - nblk % 256) % 256;
+  const int extra = p.pf.n > 0 ? std::min(p.pf.wgs, idle) : 0;
+  if (!extra) p.pf.n = 0;
+  hipLaunchKernelGGL(kern, dim3(nblk + extra), dim3(256), SMEM, s, p);
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }
@@ -210,6 +220,8 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
 
 // config 16 = 256x256, one wave per SIMD
 int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {
+  p.pf = fluxmi_take_prefetch();
+  if (!fluxmi_tuning().prefetch) p.pf.n = 0;
   // buffer descriptors address 4 GiB per operand
   for (int i = 0; i < p.n_groups; ++i)
     FLUXMI_REQUIRE((long long)p.g[i].M * p.g[i].lda * (is_fp8 ? 1 : 2) < (1LL << 32) && (long long)p.N * p.K * (is_fp8 ? 1 : 2) < (1LL << 32),

@@ -100,7 +100,7 @@ typedef struct fluxmi_tuning {
   int gemm_splitk;       /* FLUXMI_GEMM_SPLITK   1: small-M bf16 launches split K over several workgroups per tile */
   int gemm_hybrid;       /* FLUXMI_GEMM_HYBRID   1: peel the thin groups of a grouped launch into a 128x128 launch */
   int gemm_esel;         /* FLUXMI_GEMM_ESEL     1: one kernel instantiation per hot epilogue (0 = run-time switch, A/B) */
-  int gemm_persist;      /* FLUXMI_GEMM_PERSIST  1: multi-round fp8 launches on the persistent kernel (tile config 18) */
+  int gemm_persist;      /* FLUXMI_GEMM_PERSIST  1: multi-round fp8 launches on the persistent kernel (tile config 18); 2 = its timing build (probes) */
   int attn_var;          /* FLUXMI_ATTN_VAR      bit 1: exact instead of deferred running max */
   int attn_abl;          /* FLUXMI_ATTN_ABL      ablation bits of the 8-wave kernel (probes) */
   float attn_defer_log2; /* FLUXMI_ATTN_THR      rescale threshold of the deferred running max, log2; [0, 16], default 8 */
@@ -109,6 +109,8 @@ typedef struct fluxmi_tuning {
   int qlut;              /* FLUXMI_QLUT          1: table-driven GELU -> fp8 epilogues */
   int ln_variant;        /* FLUXMI_LN_V          2 = streaming LayerNorm kernel (default), 1 = one wave per row */
   int roctx;             /* FLUXMI_ROCTX         1: roctx ranges around the phases of a denoise call */
+  int prefetch;          /* FLUXMI_PREFETCH      1: launches with idle CUs (attention, the 216-tile GEMMs) carry extra workgroups that read the
+                                                 weights of the following launches into the memory-side cache (engine, fused mode) */
   int log;               /* FLUXMI_LOG           1: print the struct to stderr when it is resolved / set / an engine is created */
 } fluxmi_tuning_t;
 int fluxmi_get_tuning(fluxmi_tuning_t* out);

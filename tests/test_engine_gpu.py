@@ -183,6 +183,16 @@ def test_fused_equals_unfused_and_graph_equals_eager(dev):
     # a second request re-uses the captured graph
     a2 = model.denoise(lat, inp["img_ids"], inp["txt"], inp["txt_ids"], inp["y"], ts2, guidance=3.5, use_graph=True)
     assert torch.equal(a, a2)
+    # kernel-selection knobs are baked into a captured graph: changing the tuning struct re-captures, and none of them may change a bit --
+    # the weight prefetch riding on attention / the 216-tile GEMMs (extra workgroups that only read), the persistent GEMM, the table epilogues
+    from fluxmi import _lib
+
+    for knobs in (dict(prefetch=0), dict(prefetch=2), dict(gemm_persist=0), dict(qlut=0)):
+        with _lib.tuning(**knobs):
+            a3 = model.denoise(lat, inp["img_ids"], inp["txt"], inp["txt_ids"], inp["y"], ts2, guidance=3.5, use_graph=True)
+        assert torch.equal(a, a3), f"latents change under tuning {knobs}: rel-L2 {rel_l2(a3, a):.3e}"
+    a4 = model.denoise(lat, inp["img_ids"], inp["txt"], inp["txt_ids"], inp["y"], ts2, guidance=3.5, use_graph=True)
+    assert torch.equal(a, a4)
 
 
 @pytest.mark.parametrize("schnell", [False, True])
@@ -317,6 +327,138 @@ def test_batch_sharded_calibration_matches_whole_batch(dev):
     differ = sum(reps2[0].get_submodule(n).input_scale.item() != reps2[1].get_submodule(n).input_scale.item() for n in names)
     print(f"without the exchange {differ}/{len(names)} input scales differ between the replicas; with it 0 (and == the batch-2 run)")
     assert differ > 0
+
+
+def _two_process_worker(rank, world, port, backend, q):
+    """One rank of test_two_process_sharded_calibration_over_a_process_group: the REAL engine on cuda:0, one sample of the batch, the
+    in-step amax exchange through torch.distributed (RCCL if it takes two ranks on one device, else gloo with the 1.2 KB amax vector
+    staged through the host)."""
+    import os
+    import sys
+
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch
+        import torch.distributed as td
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for pth in (os.path.join(root, "flux-fp8-api_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
+            if pth not in sys.path:
+                sys.path.insert(0, pth)
+        import flux_oracle as fo
+        from fluxmi import dist as fdist
+        from fluxmi import synth
+        from test_engine_gpu import QUANTS, build, tiny_config, to_dev
+
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        td.init_process_group(backend=backend, rank=rank, world_size=world)
+        cfg = tiny_config()
+        B, H, W, Lt = 2, 64, 64, 32
+        inp = to_dev(synth.make_inputs(cfg.params, H, W, Lt, batch=B, seed=31, real_tokens=8), dev)
+        inp["img"][1] *= 1.7
+        inp["txt"][1] *= 2.5
+        # rank 0 owns the request: one flat broadcast of [txt | vec | noise] (fluxmi/dist.py), then every rank takes its shard
+        txt, vec, img = inp["txt"], inp["y"], inp["img"]
+        if rank != 0:
+            txt, vec, img = torch.zeros_like(txt), torch.zeros_like(vec), torch.zeros_like(img)
+        if backend == "gloo":
+            t_, v_, i_ = fdist.broadcast_request(txt.cpu(), vec.cpu(), img.cpu(), src=0)
+            txt, vec, img = t_.to(dev), v_.to(dev), i_.to(dev)
+        else:
+            txt, vec, img = fdist.broadcast_request(txt, vec, img, src=0)
+        lo, hi = fdist.shard_bounds(B, rank, world)
+        ts = fo.get_schedule(16, (H // 16) * (W // 16))
+        model = build(cfg, QUANTS["fp8"], dev)[0]
+        n_x = [0]
+        if backend == "gloo":
+            def reduce_fn(t):  # the engine hands over a device tensor on the current stream: stage the few floats through the host
+                h = t.detach().cpu()
+                td.all_reduce(h, op=td.ReduceOp.MAX)
+                t.copy_(h)
+                n_x[0] += 1
+        else:
+            def reduce_fn(t):
+                td.all_reduce(t, op=td.ReduceOp.MAX)
+                n_x[0] += 1
+        model.enable_amax_exchange(reduce_fn)
+        out = model.denoise(img[lo:hi], inp["img_ids"][lo:hi], txt[lo:hi], inp["txt_ids"][lo:hi], vec[lo:hi], ts, guidance=3.5)
+        torch.cuda.synchronize()
+        model.enable_amax_exchange(False)
+        names = [n for n, m in model.named_modules() if m in set(model.f8_modules())]
+        scales = {n: model.get_submodule(n).input_scale.item() for n in names}
+        # after an all-reduce over every rank: the group really has `world` members (a silently degraded group would not)
+        rid = torch.tensor([float(rank), 1.0])
+        if backend != "gloo":
+            rid = rid.to(dev)
+        td.all_reduce(rid, op=td.ReduceOp.SUM)
+        q.put((rank, "ok", out.cpu(), scales, n_x[0], td.get_backend(), [float(v) for v in rid.cpu()]))
+        td.barrier()
+        td.destroy_process_group()
+    except Exception as e:  # noqa
+        import traceback
+
+        q.put((rank, "error", traceback.format_exc(), None, 0, backend, None))
+
+
+def test_two_process_sharded_calibration_over_a_process_group(dev):
+    """BASELINE configs[3] (batch sharded over GPUs, one process per GPU), as far as ONE GPU can show it: two PROCESSES, each with its
+    own engine on cuda:0 and one sample of a batch of two, joined by a torch.distributed process group -- RCCL (backend "nccl") if it
+    accepts two ranks on one device, otherwise gloo with the per-layer amax vector staged through the host.  The 13 calibrating steps
+    run the in-step amax all_reduce(MAX) from inside the engine's hook (fluxmi_engine_set_amax_exchange); the frozen scales of BOTH
+    ranks and the gathered latents must equal the whole-batch run on one engine BIT FOR BIT (the reference takes amax over the whole
+    batch, float8_quantize.py:227; loop: flux_pipeline.py:505-512, 619-651)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from fluxmi import synth
+
+    cfg = tiny_config()
+    B, H, W, Lt = 2, 64, 64, 32
+    inp = to_dev(synth.make_inputs(cfg.params, H, W, Lt, batch=B, seed=31, real_tokens=8), dev)
+    inp["img"][1] *= 1.7
+    inp["txt"][1] *= 2.5
+    ts = fo.get_schedule(16, (H // 16) * (W // 16))
+    whole = build(cfg, QUANTS["fp8"], dev)[0]
+    ref = whole.denoise(inp["img"], inp["img_ids"], inp["txt"], inp["txt_ids"], inp["y"], ts, guidance=3.5).cpu()
+    names = [n for n, m in whole.named_modules() if m in set(whole.f8_modules())]
+    want = {n: whole.get_submodule(n).input_scale.item() for n in names}
+    ctx = mp.get_context("spawn")
+    tried = []
+    for backend in ("nccl", "gloo"):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_two_process_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = []
+        try:
+            for _ in procs:
+                res.append(q.get(timeout=150 if backend == "nccl" else 420))
+        except Exception:  # a rank died or hung (RCCL refuses two ranks on one device on some stacks): fall back to gloo
+            pass
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+        ok = len(res) == 2 and all(r[1] == "ok" for r in res)
+        tried.append((backend, ok, [r[2][-400:] if r[1] != "ok" else "ok" for r in res]))
+        if ok:
+            break
+    assert ok, f"no backend completed the two-process run: {tried}"
+    res.sort(key=lambda r: r[0])
+    print(f"two-process sharded calibration over backend {res[0][5]!r} ({'RCCL, two ranks on one device' if backend == 'nccl' else 'gloo, amax staged through the host'}); "
+          f"{res[0][4]} in-step amax exchanges per rank; rank-id all-reduce {res[0][6]}")
+    assert res[0][6] == [1.0, 2.0] and res[1][6] == [1.0, 2.0], "the process group did not span both ranks"
+    assert res[0][4] > 0 and res[0][4] == res[1][4], "both ranks must have gone through the same number of in-step exchanges"
+    for r in res:
+        bad = [n for n in names if r[3][n] != want[n]]
+        assert not bad, f"rank {r[0]}: {len(bad)} input scales differ from the whole-batch run (e.g. {bad[:3]})"
+    lat = torch.cat((res[0][2], res[1][2]), 0)
+    assert torch.equal(lat, ref), f"two-process latents differ from the whole-batch run: rel-L2 {rel_l2(lat, ref):.3e}"
 
 
 def test_pipeline_generate_latents(dev):

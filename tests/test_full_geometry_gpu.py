@@ -31,8 +31,12 @@ import full_geometry as fg
 from parity_util import assert_close_mag, f8_ulp_diff, round_fp64_to_bf16, ulp_diff
 
 pytestmark = pytest.mark.gpu
-A8_MIN = 0.980  # quantised attention output: fraction of e5m2 bytes identical to the oracle's (measured 0.987-0.991 tiny, 0.990-0.996 real geometry;
-                # the gates below sit ~3 x the spread seen across the pool's boxes below the measurements: the oracle's own CPU results move with the host)
+def a8_min(H):
+    """quantised attention output: required fraction of e5m2 bytes identical to the oracle's.  Measured 0.993-0.996 at the real geometry
+    (hidden 3072; gate 0.988 = 3 x the spread seen across the pool's boxes below the worst measurement) and 0.987-0.991 on the hidden-256
+    twins (few elements, L = 96: gate 0.980); the residue is e5m2 re-gridding of 1-ulp bf16 differences (profiles/r03_attention_parity_f16k.txt);
+    the oracle's own CPU results move with the host"""
+    return 0.988 if H >= 3072 else 0.980
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -254,7 +258,7 @@ def teacher_forced_double(ck, E, orc, tr, i, H, Lt, L, prev_img, prev_txt):
     ck.bf16(f"{pre} qkv GEMM (q,k columns; V leaves as V^T)", qkv[:, :2 * H], ref_qkv[:, :2 * H], 0.980, 0.997, 2e-3)
     rows = torch.arange(Lt, L, max(1, (L - Lt) // 48))[:48]
     sampled_fp64_gemm(ck, f"{pre} img qkv GEMM", qkv[rows][:, :2 * H], tr[pre + ".img_attn.qkv.x8"], _q2(orc.lin[pre + ".img_attn.qkv"], 2 * H), rows - Lt)
-    ck.f8(f"{pre} attention -> proj input", E.get("attn8", (L, H), torch.uint8), cat(pre + ".txt_attn.proj.x8", pre + ".img_attn.proj.x8").view(torch.uint8), A8_MIN, 2e-2)
+    ck.f8(f"{pre} attention -> proj input", E.get("attn8", (L, H), torch.uint8), cat(pre + ".txt_attn.proj.x8", pre + ".img_attn.proj.x8").view(torch.uint8), a8_min(H), 2e-2)
     # stage 4 on the oracle's attention output: proj + gate*y + x
     E.put("attn8", cat(pre + ".txt_attn.proj.x8", pre + ".img_attn.proj.x8").view(torch.uint8).cuda()); E.put("x", x_in); E.run(0, i, 4, 4)
     mid = torch.cat((tr[pre + ".txt_mid"][0], tr[pre + ".img_mid"][0]), 0)
@@ -314,7 +318,7 @@ def teacher_forced_single(ck, E, orc, tr, i, depth, H, L, x_prev):
     cat8 = E.get("cat8", (L, HC), torch.uint8)
     ref_cat8 = tr[pre + ".linear2.x8"].view(torch.uint8)
     ck.f8(f"{pre} linear1 GEMM + GELU -> linear2 input (mlp part)", cat8[:, H:], ref_cat8[:, H:], 0.998, 5e-3)
-    ck.f8(f"{pre} attention -> linear2 input (attn part)", cat8[:, :H], ref_cat8[:, :H], A8_MIN, 2e-2)
+    ck.f8(f"{pre} attention -> linear2 input (attn part)", cat8[:, :H], ref_cat8[:, :H], a8_min(H), 2e-2)
     # stage 4: linear2 (K = 15360) + gate*y + x
     E.put("cat8", ref_cat8.cuda()); E.put("x", x_in); E.run(1, i, 4, 4)
     out = tr[pre + ".out"][0]

@@ -37,6 +37,11 @@ def main():
     ap.add_argument("--no-lut", action="store_true", help="quantising epilogues without the table (VALU GELU)")
     ap.add_argument("--check", action="store_true", help="with --ab: compare the outputs of the configs byte for byte")
     ap.add_argument("--timeline", action="store_true")
+    ap.add_argument("--touch", default="none", choices=["none", "w", "a", "wa"], help="read these operands of the NEXT launch with a plain streaming kernel right "
+                    "before it (emulates a weight prefetch into the memory-side cache; with --rotate)")
+    ap.add_argument("--rotate-what", default="all", choices=["all", "w", "a"], help="which operands differ between the rotated sets (the others are shared)")
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many copies of the operands, one per launch: with enough of them (> 256 MB "
+                    "in total) every launch finds its weights in HBM, not in the 256 MB Infinity Cache -- the situation inside the denoise step")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     M, N, K = SHAPES[args.shape] if args.shape in SHAPES else tuple(int(v) for v in args.shape.split(","))
@@ -47,15 +52,21 @@ def main():
     lut = None if args.no_lut else ops.build_quant_lut(qs, _lib.E5M2, act=1)
     epi = {"bf16": _lib.EPI_BF16, "gelu": _lib.EPI_GELU_QUANT, "gate": _lib.EPI_GATE_RESID, "quant": _lib.EPI_QUANT, "split": _lib.EPI_SPLIT}[args.epi]
 
+    shared = {}
+
     def build():
-        groups, keep, outs = [], [], []
-        for Mg in Ms:
+        groups, keep, outs, aw = [], [], [], []
+        for gi, Mg in enumerate(Ms):
             if args.fill == "zero":
                 a = torch.zeros(Mg, K, device=dev).to(torch.float8_e5m2)
                 w = torch.zeros(N, K, device=dev).to(torch.float8_e4m3fn)
             else:
                 a = (torch.randn(Mg, K, device=dev) * 2).to(torch.float8_e5m2)
                 w = (torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn)
+            if args.rotate_what == "w":
+                a = shared.setdefault(("a", gi), a)
+            if args.rotate_what == "a":
+                w = shared.setdefault(("w", gi), w)
             bias = torch.randn(N, device=dev).bfloat16()
             kw = {}
             if args.epi == "bf16":
@@ -79,15 +90,26 @@ def main():
                 outs.append(vt)
                 kw.update(vt_out=vt.data_ptr(), vt_ld=Lp, tok0=0, vt_rows=Lp, kv_col0=H, heads=H // 128)
             keep += [a, w, bias]
+            aw.append((a, w))
             outs.append(o)
             groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr(), one.data_ptr(), o.data_ptr(), Mg, K, o.stride(0), **kw))
-        return groups, keep, outs
+        return groups, keep, outs, aw
 
-    groups, keep, outs = build()
+    sets = [build() for _ in range(max(1, args.rotate))]
+    groups, keep, outs, _aw = sets[0]
     resid0 = [o.clone() for o in outs] if args.epi == "gate" else None
+    turn = [0]
 
     def run(cfg):
-        ops.gemm_grouped(groups, N, K, True, _lib.E5M2, epi, cfg)
+        g, _k, _o, aw_ = sets[turn[0] % len(sets)]
+        turn[0] += 1
+        if args.touch != "none":
+            for a_, w_ in aw_:
+                if "w" in args.touch:
+                    w_.view(torch.int32).max()
+                if "a" in args.touch:
+                    a_.view(torch.int32).max()
+        ops.gemm_grouped(g, N, K, True, _lib.E5M2, epi, cfg)
 
     def reset():
         if resid0 is not None:  # gate*y + x updates the residual stream in place
@@ -104,8 +126,10 @@ def main():
         return e0.elapsed_time(e1) / iters * 1e-3
 
     cfgs = [int(c) for c in args.ab.split(",")] if args.ab else [args.cfg]
-    tag = f"{args.shape} Ms={Ms} N={N} K={K} epi={args.epi}{'+vt' if args.vt else ''}{' no-lut' if args.no_lut else ''} fill={args.fill}"
+    tag = f"{args.shape} Ms={Ms} N={N} K={K} epi={args.epi}{'+vt' if args.vt else ''}{' no-lut' if args.no_lut else ''} fill={args.fill}{f' rotate={len(sets)}({args.rotate_what})' if len(sets) > 1 else ''}{f' touch={args.touch}' if args.touch != 'none' else ''}"
     if args.check:
+        turn[0] = 0
+        assert len(sets) == 1, "--check compares the outputs of one operand set: do not combine with --rotate"
         ref = None
         for c in cfgs:
             reset()
