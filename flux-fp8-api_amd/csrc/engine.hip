@@ -100,18 +100,15 @@ static u16 host_f2bf(double v) {
   return (u16)(u >> 16);
 }
 
-// fluxmi_tuning_t.fuse_kv (FLUXMI_FUSE_KV): 0 = K / V^T by the relayout kernel, 1 (default) = V^T from the qkv GEMM epilogue, 2 = K and V^T from the epilogue.
-// Measured in one process (profiles/r01_fuse_kv_ab.txt): 52.23 / 51.50 / 51.70 ms per step -- the transposed V store is free in
-// the epilogue, but K's norm + RoPE is VALU work that the GEMM's 8 waves do slower than the memory-bound relayout kernel.
+// fluxmi_tuning_t.fuse_kv (FLUXMI_FUSE_KV): 0 = K / V^T by the relayout kernel, 1 = V^T from the qkv GEMM epilogue, 2 (default) = K and V^T
+// from the epilogue: no relayout launch at all.  Round 1 (profiles/r01_fuse_kv_ab.txt: 52.23 / 51.50 / 51.70 ms per step) had K's
+// norm + RoPE behind guarded stores with the pe load inside each guard; the persistent kernel's K path (gemm_persist.hip) prefetches pe,
+// normalises on the accumulators and stores unguarded (profiles/r04_fused_k.txt).
 int fuse_kv_level() { return fluxmi_tuning().fuse_kv; }
 
-// fluxmi_tuning_t.attn_f16k (FLUXMI_ATTN_F16K, default 1): the K relayout stores fp16 and attention runs the folded arithmetic (softmax scale in Q, running max in
-// the accumulator init; include/fluxmi.h, fluxmi_attention).  0 = bf16 K, the unfolded kernel.  The fused-K GEMM epilogue
-// (FLUXMI_FUSE_KV=2) writes bf16 K and therefore switches it off.
-int attn_f16k() {
-  const fluxmi_tuning_t t = fluxmi_tuning();
-  return t.attn_f16k && t.fuse_kv < 2;
-}
+// fluxmi_tuning_t.attn_f16k (FLUXMI_ATTN_F16K, default 1): K is stored as fp16 (by the relayout kernel or the fused-K GEMM epilogue) and attention runs the
+// folded arithmetic (softmax scale in Q, running max in the accumulator init; include/fluxmi.h, fluxmi_attention).  0 = bf16 K, the unfolded kernel.
+int attn_f16k() { return fluxmi_tuning().attn_f16k; }
 
 // weight prefetch riding on launches with idle CUs (fluxmi_internal.h, FluxmiPrefetch): the fp8 weights of up to six linears, for the next
 // launch that supports it; `wgs` = the CUs that launch leaves idle in its last round
@@ -505,6 +502,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
               g.vt_rows = st == 0 ? Lt : e->Lp - Lt; g.kv_col0 = H; g.heads = heads;
               if (fuse_k) {  // K: QKNorm (this stream's key scale) + RoPE in the epilogue as well -> no relayout kernel at all
                 g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[st == 0 ? 3 : 1];
+                g.k_f16 = attn_f16k();
               }
             }
             gs.push_back(g);
@@ -607,7 +605,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
   const void* const* ns = &e->norm[e->d.depth * 4 + i * 2];
   if (fused) {
     const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H + Hm, H, 1, 13);
-    const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;
+    const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0 && (long long)B * L >= 2048;  // short sequences: one launch of the relayout kernel is cheaper
     if (on(0))
       FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, ms, ms + H, ms, ms + H, MC, L1.in_scale, L1.in_scale, B, L, L, H, 1, L1.in_fmt, s));
     if (on(1)) {
@@ -619,7 +617,9 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
         if (qlut_enabled()) g.q_lut = c.qlut + (size_t)(e->d.depth * 2 + i) * 65536;
         if (fuse_v) {
           g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = 0; g.vt_rows = e->Lp; g.kv_col0 = H; g.heads = heads;
-          if (fuse_k) { g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[1]; }
+          if (fuse_k) {
+            g.k_out = K + (long long)b * H * L; g.k_rows = L; g.pe = pe + (long long)b * L * 128; g.k_norm = ns[1]; g.k_f16 = attn_f16k();
+          }
         }
         gs.push_back(g);
       }

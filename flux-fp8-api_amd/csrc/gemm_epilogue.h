@@ -419,7 +419,7 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
             y[2 * p] = rbf(rbf(cc * x[2 * p]) + rbf((-sn) * x[2 * p + 1]));
             y[2 * p + 1] = rbf(rbf(sn * x[2 * p]) + rbf(cc * x[2 * p + 1]));
           }
-          *(uint4*)((u16*)G.k_out + ((long long)head * G.k_rows + tok) * 128 + d) = pack8(y);
+          *(uint4*)((u16*)G.k_out + ((long long)head * G.k_rows + tok) * 128 + d) = G.k_f16 ? pack8_f16(y) : pack8(y);
         }
       }
       return;

@@ -96,9 +96,10 @@ __device__ __forceinline__ void ps_load_bias(const FluxmiGemmGroup& G, int n_wav
       braw[j][g4] = __builtin_bit_cast(uint2, *(fluxmi_gptr<const fluxmi_v2i>)(bias_src + n_wave0 + j * 32 + g4 * 8 + hi * 4));
 }
 
-template <int EPI, int FMT, class AfterTable>
+// KIND (compile time, tile-uniform): 0 = plain tile, 1 = table tile, 2 = fused-K tile
+template <int EPI, int FMT, int KIND, class AfterTable>
 __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc)[4][2], uint2 (&braw)[2][4], float s, unsigned char* wbuf,
-                                            unsigned char* table, int m_wave0, int n_wave0, int M, int lane, int wave, bool lut,
+                                            unsigned char* table, int m_wave0, int n_wave0, int M, int lane, int wave,
                                             AfterTable after_table, unsigned long long* stamps = nullptr) {
   // timing build only: phase stamps of the table path (stamps[0..3]) by the workgroup's first lane
   auto stamp = [&](int k) { if (stamps) stamps[k] = ps_clock(); };
@@ -140,7 +141,7 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
   };
 
   if constexpr (EPI == FLUXMI_EPI_GELU_QUANT || EPI == FLUXMI_EPI_SPLIT) {
-    if (lut) {
+    if constexpr (KIND == 1) {
       // ---- quantising path: fp8 = quantise(gelu(bf16(acc * s + bias))) -------------------------------------------------------------
       // The 64 KiB table (gemm_epilogue.h) sits in two adjacent dead ring slots; its LDS-DMA was issued inside the last K-step (kernel:
       // behind the barrier in the middle of that step, when the slots were dead), so it lands under the step's last MFMAs and the conversion.
@@ -214,7 +215,7 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
     // ---- fused V^T (wave-uniform): [32 keys][64 d] of one head's V per block -> LDS as [64 d][32 keys] (keys in the PV MFMA's k-slot
     // order: bits 2 and 3 swapped inside a 16-key group), leaves as 64-byte runs of one d-row of vt_out
     const int vcol0 = G.kv_col0 + G.heads * 128;
-    if (G.vt_out && n_wave0 >= vcol0 && n_wave0 < vcol0 + G.heads * 128) {
+    if (KIND == 0 && G.vt_out && n_wave0 >= vcol0 && n_wave0 < vcol0 + G.heads * 128) {
       const unsigned vt_ld_b = uni_u32((unsigned)G.vt_ld) * 2;
       const int d0 = n_wave0 - vcol0, tok0 = (int)uni_u32((unsigned)G.tok0), vt_rows = (int)uni_u32((unsigned)G.vt_rows);
       const __amdgpu_buffer_rsrc_t vt_rs = ps_out_rsrc(G.vt_out, (long long)(G.heads * 128) * vt_ld_b, (long long)d0 * vt_ld_b + (long long)(tok0 + m_wave0) * 2);
@@ -242,6 +243,174 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
           const uint4 raw = *(const uint4*)(wbuf + dl * 64 + c * 16);
           const int key = m_wave0 + i * 32 + c * 8;  // group-relative position of the 8 keys
           ps_store16(vt_rs, __builtin_bit_cast(v4i, raw), key < vt_rows ? (unsigned)dl * vt_ld_b + (unsigned)(i * 32 + c * 8) * 2 : 0xffffffffu);
+        }
+      }
+      return;
+    }
+    // ---- fused K (TILE-uniform: the q | k | v column blocks are multiples of 256, so all eight waves are here together and may meet at
+    // barriers): QKNorm = fp32 rms over the head's 128 columns with the learnable scale, RoPE in bf16 arithmetic, head-major store --
+    // what qkv_rope_kernel does to the K columns, with the same operations in the same order (bit-identical K), but on the accumulators:
+    // the K columns never go to the qkv buffer and back (28 MB written + 28 MB read per launch at L = 4608) and the launch disappears.
+    //   sums of squares: in the accumulator layout, where a row's 64 columns of this wave sit in lanes l31 and l31 + 32 as eight groups of
+    //     8 columns (4 + 4): per group the sequential chain of qkv_rope's lane, continued across the two lanes by v_permlane32_swap; the two
+    //     waves of a head (wave ^ 1: same rows, the other 64 columns) swap their 8 group sums per row through their 4 KiB scratches, and the
+    //     16 sums are added in the order of qkv_rope's 16-lane xor tree (8, 4, 2, 1);
+    //   normalisation: still in the accumulator layout (the row's 1 / rms lives in the lane that owns the row);
+    //   RoPE + store: after the transposition, a lane holds 8 consecutive columns of a row = 4 (cos, sin) pairs = 16 B of `pe`, loaded one
+    //     32-row block ahead like the residual rows of the gate path.                                       flux_model.py:158-176,60-65
+    const int kcol0 = (int)uni_u32((unsigned)G.kv_col0);
+    if constexpr (KIND == 2) {
+      const int hcol = n_wave0 - kcol0, head = hcol >> 7, d0 = hcol & 127;
+      const int tok0 = (int)uni_u32((unsigned)G.tok0), k_rows = (int)uni_u32((unsigned)G.k_rows);
+      const bool f16 = uni_u32((unsigned)G.k_f16) != 0;
+      const int c = lane & 7, rl = lane >> 3;
+      // scale vector, pe rows and K rows through buffer descriptors (pe / K: the range ends with the group's row M - 1): one 32-bit offset
+      // per lane plus constants, no clamps, no guards (a pe row past M reads 0, a K row past M is dropped) -- with 64-bit addresses and
+      // row guards hipcc computed all 32 of them up front and spilled them
+      const __amdgpu_buffer_rsrc_t kn_rs = make_rsrc((const char*)G.k_norm + d0 * 2, (unsigned)(128 - d0) * 2);
+      const __amdgpu_buffer_rsrc_t pe_rs = ps_out_rsrc((void*)G.pe, (long long)(tok0 + M) * 256, (long long)(tok0 + m_wave0) * 256 + d0 * 2);
+      const __amdgpu_buffer_rsrc_t k_rs = ps_out_rsrc((char*)G.k_out + ((long long)head * k_rows + tok0) * 256, (long long)M * 256,
+                                                      (long long)m_wave0 * 256 + d0 * 2);
+      const unsigned row_voff = (unsigned)rl * 256 + c * 16;
+      uint4 per[4];
+      auto load_pe = [&](int i, int it) {
+        per[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(pe_rs, row_voff + (unsigned)(i * 32 + it * 8) * 256, 0, 0));
+      };
+      auto unpack4 = [&](int i, int j, int g4, float* x) {
+        const unsigned a = hp[i][j][g4][0], b = hp[i][j][g4][1];
+        x[0] = __uint_as_float(a << 16); x[1] = __uint_as_float(a & 0xffff0000u);
+        x[2] = __uint_as_float(b << 16); x[3] = __uint_as_float(b & 0xffff0000u);
+      };
+      // every phase below is fenced (sched_barrier) and re-unpacks its inputs from an opaque copy: left alone, hipcc interleaves the
+      // phases, keeps the 256 unpacked floats of one pass alive for the next and spills ~300 registers -- into the K loop's prologue too
+      auto opaque_block = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(hp[i][j][g4][0]), "+v"(hp[i][j][g4][1]));
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      convert_all();
+#pragma unroll
+      for (int i = 0; i < TM; ++i) opaque_block(i);  // pins the whole conversion HERE: hipcc sinks the later blocks' into the code below otherwise
+      ps_wait_all_vmem();  // the ONE vmcnt(0) of this path (see the V^T path)
+      // issued after the conversion (128 accumulators + 64 packed words + bias leave no room); the L2 latency passes under the sums
+      uint2 wraw[TN][4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          wraw[j][g4] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(kn_rs, (unsigned)(j * 32 + g4 * 8 + hi * 4) * 2, 0, 0));
+#pragma unroll
+      for (int it = 0; it < 4; ++it) load_pe(0, it);
+      __builtin_amdgcn_sched_barrier(0);
+      float* mine = (float*)wbuf;
+      const float* other = (const float*)(wbuf + ((wave ^ 1) - wave) * 4096);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float gsum[8];
+        // pass 1: the lane's 4 columns of each group, left to right; pass 2: lanes 32..63 continue the chain of lanes 0..31
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            float x[4];
+            unpack4(i, j, g4, x);
+            float p = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) p += x[e] * x[e];
+            gsum[j * 4 + g4] = p;
+          }
+        opaque_block(i);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            float x[4];
+            unpack4(i, j, g4, x);
+            const unsigned u = __float_as_uint(gsum[j * 4 + g4]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // [0]: lanes 32..63 receive lanes 0..31
+            float q = hi ? __uint_as_float(sw[0]) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q += x[e] * x[e];
+            // lanes 32..63 now hold the group's 8 columns summed left to right; lanes 0..31 take a copy, so that the store below needs no
+            // branch (both lanes of a row write the same words: a basic-block boundary here lets hipcc sink code across the fences)
+            const unsigned uq = __float_as_uint(q);
+            const auto sq = __builtin_amdgcn_permlane32_swap(uq, uq, false, false);  // [1]: lanes 0..31 receive lanes 32..63
+            gsum[j * 4 + g4] = hi ? q : __uint_as_float(sq[1]);
+          }
+        *(float4*)(mine + (i * 32 + l31) * 8) = make_float4(gsum[0], gsum[1], gsum[2], gsum[3]);
+        *(float4*)(mine + (i * 32 + l31) * 8 + 4) = make_float4(gsum[4], gsum[5], gsum[6], gsum[7]);
+        opaque_block(i);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      float rinv[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const float4 a0 = *(const float4*)(mine + (i * 32 + l31) * 8), a1 = *(const float4*)(mine + (i * 32 + l31) * 8 + 4);
+        const float4 b0 = *(const float4*)(other + (i * 32 + l31) * 8), b1 = *(const float4*)(other + (i * 32 + l31) * 8 + 4);
+        const float t0 = a0.x + b0.x, t1 = a0.y + b0.y, t2 = a0.z + b0.z, t3 = a0.w + b0.w;
+        const float t4 = a1.x + b1.x, t5 = a1.y + b1.y, t6 = a1.z + b1.z, t7 = a1.w + b1.w;
+        const float ss = ((t0 + t4) + (t2 + t6)) + ((t1 + t5) + (t3 + t7));  // the order of qkv_rope's xor tree: 8, 4, 2, 1
+        rinv[i] = 1.0f / sqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float w[4];
+          const uint2 wv = wraw[j][g4];
+          w[0] = __uint_as_float(wv.x << 16); w[1] = __uint_as_float(wv.x & 0xffff0000u);
+          w[2] = __uint_as_float(wv.y << 16); w[3] = __uint_as_float(wv.y & 0xffff0000u);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            float x[4];
+            unpack4(i, j, g4, x);
+            hp[i][j][g4][0] = pack_bf2((x[0] * rinv[i]) * w[0], (x[1] * rinv[i]) * w[1]);
+            hp[i][j][g4][1] = pack_bf2((x[2] * rinv[i]) * w[2], (x[3] * rinv[i]) * w[3]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // the partner has read this wave's sums: the scratch is free for the transposition
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int nl = j * 32 + g4 * 8 + hi * 4;
+            uint2 v;
+            v.x = hp[i][j][g4][0];
+            v.y = hp[i][j][g4][1];
+            const int chunk = (nl >> 3) ^ (l31 & 7);
+            *(uint2*)(wbuf + l31 * 128 + chunk * 16 + (nl & 4) * 2) = v;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned f16m = f16 ? 0xffffffffu : 0u;  // blended, not branched: a basic-block boundary lets hipcc move code across the fences
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int ml = it * 8 + rl;
+          const uint4 raw = *(const uint4*)(wbuf + ml * 128 + ((c ^ (ml & 7)) * 16));
+          float x[8], cs[8], y[8];
+          unpack8(raw, x);
+          unpack8(per[it], cs);
+          if (i + 1 < TM) load_pe(i + 1, it);  // the row's pe registers are free again: the same row of the next block, a block ahead
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float cc = cs[2 * p], sn = cs[2 * p + 1];
+            y[2 * p] = rbf(rbf(cc * x[2 * p]) + rbf((-sn) * x[2 * p + 1]));
+            y[2 * p + 1] = rbf(rbf(sn * x[2 * p]) + rbf(cc * x[2 * p + 1]));
+          }
+          const uint4 ph = pack8_f16(y), pb = pack8(y);
+          uint4 pk;
+          pk.x = (ph.x & f16m) | (pb.x & ~f16m); pk.y = (ph.y & f16m) | (pb.y & ~f16m);
+          pk.z = (ph.z & f16m) | (pb.z & ~f16m); pk.w = (ph.w & f16m) | (pb.w & ~f16m);
+          ps_store16(k_rs, __builtin_bit_cast(v4i, pk), row_voff + (unsigned)(i * 32 + it * 8) * 256);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       return;
@@ -393,8 +562,9 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
     // K loop + epilogue of one tile, compiled ONCE PER KIND of tile (table tile or not): as a run-time flag inside one body the table
     // tile's extra work in the last K-step made hipcc spill ~230 VGPRs -- with reloads inside the K loop, each a VMEM operation that
     // drains vmcnt (linear1: 268 -> 414 us)
-    auto tile_body = [&](auto LUT_TILE) {
-    constexpr bool lut_tile = decltype(LUT_TILE)::value;
+    auto tile_body = [&](auto KIND_C) {
+    constexpr int tile_kind = decltype(KIND_C)::value;
+    constexpr bool lut_tile = tile_kind == 1;
 
     // everything derived from the lane index is recomputed per tile from an opaque copy: values that stay live across the epilogue (the
     // point of highest register pressure) are what hipcc spills, and a reload inside the K loop is a VMEM operation that drains vmcnt
@@ -562,7 +732,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
     if constexpr (TIMING) {
       if (threadIdx.x == 0 && P.dbg) stamps = P.dbg + ((size_t)blockIdx.x * 8 + (jt < 8 ? jt : 7)) * 8 + 4;
     }
-    ps_epilogue<ESEL, ACT_FMT>(G, acc, braw, s, wbuf, smem + tbl_slot * STAGE, c_m0 + wm * 128, c_n0 + wn * 64, M, lane_e, wave, lut_tile,
+    ps_epilogue<ESEL, ACT_FMT, tile_kind>(G, acc, braw, s, wbuf, smem + tbl_slot * STAGE, c_m0 + wm * 128, c_n0 + wn * 64, M, lane_e, wave,
                                [&]() {  // table tiles: the successor's third and fourth K-step, into the slots the table vacates
                                  dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 2, s_m3);
                                  dma_stage(n_ars, n_wrs, n_asoff, n_wsoff, 3, nslot(s_m3, 1));
@@ -574,12 +744,24 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       }
     }
     };  // tile_body
+    // fused-K tiles (whole 256-column tiles of the K columns, host check) get their own body like the table tiles: in one body with the
+    // other paths their register pressure spilled the BIAS registers at the common entry of the epilogue -- a scratch reload + vmcnt(0) in
+    // front of every tile's conversion
+    using KPlain = std::integral_constant<int, 0>;
+    using KTable = std::integral_constant<int, 1>;
+    using KFused = std::integral_constant<int, 2>;
+    const int kc0 = (int)uni_u32((unsigned)G.kv_col0);
+    const bool k_tile = uni_ptr((const u16*)G.k_out) != nullptr && c_n0 >= kc0 && c_n0 < kc0 + (int)uni_u32((unsigned)G.heads) * 128;
     if constexpr (ESEL == FLUXMI_EPI_GELU_QUANT) {
-      tile_body(std::true_type{});
+      tile_body(KTable{});
     } else if constexpr (ESEL == FLUXMI_EPI_SPLIT) {
-      if (c_n0 >= (int)uni_u32((unsigned)G.split_n)) tile_body(std::true_type{}); else tile_body(std::false_type{});
+      if (c_n0 >= (int)uni_u32((unsigned)G.split_n)) tile_body(KTable{});
+      else if (k_tile) tile_body(KFused{});
+      else tile_body(KPlain{});
+    } else if constexpr (ESEL == FLUXMI_EPI_BF16) {
+      if (k_tile) tile_body(KFused{}); else tile_body(KPlain{});
     } else {
-      tile_body(std::false_type{});
+      tile_body(KPlain{});
     }
     if (!has_next) break;
     slot0 = nslot(slot0, nk % NS);
@@ -630,15 +812,19 @@ extern "C" int fluxmi_gemm_debug_buffer(void* dev_u64) {
   return 0;
 }
 
-// What the persistent kernel is built for: fp8 x e5m2 operands, the step's four hot epilogues, K bytes % 256 == 0 and >= 512, one lda for
-// every group, no fused-K output; the quantising epilogues only through the table.
+// What the persistent kernel is built for: fp8 x e5m2 operands, the step's four hot epilogues (with the fused V^T / K outputs), K bytes
+// % 256 == 0 and >= 512, one lda for every group; the quantising epilogues only through the table.
 int fluxmi_gemm_persist_ok(const FluxmiGemmParams& p, int is_fp8, int act_fmt) {
   if (!is_fp8 || act_fmt != FLUXMI_FMT_E5M2) return 0;
   if (p.N % 256 != 0 || p.K % 256 != 0 || p.K < 512) return 0;
   if (p.epi != FLUXMI_EPI_BF16 && p.epi != FLUXMI_EPI_GATE_RESID && p.epi != FLUXMI_EPI_SPLIT && p.epi != FLUXMI_EPI_GELU_QUANT) return 0;
   for (int i = 0; i < p.n_groups; ++i) {
     const FluxmiGemmGroup& g = p.g[i];
-    if (g.lda != p.g[0].lda || g.k_out) return 0;
+    if (g.lda != p.g[0].lda) return 0;
+    // fused K: whole 256-column tiles inside the K columns, head pairs (the dispatcher requires the same of configs 13 / 16)
+    if (g.k_out && (g.kv_col0 % 256 != 0 || (g.heads * 128) % 256 != 0 || !g.pe || !g.k_norm || g.k_rows <= 0 ||
+                    (long long)g.heads * g.k_rows * 256 >= (1LL << 32) || (p.epi != FLUXMI_EPI_BF16 && p.epi != FLUXMI_EPI_SPLIT)))
+      return 0;
     if ((long long)g.M * g.lda >= (1LL << 32) || (long long)p.N * p.K >= (1LL << 32)) return 0;
     if ((p.epi == FLUXMI_EPI_SPLIT || p.epi == FLUXMI_EPI_GELU_QUANT) && !g.q_lut) return 0;
     if (p.epi == FLUXMI_EPI_SPLIT && (g.split_n % 256 != 0 || g.split_n != p.g[0].split_n)) return 0;
@@ -650,7 +836,7 @@ int fluxmi_gemm_persist_ok(const FluxmiGemmParams& p, int is_fp8, int act_fmt) {
 int fluxmi_launch_gemm_persist(FluxmiGemmParams& p, int is_fp8, int act_fmt, int timing, hipStream_t s) {
   FLUXMI_REQUIRE(fluxmi_gemm_persist_ok(p, is_fp8, act_fmt),
                  "gemm_persist: needs fp8 x e5m2 operands, N %% 256 == 0, K %% 256 == 0, K >= 512, a bf16 / gate_resid / split / gelu_quant "
-                 "epilogue (the quantising ones with a table), one lda, no fused-K output (N=%d K=%d epi=%d)", p.N, p.K, p.epi);
+                 "epilogue (the quantising ones with a table), one lda (N=%d K=%d epi=%d)", p.N, p.K, p.epi);
   p.dbg = timing ? g_ps_dbg : nullptr;
   if (timing) {
     switch (p.epi) {

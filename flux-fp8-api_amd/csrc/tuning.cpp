@@ -63,7 +63,7 @@ void init_from_env() {
     t.attn_defer_log2 = (e && *e) ? (float)atof(e) : 8.0f;
   }
   t.attn_f16k = env_int("FLUXMI_ATTN_F16K", 1);
-  t.fuse_kv = env_int("FLUXMI_FUSE_KV", 1);
+  t.fuse_kv = env_int("FLUXMI_FUSE_KV", 2);
   t.qlut = env_int("FLUXMI_QLUT", 1);
   t.ln_variant = env_int("FLUXMI_LN_V", 2);
   t.roctx = env_int("FLUXMI_ROCTX", 0);
@@ -71,7 +71,7 @@ void init_from_env() {
   if (validate(t) != 0) {  // a bad environment must not silently change the arithmetic: say so and keep the compiled defaults for that knob
     fprintf(stderr, "fluxmi: ignoring invalid FLUXMI_* environment (%s)\n", fluxmi_last_error());
     if (!(isfinite(t.attn_defer_log2) && t.attn_defer_log2 >= 0.f && t.attn_defer_log2 <= 16.f)) t.attn_defer_log2 = 8.0f;
-    if (t.fuse_kv < 0 || t.fuse_kv > 2) t.fuse_kv = 1;
+    if (t.fuse_kv < 0 || t.fuse_kv > 2) t.fuse_kv = 2;
     if (t.ln_variant != 1 && t.ln_variant != 2) t.ln_variant = 2;
     if (t.gemm_cfg < -1 || t.gemm_cfg > 200) t.gemm_cfg = -1;
   }

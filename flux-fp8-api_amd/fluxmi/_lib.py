@@ -32,7 +32,7 @@ class GemmGroup(C.Structure):
         ("lda", i64), ("ldc", i64), ("ldc2", i64), ("ldr", i64),
         ("M", i32), ("m_tile_start", i32), ("split_n", i32), ("c2_col0", i32),
         ("vt_out", vp), ("k_out", vp), ("pe", vp), ("k_norm", vp), ("vt_ld", i64),
-        ("k_rows", i32), ("tok0", i32), ("vt_rows", i32), ("kv_col0", i32), ("heads", i32), ("_pad", i32),
+        ("k_rows", i32), ("tok0", i32), ("vt_rows", i32), ("kv_col0", i32), ("heads", i32), ("k_f16", i32),
         ("q_lut", vp),
     ]
 

@@ -101,9 +101,10 @@ def lora_fuse_f8(w8: torch.Tensor, w_scale: torch.Tensor, w_scale_recip: torch.T
 # ---- linear ----------------------------------------------------------------------------------------
 def make_group(A, W, bias, sa_recip, sb_recip, Cout, M, lda, ldc, *, C2=None, ldc2=0, gate=None, resid=None, ldr=0,
                q_scale=None, split_n=0, c2_col0=0, vt_out=None, vt_ld=0, tok0=0, vt_rows=0, kv_col0=0, heads=0, k_out=None, pe=None,
-               k_norm=None, k_rows=0, q_lut=None) -> GemmGroup:
+               k_norm=None, k_rows=0, q_lut=None, k_f16=False) -> GemmGroup:
     g = GemmGroup()
     g.q_lut = q_lut
+    g.k_f16 = int(k_f16)
     g.vt_out, g.k_out, g.pe, g.k_norm = vt_out, k_out, pe, k_norm
     g.vt_ld, g.k_rows, g.tok0, g.vt_rows, g.kv_col0, g.heads = vt_ld, k_rows, tok0, vt_rows, kv_col0, heads
     g.A, g.W, g.bias, g.sa_recip, g.sb_recip = A, W, bias, sa_recip, sb_recip

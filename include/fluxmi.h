@@ -69,14 +69,16 @@ typedef struct fluxmi_gemm_group {
    * or the first 3*hidden columns of SingleStreamBlock.linear1).  V columns are written TRANSPOSED into vt_out
    * [heads*128][vt_ld] (key position = tok0 + row, key order inside every 16-key group bit2<->bit3 swapped = the k-slot order of
    * the attention kernel's PV MFMA; positions tok0+M .. tok0+vt_rows-1 are zero filled) instead of into C; K columns are
-   * RMS-normalised (k_norm), rotated (pe) and written to k_out [heads][k_rows][128] instead of into C.
+   * RMS-normalised (k_norm), rotated (pe) and written to k_out [heads][k_rows][128] instead of into C (tile configs 13, 16 and the
+   * persistent config 18, which does it at a fraction of the cost: csrc/gemm_persist.hip).
    * Replaces the V / K halves of fluxmi_qkv_rope.                       flux_model.py:351-354,158-176,60-65,380-382 */
   void* vt_out;
   void* k_out;
   const void* pe;         /* (cos, sin) bf16 [k_rows][64][2] of this batch element */
   const void* k_norm;     /* bf16 [128] */
   long long vt_ld;
-  int k_rows, tok0, vt_rows, kv_col0, heads, _pad;
+  int k_rows, tok0, vt_rows, kv_col0, heads;
+  int k_f16;              /* k_out holds fp16 instead of bf16 (exact for bf16 values in fp16's range: fluxmi_attention's folded QK^T) */
   /* Optional 64 KiB table for the quantising epilogues (FLUXMI_EPI_GELU_QUANT and the mlp columns of FLUXMI_EPI_SPLIT, tile config
    * 13): q_lut[b] = the fp8 byte the epilogue would compute for the bf16 GEMM output with bit pattern b -- bf16 -> GELU -> bf16 ->
    * x input_scale -> bf16 -> clamp -> fp8 is a pure function of those 16 bits once the scale is frozen.  Built by
@@ -105,7 +107,7 @@ typedef struct fluxmi_tuning {
   int attn_abl;          /* FLUXMI_ATTN_ABL      ablation bits of the 8-wave kernel (probes) */
   float attn_defer_log2; /* FLUXMI_ATTN_THR      rescale threshold of the deferred running max, log2; [0, 16], default 8 */
   int attn_f16k;         /* FLUXMI_ATTN_F16K     1: the engine stores K as fp16 and runs the folded attention arithmetic */
-  int fuse_kv;           /* FLUXMI_FUSE_KV       0 / 1 (default) / 2: K, V^T by the relayout kernel / V^T from the qkv GEMM / both */
+  int fuse_kv;           /* FLUXMI_FUSE_KV       0 / 1 / 2 (default): K, V^T by the relayout kernel / V^T from the qkv GEMM epilogue / both */
   int qlut;              /* FLUXMI_QLUT          1: table-driven GELU -> fp8 epilogues */
   int ln_variant;        /* FLUXMI_LN_V          2 = streaming LayerNorm kernel (default), 1 = one wave per row */
   int roctx;             /* FLUXMI_ROCTX         1: roctx ranges around the phases of a denoise call */

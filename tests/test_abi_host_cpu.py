@@ -72,7 +72,7 @@ def test_tuning_struct_round_trip_and_validation(monkeypatch):
     assert fields == [f[0] for f in _lib.Tuning._fields_]
     t = _lib.get_tuning()
     assert t.struct_size == C.sizeof(_lib.Tuning) and t.gemm_cfg == -1 and t.gemm_persist == 1 and t.ln_variant == 2
-    assert abs(t.attn_defer_log2 - 8.0) < 1e-6 and t.attn_f16k == 1 and t.fuse_kv == 1 and t.qlut == 1
+    assert abs(t.attn_defer_log2 - 8.0) < 1e-6 and t.attn_f16k == 1 and t.fuse_kv == 2 and t.qlut == 1
     with _lib.tuning(gemm_cfg=13, attn_defer_log2=6.5):
         u = _lib.get_tuning()
         assert u.gemm_cfg == 13 and abs(u.attn_defer_log2 - 6.5) < 1e-6
@@ -80,7 +80,7 @@ def test_tuning_struct_round_trip_and_validation(monkeypatch):
     for bad in (dict(attn_defer_log2=float("nan")), dict(attn_defer_log2=-1.0), dict(attn_defer_log2=100.0), dict(fuse_kv=7), dict(ln_variant=0)):
         with pytest.raises(RuntimeError, match="tuning"):
             _lib.set_tuning(**bad)
-    assert _lib.get_tuning().fuse_kv == 1  # a refused struct changes nothing
+    assert _lib.get_tuning().fuse_kv == 2  # a refused struct changes nothing
     bad = _lib.get_tuning()
     bad.struct_size = 4
     assert _lib.lib.fluxmi_set_tuning(C.byref(bad)) == 1 and b"struct_size" in _lib.lib.fluxmi_last_error()

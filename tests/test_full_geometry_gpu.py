@@ -589,4 +589,16 @@ def test_frozen_denoise_loop_at_real_geometry(dev, name):
     ck.rows.append(f"  {'ok ' if same else 'BAD'} graph-replayed loop == eager loop, bit for bit")
     if not same:
         ck.fail.append("graph vs eager")
+    # kernel-selection knobs compute the same bits at real geometry too: K by the relayout kernel (fuse_kv 1, 0) instead of the GEMM epilogue
+    # (the fused-K tiles sum their squares in the relayout kernel's order), one-tile-per-workgroup GEMMs (their fused-K epilogue sums in
+    # another order, within 1 ulp: tests/test_ops_gpu.py -- hence with the relayout kernel), no weight prefetch
+    from fluxmi import _lib
+
+    for knobs in (dict(fuse_kv=1), dict(fuse_kv=0), dict(gemm_persist=0, fuse_kv=1), dict(prefetch=0)):
+        with _lib.tuning(**knobs):
+            lat3 = model.denoise(d["img"], d["img_ids"], d["txt"], d["txt_ids"], d["y"], ts, guidance=fg.GUIDANCE, use_graph=True)
+        same = torch.equal(lat.view(torch.int16), lat3.view(torch.int16))
+        ck.rows.append(f"  {'ok ' if same else 'BAD'} latents under tuning {knobs} == default, bit for bit" + ("" if same else f" (rel-L2 {rel_l2(lat3, lat):.3e})"))
+        if not same:
+            ck.fail.append(f"tuning {knobs}")
     ck.done()

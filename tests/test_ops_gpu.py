@@ -774,6 +774,73 @@ def test_gemm_fused_kv_epilogue(ops, dev, cfg):
     assert_bf16_close(K_out, K_ref, max_ulp=1, min_exact=0.999, what="fused K")  # row sums of squares in another order
 
 
+@pytest.mark.parametrize("k_f16", [False, True])
+@pytest.mark.parametrize("epi", ["bf16", "split"])
+def test_gemm_persistent_fused_k(ops, dev, k_f16, epi):
+    """The persistent kernel's fused-K tiles (QKNorm on the accumulators, sums of squares swapped between the two waves of a head, RoPE
+    after the transposition: csrc/gemm_persist.hip) == the plain GEMM followed by fluxmi_qkv_rope, BIT FOR BIT (the sums run in the
+    relayout kernel's order), bf16 and fp16 K; two streams with their own key scales, a ragged last tile per stream, three tiles per
+    workgroup, q columns still in C, V^T from the same launch; `split`: the single-block linear1 form (table tiles in the same launch).
+    flux_model.py:158-176,60-65,351-354"""
+    from fluxmi import _lib
+
+    torch.manual_seed(31)
+    Hh, K = 2, 512
+    HD = Hh * 128
+    Lt, Li = 304, 21777 if epi == "bf16" else 9000   # bf16: 2 + 86 row tiles x 3 column tiles = 264 tiles on 256 workgroups
+    L = Lt + Li
+    Lp = (L + 63) // 64 * 64
+    N = 3 * HD + (1024 if epi == "split" else 0)
+    streams = ((0, Lt), (Lt, Li))
+    ws, a8s, bs = [], [], []
+    for r0, M in streams:
+        a8s.append((torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2))
+        ws.append((torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn))
+        bs.append(torch.randn(N, device=dev).bfloat16())
+    sar, sbr = torch.tensor(0.41, device=dev), torch.tensor(0.77, device=dev)
+    s = [(1 + 0.1 * torch.randn(128, device=dev)).bfloat16() for _ in range(4)]  # txt q,k ; img q,k
+    ids = torch.zeros(1, L, 3, dtype=torch.bfloat16)
+    ids[0, Lt:, 1] = (torch.arange(Li) // 150).bfloat16()
+    ids[0, Lt:, 2] = (torch.arange(Li) % 150).bfloat16()
+    pe6 = fo.rope_table(ids, [16, 56, 56], 10000, torch.bfloat16)
+    pe = torch.stack((pe6[:, 0, :, :, 0, 0], pe6[:, 0, :, :, 1, 0]), -1).contiguous().to(dev)
+    qs = torch.tensor(3.0, device=dev)
+    lut = ops.build_quant_lut(qs, E5M2, act=1)
+    e = _lib.EPI_BF16 if epi == "bf16" else _lib.EPI_SPLIT
+
+    def run(cfg, fused_k):
+        qkv = torch.full((1, L, 3 * HD), float("nan"), dtype=torch.bfloat16, device=dev)
+        c2 = torch.zeros(L, HD + (N - 3 * HD), dtype=torch.uint8, device=dev)
+        K_out = torch.zeros(1, Hh, L, 128, dtype=torch.float16 if k_f16 else torch.bfloat16, device=dev)
+        VT_out = torch.zeros(1, Hh, 128, Lp, dtype=torch.bfloat16, device=dev)
+        groups = []
+        for st, (r0, M) in enumerate(streams):
+            kw = dict(vt_out=VT_out.data_ptr(), vt_ld=Lp, tok0=r0, vt_rows=Lt if st == 0 else Lp - Lt, kv_col0=HD, heads=Hh)
+            if fused_k:
+                kw.update(k_out=K_out.data_ptr(), pe=pe.data_ptr(), k_norm=s[1 if st == 0 else 3].data_ptr(), k_rows=L, k_f16=k_f16)
+            if epi == "split":
+                kw.update(C2=c2[r0:].data_ptr(), ldc2=c2.stride(0), split_n=3 * HD, c2_col0=HD, q_scale=qs.data_ptr(), q_lut=lut.data_ptr())
+            groups.append(ops.make_group(a8s[st].data_ptr(), ws[st].data_ptr(), bs[st].data_ptr(), sar.data_ptr(), sbr.data_ptr(),
+                                         qkv[0, r0:].data_ptr(), M, K, 3 * HD, **kw))
+        ops.gemm_grouped(groups, N, K, True, E5M2, e, cfg)
+        torch.cuda.synchronize()
+        return qkv, K_out, VT_out, c2
+
+    qkv, _, VT_ref, c2_ref = run(13, False)
+    _, K_ref, _ = ops.qkv_rope(torch.nan_to_num(qkv), pe, s[0], s[1], s[2], s[3], split=Lt, heads=Hh, skip_q=True, k_f16=k_f16)
+    qkv2, K_out, VT_out, c2 = run(18, True)
+    assert torch.equal(qkv2[..., :HD], qkv[..., :HD])              # q columns still go to C
+    assert torch.isnan(qkv2[..., HD : 2 * HD].float()).all()        # the K columns do not
+    assert torch.equal(VT_out, VT_ref)
+    assert torch.equal(c2, c2_ref)
+    same = (K_out.view(torch.int16) == K_ref.view(torch.int16)).float().mean().item()
+    assert same == 1.0, f"fused K differs from the relayout kernel's on {1 - same:.3e} of the elements"
+    # the one-tile-per-workgroup kernels' fused K adds the squares in another order: 1 / rms may differ in its last bit, i.e. an element by
+    # one bf16 ulp of the rotation's operands (more "ulps" where the rotation cancels) -- almost all elements identical, none far off
+    _, K13, _, _ = run(13, True)
+    d = (K13.float() - K_ref.float()).abs()
+    assert (K13 == K_ref).float().mean().item() >= 0.999 and d.max().item() <= 2.0 ** -6 * K_ref.float().abs().max().item()
+
 @pytest.mark.parametrize("K", [256, 320, 512, 3072])
 def test_quant_lut_epilogue(ops, dev, K):
     """Table-driven GELU + quantise epilogue (fluxmi_gemm_group_t.q_lut) == the computed one, bit for bit, for GELU_QUANT and for the
