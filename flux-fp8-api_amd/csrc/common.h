@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 typedef __bf16 bf16;
 typedef unsigned short u16;
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -68,14 +70,12 @@ __device__ __forceinline__ uint4 pack8_f16(const float* f) {
 // The clamp guarantees the hardware convert never sees an out-of-range value.
 template <int FMT> __device__ __forceinline__ float fp8_max() { return FMT == FLUXMI_FMT_E5M2 ? 57344.0f : 448.0f; }
 
-template <int FMT> __device__ __forceinline__ float q_prepare(float x, float scale) {
-  float t = rbf(x * scale);
-  const float mx = fp8_max<FMT>();
-  // clamp that propagates NaN like torch.clamp
-  t = (t > mx) ? mx : t;
-  t = (t < -mx) ? -mx : t;
-  return t;
+// clamp to +-mx that propagates NaN like torch.clamp: IEEE 754-2019 maximum / minimum (v_maximum3_f32 / v_minimum3_f32 on gfx950), two
+// instructions -- the compare + select form costs four
+__device__ __forceinline__ float clamp_nan(float t, float mx) {
+  return __builtin_elementwise_minimum(__builtin_elementwise_maximum(t, -mx), mx);
 }
+template <int FMT> __device__ __forceinline__ float q_prepare(float x, float scale) { return clamp_nan(rbf(x * scale), fp8_max<FMT>()); }
 // two prepared floats -> two fp8 bytes in the low half of the result
 template <int FMT> __device__ __forceinline__ unsigned cvt2_fp8(float a, float b) {
   if (FMT == FLUXMI_FMT_E5M2) return (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffffu;
@@ -141,15 +141,37 @@ __device__ __forceinline__ float silu_f(float x) {
 }
 
 // ---- wave-level reductions (wave = 64) ---------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// xor butterfly 32, 16, 8, 4, 2, 1 on the VALU only: v_permlane32_swap / v_permlane16_swap (gfx950) for the two widest steps, DPP for the
+// rest (row_ror:8 = lane ^ 8 inside a 16-lane row; row_ror:4 = lane ^ 4 once lanes i and i ^ 8 agree; quad_perm for ^2 and ^1).  Same
+// additions in the same order as the __shfl_xor loop it replaces (bit-identical results) -- that one compiles to six ds_bpermute round trips
+// through the LDS pipeline, each followed by s_waitcnt lgkmcnt(0).
+template <class Op>
+__device__ __forceinline__ float wave_butterfly(float v, Op op) {
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  auto dpp = [](float x, auto CTRL) {
+    const int xi = __float_as_int(x);
+    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, decltype(CTRL)::value, 0xf, 0xf, false));
+  };
+  v = op(v, dpp(v, std::integral_constant<int, 0x128>{}));  // row_ror:8
+  v = op(v, dpp(v, std::integral_constant<int, 0x124>{}));  // row_ror:4
+  v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));   // quad_perm:[2,3,0,1]
+  v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));   // quad_perm:[1,0,3,2]
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+  return wave_butterfly(v, [](float a, float b) { return a + b; });
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_butterfly(v, [](float a, float b) { return fmaxf(a, b); });
 }
 
 // async global -> LDS copy of 16 bytes per lane (LDS destination = wave-uniform base + lane*16)

@@ -260,16 +260,18 @@ __global__ void __launch_bounds__(256, 5) ln_modulate_kernel(const LnModArgs a) 
 // join -- the prefetch would be waited for right after its issue).  The next-row load is unconditional for the same reason (the
 // last iteration re-loads the wave's last row).
 template <int NCH, bool OUT_FP8, int FMT, bool FULL>
-__global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs a, int rows_per_wg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lnm_smem[];  // [stream][m1 | shift][H] bf16
+__global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs a, int rows_per_wg, int wgs_per_b) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lnm_smem[];  // [stream][m1 | shift][H] as fp32 (of the bf16 values: no unpack per use)
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row, batch and stream live in SGPRs
-  const int rows = a.B * a.L;
-  const int r_begin = blockIdx.x * rows_per_wg, r_end = min(rows, r_begin + rows_per_wg);
-  const int b0 = r_begin / a.L;
-  auto load_row = [&](int row, uint4 (&dst)[NCH]) {
-    const int b = row / a.L, l = row - b * a.L;
-    const u16* xr = a.x + (long long)b * a.x_bstride + (long long)l * a.ldx;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row and stream live in SGPRs
+  // a workgroup's rows lie inside ONE batch element (grid = B x wgs_per_b): its modulation vectors always come from the LDS table.  (With
+  // workgroups allowed to straddle two batch elements, the table-or-global choice sat as a branch inside every 512-column chunk: 12 basic
+  // blocks per row, an LDS round trip exposed in each.)
+  const int b0 = blockIdx.x / wgs_per_b;
+  const int r_begin = (blockIdx.x - b0 * wgs_per_b) * rows_per_wg, r_end = min(a.L, r_begin + rows_per_wg);
+  const u16* xb = a.x + (long long)b0 * a.x_bstride;
+  auto load_row = [&](int l, uint4 (&dst)[NCH]) {
+    const u16* xr = xb + (long long)l * a.ldx;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int c = (lane + 64 * k) * 8;
@@ -280,17 +282,19 @@ __global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs
   int row = r_begin + wave;
   uint4 cur[NCH];
   load_row(min(row, r_end - 1), cur);
-  u16* tab = (u16*)lnm_smem;
+  float* tab = (float*)lnm_smem;
   for (int st = 0; st < 2; ++st) {
     const u16* sc0 = a.scale[st] + (long long)b0 * a.mod_bstride;
     const u16* sh0 = a.shift[st] + (long long)b0 * a.mod_bstride;
     for (int c = threadIdx.x * 8; c < a.H; c += 512 * 8) {
-      float fs[8], m1[8];
+      float fs[8], sh[8];
       unpack8(*(const uint4*)(sc0 + c), fs);
+      unpack8(*(const uint4*)(sh0 + c), sh);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m1[j] = 1.0f + fs[j];
-      *(uint4*)(tab + (st * 2) * a.H + c) = pack8(m1);          // bf16(1 + scale): the reference materialises it (flux_model.py:367)
-      *(uint4*)(tab + (st * 2 + 1) * a.H + c) = *(const uint4*)(sh0 + c);
+      for (int j = 0; j < 8; ++j) fs[j] = rbf(1.0f + fs[j]);  // bf16(1 + scale): the reference materialises it (flux_model.py:367)
+      float* tm0 = tab + (st * 2) * a.H + c;
+      *(float4*)tm0 = make_float4(fs[0], fs[1], fs[2], fs[3]); *(float4*)(tm0 + 4) = make_float4(fs[4], fs[5], fs[6], fs[7]);
+      *(float4*)(tm0 + a.H) = make_float4(sh[0], sh[1], sh[2], sh[3]); *(float4*)(tm0 + a.H + 4) = make_float4(sh[4], sh[5], sh[6], sh[7]);
     }
   }
   float qs2[2] = {1.f, 1.f};
@@ -301,9 +305,9 @@ __global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs
     uint4 nxt[NCH];
     load_row(min(nrow, r_end - 1), nxt);
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch on top (hipcc sinks it below the first reduction otherwise)
-    const int b = row / a.L, l = row - b * a.L, st = (l < a.split) ? 0 : 1;
+    const int l = row, st = (l < a.split) ? 0 : 1;
     const float qs = st ? qs2[1] : qs2[0];
-    const long long orow = (long long)b * a.out_bstride + (long long)l * a.ldo;
+    const long long orow = (long long)b0 * a.out_bstride + (long long)l * a.ldo;
     // pairs of elements in packed f32 VALU ops (v_pk_add / v_pk_mul / v_pk_fma: two elements per instruction) -- the kernel is VALU-bound
     v2f_t sum2 = {0.f, 0.f};
     float xv[NCH][8];  // the row in fp32, unpacked once for the three passes
@@ -335,26 +339,28 @@ __global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs
     const float sq = sq2[0] + sq2[1];
     const float var = wave_sum(sq) / (float)a.H;
     const float rstd = 1.0f / sqrtf(var + 1e-6f);
-    // rows of another batch element than the table's (B > 1, a workgroup straddling two of them): vectors from global memory
-    const bool from_lds = b == b0;
+    // the chunk's bf16(1 + scale) | shift words come from the LDS table one chunk ahead of their use
+    const float* tm = tab + (st * 2) * a.H + lane * 8;
+    const float* tsft = tm + a.H;
+    auto tab_ok = [&](int k) { return FULL || (lane + 64 * k) * 8 < a.H; };
+    struct Tab { float4 m[2], s[2]; };
+    auto tab_read = [&](int k) {
+      Tab t;
+      t.m[0] = *(const float4*)(tm + 512 * k); t.m[1] = *(const float4*)(tm + 512 * k + 4);
+      t.s[0] = *(const float4*)(tsft + 512 * k); t.s[1] = *(const float4*)(tsft + 512 * k + 4);
+      return t;
+    };
+    Tab tc = tab_read(0);
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int c = (lane + 64 * k) * 8;
+      Tab tn = tc;
+      if (k + 1 < NCH && tab_ok(k + 1)) tn = tab_read(k + 1);
       if (FULL || c < a.H) {
-        float m1[8], fh[8], y[8];
+        float y[8];
         const float* v = xv[k];
-        if (from_lds) {
-          unpack8(*(const uint4*)(tab + (st * 2) * a.H + c), m1);
-          unpack8(*(const uint4*)(tab + (st * 2 + 1) * a.H + c), fh);
-        } else {
-          const u16* scg = (st ? a.scale[1] : a.scale[0]) + (long long)b * a.mod_bstride;
-          const u16* shg = (st ? a.shift[1] : a.shift[0]) + (long long)b * a.mod_bstride;
-          float fs[8];
-          unpack8(*(const uint4*)(scg + c), fs);
-          unpack8(*(const uint4*)(shg + c), fh);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) m1[j] = rbf(1.0f + fs[j]);
-        }
+        const float m1[8] = {tc.m[0].x, tc.m[0].y, tc.m[0].z, tc.m[0].w, tc.m[1].x, tc.m[1].y, tc.m[1].z, tc.m[1].w};
+        const float fh[8] = {tc.s[0].x, tc.s[0].y, tc.s[0].z, tc.s[0].w, tc.s[1].x, tc.s[1].y, tc.s[1].z, tc.s[1].w};
         const v2f_t rstd2 = {rstd, rstd}, qs2v = {qs, qs};
         float q[8];
 #pragma unroll
@@ -366,9 +372,8 @@ __global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs
           if (OUT_FP8) {
             const v2f_t t = rbf2(yy * qs2v);
             const float mx = fp8_max<FMT>();
-            // clamp that propagates NaN like torch.clamp (one compare on |t| per element; +-inf saturate)
-            q[j] = fabsf(t[0]) > mx ? copysignf(mx, t[0]) : t[0];
-            q[j + 1] = fabsf(t[1]) > mx ? copysignf(mx, t[1]) : t[1];
+            q[j] = clamp_nan(t[0], mx);  // propagates NaN like torch.clamp; +-inf saturate
+            q[j + 1] = clamp_nan(t[1], mx);
           }
         }
         if (OUT_FP8) {
@@ -380,6 +385,7 @@ __global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs
           *(uint4*)((u16*)a.out + orow + c) = pack8(y);
         }
       }
+      tc = tn;
     }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) cur[k] = nxt[k];
@@ -660,17 +666,18 @@ int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void
   // fluxmi_tuning_t.ln_variant: 2 = streaming kernel (one 8-wave workgroup per CU, next row's loads under this row's arithmetic),
   // 1 = one wave per row, every row resident at once
   const int lnv = fluxmi_tuning().ln_variant;
-  if (lnv == 2) {
-    const int rows = B * L;
-    const int n_wg = min(256, (rows + 7) / 8);
-    const int rows_per_wg = (rows + n_wg - 1) / n_wg;
-    const dim3 grid((rows + rows_per_wg - 1) / rows_per_wg), block(512);
-    const size_t lds = (size_t)H * 8;
+  if (lnv >= 2 && (size_t)H * 16 <= 49152) {  // the streaming kernel keeps four fp32 vectors of H in LDS (48 KiB at H = 3072)
+    // one workgroup per CU overall, each inside one batch element
+    const int n_wg_b = std::max(1, std::min((lnv == 3 ? 512 : 256) / std::max(B, 1), (L + 7) / 8));
+    const int rows_per_wg = (L + n_wg_b - 1) / n_wg_b;
+    const int wgs_per_b = (L + rows_per_wg - 1) / rows_per_wg;
+    const dim3 grid(B * wgs_per_b), block(512);
+    const size_t lds = (size_t)H * 16;  // [stream][1 + scale | shift][H] fp32
 #define LNS2(N_, F_)                                                                                                             \
   do {                                                                                                                           \
-    if (!out_fp8) hipLaunchKernelGGL((ln_modulate_stream_kernel<N_, false, FLUXMI_FMT_E5M2, F_>), grid, block, lds, s, a, rows_per_wg);           \
-    else if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((ln_modulate_stream_kernel<N_, true, FLUXMI_FMT_E5M2, F_>), grid, block, lds, s, a, rows_per_wg); \
-    else hipLaunchKernelGGL((ln_modulate_stream_kernel<N_, true, FLUXMI_FMT_E4M3, F_>), grid, block, lds, s, a, rows_per_wg);                     \
+    if (!out_fp8) hipLaunchKernelGGL((ln_modulate_stream_kernel<N_, false, FLUXMI_FMT_E5M2, F_>), grid, block, lds, s, a, rows_per_wg, wgs_per_b);           \
+    else if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((ln_modulate_stream_kernel<N_, true, FLUXMI_FMT_E5M2, F_>), grid, block, lds, s, a, rows_per_wg, wgs_per_b); \
+    else hipLaunchKernelGGL((ln_modulate_stream_kernel<N_, true, FLUXMI_FMT_E4M3, F_>), grid, block, lds, s, a, rows_per_wg, wgs_per_b);                     \
   } while (0)
 #define LNS(N_) do { if (H == N_ * 512) LNS2(N_, true); else LNS2(N_, false); } while (0)
     if (nch <= 1) LNS(1);

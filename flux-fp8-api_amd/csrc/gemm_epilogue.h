@@ -157,10 +157,7 @@ __device__ __forceinline__ void row_epilogue(const FluxmiGemmGroup& G, float qs,
       const float mx = fp8_max<FMT>();
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        float v = p[e];
-        v = (v > mx) ? mx : v;
-        v = (v < -mx) ? -mx : v;
-        t[j + e] = v;
+        t[j + e] = clamp_nan(p[e], mx);
       }
     }
     uint2 o;

@@ -34,7 +34,7 @@ int validate(const fluxmi_tuning_t& t) {
   FLUXMI_REQUIRE(isfinite(t.attn_defer_log2) && t.attn_defer_log2 >= 0.f && t.attn_defer_log2 <= 16.f,
                  "tuning: attn_defer_log2 %g outside [0, 16]", (double)t.attn_defer_log2);
   FLUXMI_REQUIRE(t.fuse_kv >= 0 && t.fuse_kv <= 2, "tuning: fuse_kv %d (0..2)", t.fuse_kv);
-  FLUXMI_REQUIRE(t.ln_variant == 1 || t.ln_variant == 2, "tuning: ln_variant %d (1 = wave per row, 2 = streaming)", t.ln_variant);
+  FLUXMI_REQUIRE(t.ln_variant >= 1 && t.ln_variant <= 3, "tuning: ln_variant %d (1 = wave per row, 2 = streaming, 3 = streaming, two workgroups per CU)", t.ln_variant);
   return 0;
 }
 
@@ -72,7 +72,7 @@ void init_from_env() {
     fprintf(stderr, "fluxmi: ignoring invalid FLUXMI_* environment (%s)\n", fluxmi_last_error());
     if (!(isfinite(t.attn_defer_log2) && t.attn_defer_log2 >= 0.f && t.attn_defer_log2 <= 16.f)) t.attn_defer_log2 = 8.0f;
     if (t.fuse_kv < 0 || t.fuse_kv > 2) t.fuse_kv = 2;
-    if (t.ln_variant != 1 && t.ln_variant != 2) t.ln_variant = 2;
+    if (t.ln_variant < 1 || t.ln_variant > 3) t.ln_variant = 2;
     if (t.gemm_cfg < -1 || t.gemm_cfg > 200) t.gemm_cfg = -1;
   }
   g_tuning = t;

@@ -109,7 +109,7 @@ typedef struct fluxmi_tuning {
   int attn_f16k;         /* FLUXMI_ATTN_F16K     1: the engine stores K as fp16 and runs the folded attention arithmetic */
   int fuse_kv;           /* FLUXMI_FUSE_KV       0 / 1 / 2 (default): K, V^T by the relayout kernel / V^T from the qkv GEMM epilogue / both */
   int qlut;              /* FLUXMI_QLUT          1: table-driven GELU -> fp8 epilogues */
-  int ln_variant;        /* FLUXMI_LN_V          2 = streaming LayerNorm kernel (default), 1 = one wave per row */
+  int ln_variant;        /* FLUXMI_LN_V          2 = streaming LayerNorm kernel (default), 3 = the same at two workgroups per CU, 1 = one wave per row */
   int roctx;             /* FLUXMI_ROCTX         1: roctx ranges around the phases of a denoise call */
   int prefetch;          /* FLUXMI_PREFETCH      1: launches with idle CUs (attention, the 216-tile GEMMs) carry extra workgroups that read the
                                                  weights of the following launches into the memory-side cache (engine, fused mode) */
