@@ -86,7 +86,7 @@ def kernel_source_key():
 
 def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
     """Average duration of one Linear GEMM launch of the step: the six launch shapes WITH their fused epilogues (fp8 path: GELU+quantise,
-    gate*y+x in place, qkv|mlp split; bf16 path of config 1: plain bf16 outputs, what the unfused engine issues), weighted by their
+    gate*y+x in place, qkv|mlp split, V^T and normalised + rotated K in the attention layout; bf16 path of config 1: plain bf16 outputs, what the unfused engine issues), weighted by their
     count per step; HIP events on the launch stream, random operands.  Returns (flops, algorithmic bytes, seconds) per launch + table."""
     from fluxmi import _lib
 
@@ -96,9 +96,22 @@ def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
     lut_ptr = lut.data_ptr() if lut is not None else None
     tot_t = tot_f = tot_b = 0.0
     n_launch, table = 0, []
+    # the attention-layout outputs the engine fuses into the qkv / linear1 launches (fluxmi_tuning_t.fuse_kv: V^T, and K with QKNorm + RoPE)
+    fuse_kv = _lib.get_tuning().fuse_kv if fp8 else 0
+    L_all = Li + Lt
+    Lp = (L_all + 63) // 64 * 64
+    heads = H // 128
     for name, Ms, N, K, cnt, epi in gemm_shapes(Li, Lt):
         groups, keep = [], []
         nbytes = 0
+        attn_out = fuse_kv >= 1 and epi in ("bf16", "split") and N >= 3 * H
+        if attn_out:
+            vt_t = torch.empty(H, Lp, dtype=torch.bfloat16, device=dev)
+            k_t = torch.empty(heads, L_all, 128, dtype=torch.float16, device=dev)
+            pe_t = torch.randn(L_all, 64, 2, device=dev).bfloat16()
+            kn_t = (1 + 0.1 * torch.randn(128, device=dev)).bfloat16()
+            keep += [vt_t, k_t, pe_t, kn_t]
+        tok0 = 0
         for M in Ms:
             if fp8:
                 a = (torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2)
@@ -132,6 +145,12 @@ def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
                 keep.append(o2)
                 code, kw = _lib.EPI_SPLIT, dict(C2=o2.data_ptr(), ldc2=5 * H, split_n=3 * H, c2_col0=H, q_scale=one.data_ptr(), q_lut=lut_ptr)
                 nbytes += M * 3 * H * 2 + M * 4 * H
+            if attn_out:
+                last = tok0 + M == L_all
+                kw.update(vt_out=vt_t.data_ptr(), vt_ld=Lp, tok0=tok0, vt_rows=(Lp - tok0) if last else M, kv_col0=H, heads=heads)
+                if fuse_kv >= 2:
+                    kw.update(k_out=k_t.data_ptr(), pe=pe_t.data_ptr(), k_norm=kn_t.data_ptr(), k_rows=L_all, k_f16=bool(_lib.get_tuning().attn_f16k))
+                tok0 += M
             keep.append(o)
             groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr() if fp8 else None, one.data_ptr() if fp8 else None,
                                          o.data_ptr(), M, K, o.stride(0), **kw))
@@ -223,7 +242,7 @@ def collect_pmc(cfg_id, Li, Lt):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
                    sys.executable, os.path.join(ROOT, "tools", "gemm_probe.py"), "--shape", f"{sum(Ms)},{N},{K}",
                    *(["--groups", ",".join(str(m) for m in Ms)] if len(Ms) > 1 else []), "--cfg", "-1", "--iters", "4",
-                   "--epi", {"bf16": "bf16", "gate_resid": "gate", "gelu_quant": "gelu", "split": "split"}[epi]] + (["--vt"] if epi == "split" else [])
+                   "--epi", {"bf16": "bf16", "gate_resid": "gate", "gelu_quant": "gelu", "split": "split"}[epi]] + (["--vt"] if epi in ("split", "bf16") else [])
             try:
                 subprocess.run(cmd, env=env, cwd="/tmp", check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=min(150.0, left))
             except Exception:  # noqa
@@ -703,8 +722,9 @@ def main():
                             num, den = num + w * busy["per_launch"][row["launch"]], den + w
                     busy_w = round(num / den, 4) if den else None
                 if fp8:
-                    roof = {"bound": "mfma", "kernel": "gemm_pp_kernel / gemm_w1_kernel <fp8 MX-MFMA 32x32x64, 256x256 tiles> (the 152 grouped "
-                                                        "F8Linear GEMM launches of a step, fused epilogues included)",
+                    roof = {"bound": "mfma", "kernel": "gemm_ps_kernel (persistent) / gemm_w1_kernel / gemm_pp_kernel <fp8 MX-MFMA 32x32x64, 256x256 tiles> "
+                                                        "(the 152 grouped F8Linear GEMM launches of a step as the engine issues them: fused epilogues, "
+                                                        "V^T and K in the attention layout included)",
                             "achieved": round(fl / sec / 1e12, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / FP8_PEAK_TFLOPS, 4)}
                 else:
                     roof = {"bound": "hbm", "kernel": "bf16 MFMA GEMM at M = 512 (weight-stream bound: 23.8 GB of bf16 weights per step)",

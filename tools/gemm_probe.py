@@ -89,6 +89,13 @@ def main():
                 vt = torch.zeros(H, Lp, dtype=torch.bfloat16, device=dev)
                 outs.append(vt)
                 kw.update(vt_out=vt.data_ptr(), vt_ld=Lp, tok0=0, vt_rows=Lp, kv_col0=H, heads=H // 128)
+                if _lib.get_tuning().fuse_kv >= 2:  # K (QKNorm + RoPE, head-major) from the epilogue as well, as the engine issues it
+                    kt = torch.zeros(H // 128, Mg, 128, dtype=torch.float16, device=dev)
+                    pe = torch.randn(Mg, 64, 2, device=dev).bfloat16()
+                    kn = (1 + 0.1 * torch.randn(128, device=dev)).bfloat16()
+                    keep += [pe, kn]
+                    outs.append(kt)
+                    kw.update(k_out=kt.data_ptr(), pe=pe.data_ptr(), k_norm=kn.data_ptr(), k_rows=Mg, k_f16=True)
             keep += [a, w, bias]
             aw.append((a, w))
             outs.append(o)
