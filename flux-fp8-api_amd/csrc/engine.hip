@@ -746,6 +746,20 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
   return 0;
 }
 
+bool needs_splitk(E* e) {
+  for (const fluxmi_linear_t& l : e->lin)
+    if (!l.kind && (long long)l.K * 2 / 64 >= 192) return true;
+  return false;
+}
+// the engine's split-K scratch for every launch of this thread while an engine entry point runs
+struct SplitkScope {
+  explicit SplitkScope(E* e) {
+    auto it = e->bufs.find("splitk");
+    fluxmi_set_splitk_scratch(it != e->bufs.end() && it->second.n >= FLUXMI_SPLITK_WS_BYTES ? (float*)it->second.p : nullptr);
+  }
+  ~SplitkScope() { fluxmi_set_splitk_scratch(nullptr); }
+};
+
 void free_ws(E* e) {
   if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
   e->graph_ok = false;
@@ -898,6 +912,9 @@ int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void*
         // static request buffers (make the captured graph independent of caller pointers)
         {"img_s", (size_t)B * Li * e->d.in_channels * 2}, {"txt_s", (size_t)B * Lt * e->d.ctx_in * 2}, {"y_s", (size_t)B * e->d.vec_in * 2},
         {"pred_s", (size_t)B * Li * e->d.in_channels * 2}, {"txt_emb", (size_t)B * Lt * H * 2},
+        // split-K partial tiles of the bf16 small-M launches (api.cpp: bf16 operands, >= 192 K-steps): owned by the engine, because its step
+        // graph is captured on a private stream and replayed on the caller's -- a scratch keyed by stream would be nobody's
+        {"splitk", needs_splitk(e) ? FLUXMI_SPLITK_WS_BYTES : 256},
     };
     size_t total = 0;
     for (auto& it : items) total += (it.bytes + 255) & ~(size_t)255;
@@ -942,6 +959,7 @@ int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, 
   if (mode == 0) FLUXMI_REQUIRE(trial_index >= 0 && trial_index <= e->d.num_trials, "engine_forward: trial_index %d out of range", trial_index);
   if (mode == 0) e->qlut_valid = false;  // input scales move during calibration
   if (mode == 1) FLUXMI_TRY(build_qluts(e, (hipStream_t)stream));
+  SplitkScope splitk(e);
   return forward_impl(e, (const u16*)img, (const u16*)txt, (const u16*)y, (const u16*)timesteps, (const u16*)guidance, (u16*)pred,
                       mode, trial_index, false, (hipStream_t)stream);
 }
@@ -954,6 +972,7 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
   FLUXMI_REQUIRE(img && txt && y && timesteps_host && trial_index_inout, "engine_denoise: NULL argument");
   FLUXMI_REQUIRE(n_steps >= 0 && n_steps <= MAX_STEPS, "engine_denoise: n_steps=%d out of range", n_steps);
   Range whole("fluxmi_engine_denoise");
+  SplitkScope splitk(e);
   const int B = e->B, Li = e->Li, Lt = e->Lt, C = e->d.in_channels;
   // any bf16 block linear -> the fused path is unavailable, run unfused-frozen (mode 2)
   bool all_f8 = true;
@@ -1112,6 +1131,7 @@ int fluxmi_engine_set_amax_exchange(fluxmi_engine_t* e, float* amax_dev, int n, 
 int fluxmi_engine_run_block(fluxmi_engine_t* e, int kind, int index, int mode, int stage_from, int stage_to, void* stream) {
   FLUXMI_REQUIRE(e && e->ws, "engine_run_block: call fluxmi_engine_prepare first");
   FLUXMI_REQUIRE(mode == 1 || mode == 2, "engine_run_block: mode must be 1 (fused) or 2 (unfused, frozen scales)");
+  SplitkScope splitk(e);
   if (kind == 2) {  // LastLayer: x (img rows) + the last 2H entries of `mod` -> the engine's own `pred_s` buffer
     FLUXMI_REQUIRE(index == 0 && stage_from >= 0 && stage_to <= 1 && stage_from <= stage_to, "engine_run_block: LastLayer has stages 0..1, index 0");
     return final_layer(e, buf<u16>(e, "pred_s"), stage_from, stage_to, (hipStream_t)stream);

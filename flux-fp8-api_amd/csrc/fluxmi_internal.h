@@ -96,6 +96,11 @@ int fluxmi_launch_gemm_persist(FluxmiGemmParams& p, int is_fp8, int act_fmt, int
 // 256x256 ping-pong tiles with `split_k` K ranges per tile + the reduce / epilogue pass (BF16 and GATE_RESID epilogues)
 void fluxmi_gemm_block_splitk(int on);  // +1 / -1: no M-dependent split-K choice while > 0 (thread-local)
 int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int split_k, hipStream_t s);
+// split-K partial-tile scratch of the calling thread's launches (thread-local; nullptr = the library's own per-(device, stream) buffer, which is
+// allocated at the first EAGER use on that stream and refuses to appear under stream capture).  An engine owns one and sets it around its launches:
+// its step graph is captured on a private stream and replayed on the caller's, so the scratch must belong to the engine, not to a stream.
+constexpr size_t FLUXMI_SPLITK_WS_BYTES = (size_t)256 << 20;
+void fluxmi_set_splitk_scratch(float* p);
 // tile choice + (when it pays) the split of a grouped launch into a 256x256 and a 128x128 launch; any number of groups
 int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs, int n, int N, int K, int is_fp8, int act_fmt, int epi, hipStream_t s);
 int fluxmi_launch_gemv(const FluxmiGemvLayer* layers_dev, FluxmiGemvLayer* layers_host, int n_layers, int B, int total_blocks,

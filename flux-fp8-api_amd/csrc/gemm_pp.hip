@@ -334,10 +334,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const FluxmiGemmPara
 // GEMM pass to the reduce pass of the SAME stream, so two streams must never share one -- created under a mutex on the first use, and
 // never under stream capture (a hipMalloc there would invalidate the capture: the launch is refused instead; run the shape once
 // eagerly first, as fluxmi_engine_denoise does with its warm step).
-constexpr size_t SPLITK_WS_BYTES = (size_t)256 << 20;
+constexpr size_t SPLITK_WS_BYTES = FLUXMI_SPLITK_WS_BYTES;
+thread_local float* t_splitk_override = nullptr;
 std::mutex g_splitk_mu;
 std::map<std::pair<int, hipStream_t>, float*> g_splitk_ws;
 int splitk_workspace(hipStream_t s, float** out) {
+  if (t_splitk_override) { *out = t_splitk_override; return 0; }
   int dev = 0;
   FLUXMI_CHECK_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_splitk_mu);
@@ -409,6 +411,8 @@ int launch_pp_cfg(FluxmiGemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+void fluxmi_set_splitk_scratch(float* p) { t_splitk_override = p; }
 
 int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int split_k, hipStream_t s) {
   FLUXMI_REQUIRE(fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, 13), "gemm split-K: shape N=%d K=%d not tileable", p.N, p.K);

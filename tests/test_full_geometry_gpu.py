@@ -519,6 +519,17 @@ def test_schnell_bf16_flow_at_full_depth(dev, name):
     assert torch.isfinite(pred).all()
     ck.l2(f"Flux.forward end to end, bf16 flow, {p.depth}+{p.depth_single_blocks} blocks vs oracle", pred, o1, 3.5e-2)
     E, x_final = teacher_forced_all_blocks(ck, name, model, orc, tr, p, case, mode=2, single_tol=5e-3, double_tol=7e-3)
+    # the bf16 flow's denoise loop as bench.py --config 1 runs it: hipGraph replay == eager launches, bit for bit.  At hidden 3072 the M = 512
+    # launches with K >= 6144 run split-K, whose partial-tile scratch must belong to the ENGINE (the graph is captured on a private stream and
+    # replayed on the caller's; a scratch keyed by stream failed under capture in round 4)
+    ts = [1.0, 0.75, 0.5, 0.25, 0.0]
+    lat_g = model.denoise(d["img"], d["img_ids"], d["txt"], d["txt_ids"], d["y"], ts, guidance=fg.GUIDANCE, use_graph=True)
+    lat_e = model.denoise(d["img"], d["img_ids"], d["txt"], d["txt_ids"], d["y"], ts, guidance=fg.GUIDANCE, use_graph=False)
+    torch.cuda.synchronize()
+    same = torch.isfinite(lat_g).all().item() and torch.equal(lat_g.view(torch.int16), lat_e.view(torch.int16))
+    ck.rows.append(f"  {'ok ' if same else 'BAD'} 4-step bf16 denoise loop: graph replay == eager, bit for bit")
+    if not same:
+        ck.fail.append("bf16 graph vs eager")
     ck.done()
     if p.depth >= 19:
         fg.drop_sd_cache()  # 24 GB of synthetic checkpoint shared with test_full_depth_19_38
