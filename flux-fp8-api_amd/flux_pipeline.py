@@ -276,11 +276,13 @@ class FluxPipeline:
         generator, seed = self.set_seed(seed)
         world, rank = fdist.world_size(), fdist.rank()
         cal = getattr(self.model, "calibration_state", None)
-        if world > 1 and num_images < world and cal is not None and cal()[0] is False:
-            # every rank sees the same (num_images, world, calibration state), so every rank raises -- before any collective.  A rank
+        # the batch prepare() will build: a list prompt with one noise sample sizes the batch by its length (flux_pipeline.py:267-278)
+        eff_images = len(prompt) if (isinstance(prompt, (list, tuple)) and num_images == 1) else num_images
+        if world > 1 and eff_images < world and cal is not None and cal()[0] is False:
+            # every rank sees the same (batch, world, calibration state), so every rank raises -- before any collective.  A rank
             # with an empty shard would skip the calibrating steps: its trial counters would not advance and (with or without the in-step
             # amax exchange) the replicas would freeze different input scales, silently.
-            raise RuntimeError(f"fluxmi: calibrating with fewer images ({num_images}) than ranks ({world}); use num_images >= world_size "
+            raise RuntimeError(f"fluxmi: calibrating with fewer images ({eff_images}) than ranks ({world}); use num_images >= world_size "
                                "until the F8Linear input scales are frozen (FluxPipeline.compile() does)")
         # batch-sharded replicas: every rank denoises its own slice of the batch (rank 0's noise / init latent is
         # what the broadcast below distributes)

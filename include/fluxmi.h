@@ -131,11 +131,17 @@ int fluxmi_clock_sample(void* out24_dev_u64, void* stream);
  * is_fp8=0: A, W bf16 (F.linear).  tile_cfg: -1 auto (cost model + split of a thin last round, what the engine uses);
  * 13 = 256x256 ping-pong LDS ring (K*bytes % 64 == 0); 16 = 256x256 with one wave per SIMD (K*bytes % 256 == 0); 2 = 128x128 and 15 = 128x64
  * double-buffered tiles (K*bytes % 128 == 0); 100 = generic any-shape kernel.  Every one of these computes the same bits.  (Other numbers
- * named kernel generations that were removed: they are rejected.)  113 + S (S = 2..32): config 13 with SPLIT-K -- S workgroups per tile, each
- * over its own K range, fp32 partial tiles in a 256 MiB per-device scratch (allocated by the first such launch) summed in ascending K
- * order by a second pass that applies the epilogue (FLUXMI_EPI_BF16 / FLUXMI_EPI_GATE_RESID only).  The auto dispatch uses it for bf16
- * launches of <= 128 tiles (M <= 512: Flux-schnell at 256x256, the text encoders): deterministic, <= 1 bf16 ulp of fp64 like the others, but
- * not bit-identical to the unsplit kernels (the fp32 sum is associated differently). */
+ * named kernel generations that were removed: they are rejected.)  18 = config 13 as a PERSISTENT kernel (one workgroup per CU walks the tiles;
+ * fp8 x e5m2, N % 256 == 0, K % 256 == 0, K >= 512; the auto dispatch takes it for launches of more than 256 tiles), 19 = its timing build.
+ * 113 + S (S = 2..32, S <= K-steps): config 13 with SPLIT-K -- S workgroups per tile, each over its own K range, fp32 partial tiles in a 256 MiB
+ * scratch summed in ascending K order by a second pass that applies the epilogue (FLUXMI_EPI_BF16 / FLUXMI_EPI_GATE_RESID only).  The scratch
+ * belongs to the (device, stream) pair of the launch: allocated, under a lock, by the first EAGER split-K launch on that stream -- a first use
+ * under stream capture is refused -- so launches on different streams never share partial tiles; a fluxmi_engine owns one of its own (its step
+ * graph is captured on a private stream).  The auto dispatch uses split-K for bf16 launches of <= 128 tiles with >= 192 K-steps (M <= 512:
+ * Flux-schnell at 256x256, the text encoders): deterministic, <= 1 bf16 ulp of fp64 like the others, but not bit-identical to the unsplit
+ * kernels (the fp32 sum is associated differently) -- i.e. the bits of a bf16 auto-dispatched GEMM depend on how many rows share the launch.
+ * Callers that need batch-invariant bits launch a fixed number of rows (the native text encoders run one prompt per launch; the engine's
+ * modulation-table GEMM blocks the choice) or set fluxmi_tuning_t.gemm_splitk = 0. */
 int fluxmi_gemm_grouped(const fluxmi_gemm_group_t* groups, int n_groups, int N, int K, int is_fp8, int act_fmt,
                         int epilogue, int tile_cfg, void* stream);
 /* single-problem convenience form of the above (F8Linear.forward after quantisation) */

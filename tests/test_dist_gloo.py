@@ -163,6 +163,46 @@ def test_two_rank_pipeline_generate_matches_single_process(batch):
     assert all(ok for _, ok, _ in res), res
 
 
+def test_calibration_guard_counts_a_list_prompt_as_its_batch(monkeypatch):
+    """While the input scales are still moving, a request with fewer images than ranks is refused (a rank with an empty shard would not
+    advance its trial counters) -- but the batch a LIST prompt with num_images == 1 builds is its length (flux_pipeline.py:267-278):
+    two prompts on two ranks give every rank a shard and must pass the guard."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "flux-fp8-api_amd"))
+    import flux_pipeline
+    from flux_pipeline import FluxPipeline
+
+    class Reached(Exception):
+        pass
+
+    class CalibratingFlow:
+        def calibration_state(self):
+            return (False, 3)
+
+    pipe = FluxPipeline.__new__(FluxPipeline)
+    pipe.name, pipe.debug, pipe.dtype, pipe.ae_dtype = "flux-dev", False, torch.bfloat16, torch.bfloat16
+    pipe.device_flux = pipe.device_ae = pipe.device_clip = pipe.device_t5 = torch.device("cpu")
+    pipe.model, pipe.ae, pipe.clip, pipe.t5, pipe.rng = CalibratingFlow(), None, None, None, torch.Generator(device="cpu")
+
+    def reached(*a, **k):
+        raise Reached()
+
+    pipe.prepare = reached
+    monkeypatch.setattr(flux_pipeline.fdist, "world_size", lambda: 2)
+    monkeypatch.setattr(flux_pipeline.fdist, "rank", lambda: 0)
+    kw = dict(width=64, height=64, num_steps=2, seed=1, output_type="latent", silent=True)
+    with pytest.raises(RuntimeError, match="fewer images"):
+        pipe.generate("one prompt", num_images=1, **kw)
+    with pytest.raises(RuntimeError, match="fewer images"):
+        pipe.generate(["only one"], num_images=1, **kw)
+    with pytest.raises(Reached):
+        pipe.generate(["first", "second"], num_images=1, **kw)
+    with pytest.raises(Reached):
+        pipe.generate("one prompt", num_images=2, **kw)
+
+
 # ---- bench.py: the launch paths the driver uses for N > 1, on CPU (gloo, stub engine) ---------------------------------------------------
 def _run_bench(extra, env=None, launcher=False, timeout=240):
     import json
