@@ -151,6 +151,10 @@ def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
                 if fuse_kv >= 2:
                     kw.update(k_out=k_t.data_ptr(), pe=pe_t.data_ptr(), k_norm=kn_t.data_ptr(), k_rows=L_all, k_f16=bool(_lib.get_tuning().attn_f16k))
                 tok0 += M
+            if fp8 and _lib.get_tuning().w_pairs and name.split("(")[0] in ("double.qkv", "double.mlp0", "double.mlp2", "single.linear1", "single.linear2"):
+                wp = ops.pair_rows(w)  # the engine's row-pair copy of these weights (fluxmi_gemm_group_t.W_pairs)
+                keep.append(wp)
+                kw.update(W_pairs=wp.data_ptr())
             keep.append(o)
             groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr() if fp8 else None, one.data_ptr() if fp8 else None,
                                          o.data_ptr(), M, K, o.stride(0), **kw))

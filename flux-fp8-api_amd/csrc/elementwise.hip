@@ -708,6 +708,26 @@ int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void
   return 0;
 }
 
+// rows x row_bytes -> [rows/2][row_bytes/64][2][64]: the 64-byte K-steps of a row pair share one 128-byte line (fluxmi_gemm_group_t.W_pairs).
+// One 16-byte chunk per thread; reads and writes are both 64-byte runs.
+__global__ void __launch_bounds__(256) pair_rows_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long chunks, int cpr) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cpr;
+    const int c = (int)(i - r * cpr);                   // 16-byte chunk inside the row
+    const long long line = (r >> 1) * (cpr >> 2) + (c >> 2);  // 128-byte line of (row pair, K-step)
+    out[line * 8 + (r & 1) * 4 + (c & 3)] = in[i];
+  }
+}
+int fluxmi_k_pair_rows(const void* in, void* out, int rows, long long row_bytes, hipStream_t s) {
+  FLUXMI_REQUIRE(in && out && in != out, "pair_rows: NULL or aliased buffers");
+  FLUXMI_REQUIRE(rows >= 0 && rows % 2 == 0 && row_bytes > 0 && row_bytes % 64 == 0, "pair_rows: rows %d (even), row_bytes %lld (multiple of 64)", rows, row_bytes);
+  if (rows == 0) return 0;
+  const long long chunks = (long long)rows * (row_bytes / 16);
+  hipLaunchKernelGGL(pair_rows_kernel, dim3(grid_for(chunks)), dim3(256), 0, s, (const uint4*)in, (uint4*)out, chunks, (int)(row_bytes / 16));
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
 int fluxmi_k_act(const void* x, void* y, int rows, int cols, long long ld_in, long long ld_out, int mode, hipStream_t s) {
   FLUXMI_REQUIRE(cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, "act: cols/ld must be multiples of 8");
   if (rows == 0 || cols == 0) return 0;

@@ -68,6 +68,13 @@ struct fluxmi_engine {
   unsigned graph_gen = 0;          // fluxmi_tuning_generation() the step graph was captured under: a changed tuning struct re-captures
   bool warmed = false;             // one frozen step of this shape has run eagerly (lazy one-time inits done): later calls may capture at once
   bool txt_emb_valid = false;
+  // row-pair copies of the F8Linear weights the persistent GEMM launches read (fluxmi_gemm_group_t.W_pairs): one allocation, offsets per linear
+  // (-1 = none); rebuilt on the first launch after create / rebind (the weights may have been rewritten: LoRA fuse)
+  char* pairs = nullptr;
+  size_t pairs_bytes = 0;
+  std::vector<long long> pairs_off;
+  bool pairs_dirty = true;
+  unsigned pairs_gen = 0;          // fluxmi_tuning_generation() the copies were built under (fluxmi_tuning_t.w_pairs may have changed)
   int* d_step0 = nullptr;          // first step of the modulation table (device scalar: the captured graph reads it)
   int mods_rows_cap = 0;           // rows (steps x B) the table holds; sized in engine_prepare, never inside denoise
   // pinned host staging for the per-request schedule (ts | dts), guarded by an event so that engine_denoise never waits on the stream
@@ -113,6 +120,7 @@ int attn_f16k() { return fluxmi_tuning().attn_f16k; }
 // weight prefetch riding on launches with idle CUs (fluxmi_internal.h, FluxmiPrefetch): the fp8 weights of up to six linears, for the next
 // launch that supports it; `wgs` = the CUs that launch leaves idle in its last round
 void set_pf(fluxmi_engine* e, std::initializer_list<int> lins, int wgs);
+const void* pairs_of(fluxmi_engine* e, int li);
 
 int lin_count(const fluxmi_model_desc_t& d) { return 6 + (d.guidance_embed ? 2 : 0) + d.depth * 10 + d.depth_single * 3 + 2; }
 
@@ -133,7 +141,8 @@ void set_pf(fluxmi_engine* e, std::initializer_list<int> lins, int wgs) {
       if (li < 0 || li >= (int)e->lin.size() || pf.n >= 6) continue;
       const fluxmi_linear_t& l = e->lin[li];
       if (!l.kind || !l.weight) continue;  // fp8 weights only (N * K bytes)
-      pf.ptr[pf.n] = l.weight;
+      const void* wp = pairs_of(e, li);  // what the launch will actually read
+      pf.ptr[pf.n] = wp ? wp : l.weight;
       pf.bytes[pf.n] = ((long long)l.N * l.K) & ~15LL;
       ++pf.n;
     }
@@ -141,6 +150,50 @@ void set_pf(fluxmi_engine* e, std::initializer_list<int> lins, int wgs) {
   fluxmi_set_prefetch(pf.n ? &pf : nullptr);
 }
 int idle_cus(long long wgs) { return (int)((256 - wgs % 256) % 256); }
+
+// the row-pair copy of linear li's weight, or nullptr
+const void* pairs_of(E* e, int li) {
+  if (!e->pairs || e->pairs_dirty || !fluxmi_tuning().w_pairs || li < 0 || li >= (int)e->pairs_off.size() || e->pairs_off[li] < 0) return nullptr;
+  return e->pairs + e->pairs_off[li];
+}
+// Linears whose launches go through the kernels that honour W_pairs at Flux geometry: the persistent kernel (double blocks' qkv and mlp.0,
+// single blocks' linear1) and the one-wave-per-SIMD kernel (mlp.2, linear2).  +8 GB at Flux-dev.  Built lazily on the caller's stream:
+// create / rebind have none, and a rebind follows weight surgery.
+int ensure_pairs(E* e, hipStream_t s) {
+  if (!e->pairs_dirty && e->pairs_gen == fluxmi_tuning_generation()) return 0;
+  e->pairs_gen = fluxmi_tuning_generation();
+  const int n = (int)e->lin.size();
+  std::vector<long long> off(n, -1);
+  size_t total = 0;
+  if (fluxmi_tuning().w_pairs) {
+    auto want = [&](int li) {
+      const fluxmi_linear_t& l = e->lin[li];
+      if (l.kind != 1 || !l.weight || l.N % 2 || l.K % 64) return;
+      off[li] = (long long)total;
+      total += ((size_t)l.N * l.K + 255) & ~(size_t)255;
+    };
+    for (int i = 0; i < e->d.depth; ++i)
+      for (int sl : {D_IMG_QKV, D_TXT_QKV, D_IMG_MLP0, D_TXT_MLP0, D_IMG_MLP2, D_TXT_MLP2}) want(DLi(e, i, sl));
+    for (int i = 0; i < e->d.depth_single; ++i) { want(SLi(e, i, S_LIN1)); want(SLi(e, i, S_LIN2)); }
+  }
+  if (total > e->pairs_bytes) {
+    if (e->pairs) hipFree(e->pairs);
+    e->pairs = nullptr; e->pairs_bytes = 0;
+    if (hipMalloc((void**)&e->pairs, total) != hipSuccess) {
+      // no room for the copies: run without them (same results)
+      (void)hipGetLastError();
+      e->pairs_off.assign(n, -1);
+      e->pairs_dirty = false;
+      return 0;
+    }
+    e->pairs_bytes = total;
+  }
+  for (int li = 0; li < n; ++li)
+    if (off[li] >= 0) FLUXMI_TRY(fluxmi_k_pair_rows(e->lin[li].weight, e->pairs + off[li], e->lin[li].N, e->lin[li].K, s));
+  e->pairs_off = off;
+  e->pairs_dirty = false;
+  return 0;
+}
 
 FluxmiGemmGroup mk_group(const fluxmi_linear_t& l, const void* A, long long lda, void* C, long long ldc, int M) {
   FluxmiGemmGroup g;
@@ -497,6 +550,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
             const fluxmi_linear_t& l = e->lin[li_q[st]];
             const long long r0 = (long long)b * L + roff[st];
             FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H, qkv + r0 * 3 * H, 3 * H, rows[st]);
+            g.W_pairs = pairs_of(e, li_q[st]);
             if (fuse_v) {
               g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = roff[st];
               g.vt_rows = st == 0 ? Lt : e->Lp - Lt; g.kv_col0 = H; g.heads = heads;
@@ -552,6 +606,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
             FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H,
                                          fused ? (void*)(h8 + r0 * Hm) : (void*)(hbf + r0 * Hm), Hm, rows[st]);
             g.q_scale = e->lin[li_m2[st]].in_scale;
+            g.W_pairs = pairs_of(e, li_m0[st]);
             if (fused && qlut_enabled()) g.q_lut = c.qlut + (size_t)(i * 2 + st) * 65536;
             gs.push_back(g);
           }
@@ -571,6 +626,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
             const long long r0 = (long long)b * L + roff[st];
             FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(h8 + r0 * Hm) : (const void*)(hbf + r0 * Hm), Hm, x + r0 * H, H, rows[st]);
             g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 5 * H;
+            g.W_pairs = pairs_of(e, li_m2[st]);
             gs.push_back(g);
           }
         if (fused) {  // the 216-tile launch leaves 40 CUs idle: they pull in the first weights of the NEXT block
@@ -614,6 +670,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
         const long long r0 = (long long)b * L;
         FluxmiGemmGroup g = mk_group(L1, a8 + r0 * H, H, qkv + r0 * 3 * H, 3 * H, L);
         g.C2 = cat8 + r0 * HC; g.ldc2 = HC; g.split_n = 3 * H; g.c2_col0 = H; g.q_scale = L2.in_scale;
+        g.W_pairs = pairs_of(e, l1);
         if (qlut_enabled()) g.q_lut = c.qlut + (size_t)(e->d.depth * 2 + i) * 65536;
         if (fuse_v) {
           g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = 0; g.vt_rows = e->Lp; g.kv_col0 = H; g.heads = heads;
@@ -657,6 +714,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
       const long long r0 = (long long)b * L;
       FluxmiGemmGroup g = mk_group(L2, L2.kind ? (const void*)(cat8 + r0 * HC) : (const void*)(catbf + r0 * HC), HC, x + r0 * H, H, L);
       g.resid = x + r0 * H; g.ldr = H; g.gate = ms + (long long)b * MC + 2 * H;
+      g.W_pairs = pairs_of(e, l2);
       gs.push_back(g);
     }
     if (fused) {  // linear2's 216 tiles leave 40 CUs idle: they pull in the next block's linear1 (after the last block: the next step's first qkv)
@@ -853,6 +911,7 @@ int fluxmi_engine_destroy(fluxmi_engine_t* e) {
   if (!e) return 0;
   free_ws(e);
   if (e->mods_all) hipFree(e->mods_all);
+  if (e->pairs) hipFree(e->pairs);
   if (e->consts) hipFree(e->consts);
   if (e->h_sched) hipHostFree(e->h_sched);
   if (e->ev_sched) hipEventDestroy(e->ev_sched);
@@ -868,6 +927,7 @@ int fluxmi_engine_rebind(fluxmi_engine_t* e, const fluxmi_linear_t* linears, int
   e->graph_ok = false;
   e->warmed = false;
   e->txt_emb_valid = false;
+  e->pairs_dirty = true;
   e->qlut_valid = false;
   if (e->ws) return build_gemv_table(e, 0);
   return 0;
@@ -960,6 +1020,7 @@ int fluxmi_engine_forward(fluxmi_engine_t* e, const void* img, const void* txt, 
   if (mode == 0) e->qlut_valid = false;  // input scales move during calibration
   if (mode == 1) FLUXMI_TRY(build_qluts(e, (hipStream_t)stream));
   SplitkScope splitk(e);
+  FLUXMI_TRY(ensure_pairs(e, (hipStream_t)stream));
   return forward_impl(e, (const u16*)img, (const u16*)txt, (const u16*)y, (const u16*)timesteps, (const u16*)guidance, (u16*)pred,
                       mode, trial_index, false, (hipStream_t)stream);
 }
@@ -973,6 +1034,7 @@ int fluxmi_engine_denoise(fluxmi_engine_t* e, void* img, const void* txt, const 
   FLUXMI_REQUIRE(n_steps >= 0 && n_steps <= MAX_STEPS, "engine_denoise: n_steps=%d out of range", n_steps);
   Range whole("fluxmi_engine_denoise");
   SplitkScope splitk(e);
+  FLUXMI_TRY(ensure_pairs(e, s));
   const int B = e->B, Li = e->Li, Lt = e->Lt, C = e->d.in_channels;
   // any bf16 block linear -> the fused path is unavailable, run unfused-frozen (mode 2)
   bool all_f8 = true;
@@ -1132,6 +1194,7 @@ int fluxmi_engine_run_block(fluxmi_engine_t* e, int kind, int index, int mode, i
   FLUXMI_REQUIRE(e && e->ws, "engine_run_block: call fluxmi_engine_prepare first");
   FLUXMI_REQUIRE(mode == 1 || mode == 2, "engine_run_block: mode must be 1 (fused) or 2 (unfused, frozen scales)");
   SplitkScope splitk(e);
+  FLUXMI_TRY(ensure_pairs(e, (hipStream_t)stream));
   if (kind == 2) {  // LastLayer: x (img rows) + the last 2H entries of `mod` -> the engine's own `pred_s` buffer
     FLUXMI_REQUIRE(index == 0 && stage_from >= 0 && stage_to <= 1 && stage_from <= stage_to, "engine_run_block: LastLayer has stages 0..1, index 0");
     return final_layer(e, buf<u16>(e, "pred_s"), stage_from, stage_to, (hipStream_t)stream);

@@ -124,6 +124,7 @@ int fluxmi_k_gate_residual(const void* x, const void* y, const void* gate, void*
                            long long ldy, long long ldo, long long gate_bstride, hipStream_t s);
 int fluxmi_k_add(const void* a, const void* b, void* z, long long n, hipStream_t s);
 int fluxmi_k_build_qlut(const float* scale, int fmt, int act, void* lut, hipStream_t s);
+int fluxmi_k_pair_rows(const void* in, void* out, int rows, long long row_bytes, hipStream_t s);
 int fluxmi_k_add_bcast(const void* a, const void* b, void* z, long long rows, int nb, int cols, hipStream_t s);
 int fluxmi_k_select_step(const void* table, const int* step, const int* step0_dev, void* dst, long long bytes, hipStream_t s);
 int fluxmi_k_timestep_rows(void* t_rows, const float* ts, int step0, int B, int R, hipStream_t s);

@@ -29,6 +29,14 @@
 
 #include "gemm_epilogue.h"
 
+// Timing-only ablations of the K loop (wrong results; never defined in the product build -- tools/probes, profiles/r04_gemm_persist.txt §9):
+// bit 0: no LDS-DMA refills of the current tile's K-steps, bit 1: no fragment reads after a tile's first, bit 2: no MFMAs,
+// bit 3 / bit 4: the A / W refills address their operand as if it were stored in row pairs ([R/2][K/64][2][64]: a K-step of a row pair is ONE
+// 128-byte line) -- same byte count, every L2 line fetched once per tile instead of twice (a 64-byte K-step is half a line).
+#ifndef PS_ABL
+#define PS_ABL 0
+#endif
+
 namespace {
 
 // wave-uniform description of one 256 x 256 output tile: descriptors + tile offsets of its A / W panels, group index, tile origin.
@@ -50,7 +58,7 @@ __device__ __forceinline__ void ps_setup(const FluxmiGemmParams& P, int lid, int
   n0 = tn * 256;
   const long long a_row_b = (long long)G.lda * eb, w_row_b = (long long)P.K * eb;
   ars = make_rsrc(G.A, (unsigned)min((long long)G.M * a_row_b, 0xffffffffLL));
-  wrs = make_rsrc(G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
+  wrs = make_rsrc(G.W_pairs ? G.W_pairs : G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
   a_soff0 = uni_u32((unsigned)(m0 * a_row_b));
   w_soff0 = uni_u32((unsigned)(n0 * w_row_b));
 }
@@ -504,6 +512,8 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
   if (wg_in_x >= cnt) return;
   const int nk = (P.K * EB) / 64;
   const unsigned a_row_b = (unsigned)(P.g[0].lda * EB), w_row_b = (unsigned)(P.K * EB);  // one lda for every group (host check)
+  const bool w_pairs = (PS_ABL & 16) != 0 || uni_ptr((const u16*)P.g[0].W_pairs) != nullptr;  // every group or none (host check)
+  const unsigned w_kstep = w_pairs ? 128u : 64u;                                               // bytes between consecutive K-steps of a W row
 
   // ring slot arithmetic (slots 0 .. NS-1; d <= NS)
   auto nslot = [](int sl, int d) { const int t = sl + d; return t >= NS ? t - NS : t; };
@@ -512,8 +522,9 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-      a_voff[i] = (unsigned)row * a_row_b + slot * 16;
-      w_voff[i] = (unsigned)row * w_row_b + slot * 16;
+      a_voff[i] = (PS_ABL & 8) ? (unsigned)(row >> 1) * 2 * a_row_b + (row & 1) * 64 + slot * 16 : (unsigned)row * a_row_b + slot * 16;
+      // W in the row-pair layout (W_pairs: the K-steps of rows 2r, 2r + 1 share a 128-byte line, consecutive K-steps of a pair are 128 bytes apart)
+      w_voff[i] = w_pairs ? (unsigned)(row >> 1) * 2 * w_row_b + (row & 1) * 64 + slot * 16 : (unsigned)row * w_row_b + slot * 16;
     }
   };
   auto fence = []() {
@@ -532,9 +543,9 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
     for (int st = 0; st < D; ++st) {
       unsigned char* dA = smem + st * STAGE + wave * 1024;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) dma16_buf(c_ars, dA + NT * 16 * i, a_voff[i], c_asoff + st * 64);
+      for (int i = 0; i < 2; ++i) dma16_buf(c_ars, dA + NT * 16 * i, a_voff[i], c_asoff + st * ((PS_ABL & 8) ? 128 : 64));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) dma16_buf(c_wrs, dA + A_BYTES + NT * 16 * i, w_voff[i], c_wsoff + st * 64);
+      for (int i = 0; i < 2; ++i) dma16_buf(c_wrs, dA + A_BYTES + NT * 16 * i, w_voff[i], c_wsoff + st * w_kstep);
     }
   }
   wait_vmcnt<0>();
@@ -585,8 +596,8 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
     // piece q of a K-step's refill into ring slot sl: 0, 1 = the lane's two A pieces, 2, 3 = its two W pieces
     auto dma_piece = [&](__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t wrs, unsigned asoff, unsigned wsoff, int kt, int sl, int q) {
       unsigned char* dA = smem + sl * STAGE + wave * 1024;
-      if (q < 2) dma16_buf(ars, dA + NT * 16 * q, a_voff[q], asoff + kt * 64);
-      else dma16_buf(wrs, dA + A_BYTES + NT * 16 * (q - 2), w_voff[q - 2], wsoff + kt * 64);
+      if (q < 2) dma16_buf(ars, dA + NT * 16 * q, a_voff[q], asoff + kt * ((PS_ABL & 8) ? 128 : 64));
+      else dma16_buf(wrs, dA + A_BYTES + NT * 16 * (q - 2), w_voff[q - 2], wsoff + kt * w_kstep);
     };
     auto dma_stage = [&](__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t wrs, unsigned asoff, unsigned wsoff, int kt, int sl) {
 #pragma unroll
@@ -620,7 +631,10 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
         } else {
           c0 = acc[i][j];
         }
-        if constexpr (FP8) {
+        if constexpr ((PS_ABL & 4) != 0) {
+          acc[i][j] = c0;
+          acc[i][j][0] += __int_as_float(fw[j][0] ^ fa[i][0]);  // keeps the fragments alive
+        } else if constexpr (FP8) {
           acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[j], fa[i], c0, FLUXMI_FMT_E4M3, ACT_FMT, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         } else {
           const v4i alo = (v4i){fa[i][0], fa[i][1], fa[i][2], fa[i][3]}, ahi = (v4i){fa[i][4], fa[i][5], fa[i][6], fa[i][7]};
@@ -642,7 +656,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
     };
     auto refill_piece = [&](auto SRC, int kt_src, int sl, int q) {
       if constexpr (std::is_same<decltype(SRC), PsNxt>::value) dma_piece(n_ars, n_wrs, n_asoff, n_wsoff, kt_src, sl, q);
-      if constexpr (std::is_same<decltype(SRC), PsCur>::value) dma_piece(c_ars, c_wrs, c_asoff, c_wsoff, kt_src, sl, q);
+      if constexpr (std::is_same<decltype(SRC), PsCur>::value && !(PS_ABL & 1)) dma_piece(c_ars, c_wrs, c_asoff, c_wsoff, kt_src, sl, q);
     };
     // One K-step in ring slot sl.  Behind the two MFMAs of activation fragment p: one piece of the refill of slot sl + 4 (K-step kt_src
     // of the current / the next tile) and, group 0, the reads of fragment p of the NEXT step (its registers are free: both MFMAs that
@@ -661,12 +675,14 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
         mma_row(ZERO, pp);
         fence();
         refill_piece(SRC, kt_src, rs, pp);
-        if constexpr (!decltype(LAST)::value) read_fa(ns, pp);
+        if constexpr (!decltype(LAST)::value && !(PS_ABL & 2)) read_fa(ns, pp);
         fence();
       }
       if constexpr (!decltype(LAST)::value) {
-        read_fw(ns, 0);
-        read_fw(ns, 1);
+        if constexpr (!(PS_ABL & 2)) {
+          read_fw(ns, 0);
+          read_fw(ns, 1);
+        }
       } else {
         __builtin_amdgcn_s_barrier();
         if constexpr (lut_tile) table_dma();
@@ -677,7 +693,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
       if constexpr (decltype(WAIT)::value) wait_vmcnt<LPT * (D - 2)>();
       __builtin_amdgcn_s_barrier();
       fence();
-      read_frags(sl);
+      if constexpr (!(PS_ABL & 2) || decltype(ZERO)::value) read_frags(sl);
       fence();
       if constexpr (decltype(LAST)::value) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments of the last K-step are in registers
@@ -820,7 +836,7 @@ int fluxmi_gemm_persist_ok(const FluxmiGemmParams& p, int is_fp8, int act_fmt) {
   if (p.epi != FLUXMI_EPI_BF16 && p.epi != FLUXMI_EPI_GATE_RESID && p.epi != FLUXMI_EPI_SPLIT && p.epi != FLUXMI_EPI_GELU_QUANT) return 0;
   for (int i = 0; i < p.n_groups; ++i) {
     const FluxmiGemmGroup& g = p.g[i];
-    if (g.lda != p.g[0].lda) return 0;
+    if (g.lda != p.g[0].lda || (g.W_pairs != nullptr) != (p.g[0].W_pairs != nullptr)) return 0;
     // fused K: whole 256-column tiles inside the K columns, head pairs (the dispatcher requires the same of configs 13 / 16)
     if (g.k_out && (g.kv_col0 % 256 != 0 || (g.heads * 128) % 256 != 0 || !g.pe || !g.k_norm || g.k_rows <= 0 ||
                     (long long)g.heads * g.k_rows * 256 >= (1LL << 32) || (p.epi != FLUXMI_EPI_BF16 && p.epi != FLUXMI_EPI_SPLIT)))

@@ -64,20 +64,24 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   // ---- LDS-DMA: descriptors (SGPRs), per-lane offsets (VGPRs, loop-invariant), tile offsets (SGPRs) ----------------------------
   const long long a_row_b = (long long)G.lda * EB, w_row_b = (long long)P.K * EB;
   const __amdgpu_buffer_rsrc_t ars = make_rsrc(G.A, (unsigned)min((long long)M * a_row_b, 0xffffffffLL));
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
+  // W in the row-pair layout when the caller has one (fluxmi_gemm_group_t.W_pairs: the 64-byte K-steps of rows 2r, 2r + 1 share a 128-byte line,
+  // consecutive K-steps of a pair are 128 bytes apart -- every L2 line of W crosses to the CU once per tile instead of twice)
+  const bool w_pairs = uni_ptr((const u16*)G.W_pairs) != nullptr;
+  const unsigned w_kstep = w_pairs ? 128u : 64u;
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(w_pairs ? G.W_pairs : G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
   unsigned a_voff[4], w_voff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
     a_voff[i] = (unsigned)(row * a_row_b + slot * 16);
-    w_voff[i] = (unsigned)(row * w_row_b + slot * 16);
+    w_voff[i] = w_pairs ? (unsigned)((row >> 1) * 2 * w_row_b + (row & 1) * 64 + slot * 16) : (unsigned)(row * w_row_b + slot * 16);
   }
   const unsigned a_soff0 = uni_u32((unsigned)(m0 * a_row_b)), w_soff0 = uni_u32((unsigned)(n0 * w_row_b));
   // piece q (0..7) of K-step kt into ring slot `slot`
   auto dma_piece = [&](int q, int slot, int kt) {
     unsigned char* d = smem + slot * STAGE + wave * 1024;
     if (q < 4) dma16_buf(ars, d + NT * 16 * q, a_voff[q], a_soff0 + kt * 64);
-    else dma16_buf(wrs, d + A_BYTES + NT * 16 * (q - 4), w_voff[q - 4], w_soff0 + kt * 64);
+    else dma16_buf(wrs, d + A_BYTES + NT * 16 * (q - 4), w_voff[q - 4], w_soff0 + kt * w_kstep);
   };
 
   v16f acc[TM][TN];

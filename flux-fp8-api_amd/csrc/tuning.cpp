@@ -41,9 +41,9 @@ int validate(const fluxmi_tuning_t& t) {
 void log_tuning(const fluxmi_tuning_t& t, const char* why) {
   fprintf(stderr,
           "fluxmi tuning (%s): gemm_cfg=%d splitk=%d hybrid=%d esel=%d persist=%d | attn var=%d abl=%d defer_log2=%g f16k=%d | "
-          "fuse_kv=%d qlut=%d ln=%d roctx=%d prefetch=%d\n",
+          "fuse_kv=%d qlut=%d ln=%d roctx=%d prefetch=%d w_pairs=%d\n",
           why, t.gemm_cfg, t.gemm_splitk, t.gemm_hybrid, t.gemm_esel, t.gemm_persist, t.attn_var, t.attn_abl,
-          (double)t.attn_defer_log2, t.attn_f16k, t.fuse_kv, t.qlut, t.ln_variant, t.roctx, t.prefetch);
+          (double)t.attn_defer_log2, t.attn_f16k, t.fuse_kv, t.qlut, t.ln_variant, t.roctx, t.prefetch, t.w_pairs);
 }
 
 void init_from_env() {
@@ -56,6 +56,7 @@ void init_from_env() {
   t.gemm_esel = env_int("FLUXMI_GEMM_ESEL", 1);
   t.gemm_persist = env_int("FLUXMI_GEMM_PERSIST", 1);
   t.prefetch = env_int("FLUXMI_PREFETCH", 1);
+  t.w_pairs = env_int("FLUXMI_W_PAIRS", 1);
   t.attn_var = env_int("FLUXMI_ATTN_VAR", 0);
   t.attn_abl = env_int("FLUXMI_ATTN_ABL", 0);
   {

@@ -101,9 +101,10 @@ def lora_fuse_f8(w8: torch.Tensor, w_scale: torch.Tensor, w_scale_recip: torch.T
 # ---- linear ----------------------------------------------------------------------------------------
 def make_group(A, W, bias, sa_recip, sb_recip, Cout, M, lda, ldc, *, C2=None, ldc2=0, gate=None, resid=None, ldr=0,
                q_scale=None, split_n=0, c2_col0=0, vt_out=None, vt_ld=0, tok0=0, vt_rows=0, kv_col0=0, heads=0, k_out=None, pe=None,
-               k_norm=None, k_rows=0, q_lut=None, k_f16=False) -> GemmGroup:
+               k_norm=None, k_rows=0, q_lut=None, k_f16=False, W_pairs=None) -> GemmGroup:
     g = GemmGroup()
     g.q_lut = q_lut
+    g.W_pairs = W_pairs
     g.k_f16 = int(k_f16)
     g.vt_out, g.k_out, g.pe, g.k_norm = vt_out, k_out, pe, k_norm
     g.vt_ld, g.k_rows, g.tok0, g.vt_rows, g.kv_col0, g.heads = vt_ld, k_rows, tok0, vt_rows, kv_col0, heads
@@ -116,6 +117,15 @@ def make_group(A, W, bias, sa_recip, sb_recip, Cout, M, lda, ldc, *, C2=None, ld
 def gemm_grouped(groups: Sequence[GemmGroup], N: int, K: int, is_fp8: bool, act_fmt: int, epilogue: int, tile_cfg: int = -1) -> None:
     arr = (GemmGroup * len(groups))(*groups)
     call("fluxmi_gemm_grouped", arr, len(groups), N, K, int(is_fp8), act_fmt, epilogue, tile_cfg, _stream())
+
+
+def pair_rows(w: torch.Tensor) -> torch.Tensor:
+    """[R, C] (1-byte or 2-byte elements, row bytes % 64 == 0, R even) -> the same bytes in the row-pair layout [R/2][row_bytes/64][2][64]
+    (fluxmi_gemm_group_t.W_pairs), as a tensor of w's shape and dtype."""
+    assert w.dim() == 2 and w.is_contiguous()
+    out = torch.empty_like(w)
+    call("fluxmi_pair_rows", _p(w), _p(out), w.shape[0], w.shape[1] * w.element_size(), _stream())
+    return out
 
 
 def build_quant_lut(scale: torch.Tensor, fmt: int = E5M2, act: int = 1) -> torch.Tensor:

@@ -85,6 +85,12 @@ typedef struct fluxmi_gemm_group {
    * fluxmi_build_quant_lut with the same device code, so results are bit-identical; it replaces ~25 VALU instructions per element
    * by one LDS gather while the matrix pipe is idle.  NULL = compute.        flux_model.py:301,480 + float8_quantize.py:217-218,274-276 */
   const void* q_lut;
+  /* Optional copy of W in the ROW-PAIR layout [N/2][K_bytes/64][2][64] (fluxmi_pair_rows): the 64-byte K-steps of rows 2r and 2r+1 share one
+   * 128-byte line.  The tiled kernels fetch an operand one 64-byte K-step at a time, i.e. HALF an L2 line per row and step -- each line crosses the
+   * L2 -> CU path twice per tile; with the weight stored in row pairs every line of W is fetched once (profiles/r04_gemm_persist.txt section 9: the
+   * K loop of the persistent kernel 62.4 K -> 56.5 K cycles per tile).  Same values, same results; NULL = read W.  Honoured by tile configs 18
+   * (all groups of a launch with or all without) and 16; the engine keeps such a copy of the weights those launches read (+8 GB at Flux-dev). */
+  const void* W_pairs;
 } fluxmi_gemm_group_t;
 
 const char* fluxmi_last_error(void);
@@ -113,6 +119,8 @@ typedef struct fluxmi_tuning {
   int roctx;             /* FLUXMI_ROCTX         1: roctx ranges around the phases of a denoise call */
   int prefetch;          /* FLUXMI_PREFETCH      1: launches with idle CUs (attention, the 216-tile GEMMs) carry extra workgroups that read the
                                                  weights of the following launches into the memory-side cache (engine, fused mode) */
+  int w_pairs;           /* FLUXMI_W_PAIRS       1: the engine keeps a row-pair copy of the F8Linear weights its persistent GEMM launches read
+                                                 (fluxmi_gemm_group_t.W_pairs: every L2 line of W fetched once per tile instead of twice) */
   int log;               /* FLUXMI_LOG           1: print the struct to stderr when it is resolved / set / an engine is created */
 } fluxmi_tuning_t;
 int fluxmi_get_tuning(fluxmi_tuning_t* out);
@@ -186,6 +194,8 @@ int fluxmi_add(const void* a, const void* b, void* z, long long n, void* stream)
 /* lut[b] for every bf16 bit pattern b: the fp8 byte of  to_fp8_saturated(act(bf16 b), *scale)  (act: 0 none, 1 gelu-tanh, 2 silu),
  * rounded at the same points as the fused epilogues.  65536 bytes.                      float8_quantize.py:217-218 */
 int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void* stream);
+/* rows x row_bytes (row-major, rows % 2 == 0, row_bytes % 64 == 0) -> the row-pair layout of fluxmi_gemm_group_t.W_pairs; out != in */
+int fluxmi_pair_rows(const void* in, void* out, int rows, long long row_bytes, void* stream);
 
 /* ---- attention path --------------------------------------------------------------------------------- */
 /* pe[rows, pairs, (cos,sin)] from position ids                                    flux_model.py:49-57,82-92 */

@@ -91,7 +91,7 @@ def test_tuning_struct_round_trip_and_validation(monkeypatch):
 def test_struct_layouts_match_the_header():
     from fluxmi import _lib
 
-    assert C.sizeof(_lib.GemmGroup) == 10 * 8 + 4 * 8 + 4 * 4 + 4 * 8 + 8 + 6 * 4 + 8
+    assert C.sizeof(_lib.GemmGroup) == 10 * 8 + 4 * 8 + 4 * 4 + 4 * 8 + 8 + 6 * 4 + 8 + 8  # ... q_lut, W_pairs
     assert C.sizeof(_lib.Linear) == 6 * 8 + 4 * 4
     assert C.sizeof(_lib.ModelDesc) == 14 * 4
 

@@ -605,7 +605,7 @@ def test_frozen_denoise_loop_at_real_geometry(dev, name):
     # another order, within 1 ulp: tests/test_ops_gpu.py -- hence with the relayout kernel), no weight prefetch
     from fluxmi import _lib
 
-    for knobs in (dict(fuse_kv=1), dict(fuse_kv=0), dict(gemm_persist=0, fuse_kv=1), dict(prefetch=0)):
+    for knobs in (dict(fuse_kv=1), dict(fuse_kv=0), dict(gemm_persist=0, fuse_kv=1), dict(prefetch=0), dict(w_pairs=0)):
         with _lib.tuning(**knobs):
             lat3 = model.denoise(d["img"], d["img_ids"], d["txt"], d["txt_ids"], d["y"], ts, guidance=fg.GUIDANCE, use_graph=True)
         same = torch.equal(lat.view(torch.int16), lat3.view(torch.int16))

@@ -774,6 +774,81 @@ def test_gemm_fused_kv_epilogue(ops, dev, cfg):
     assert_bf16_close(K_out, K_ref, max_ulp=1, min_exact=0.999, what="fused K")  # row sums of squares in another order
 
 
+def test_gemm_persistent_row_pair_weights(ops, dev):
+    """fluxmi_gemm_group_t.W_pairs: the weight in the row-pair layout [N/2][K/64][2][64] (fluxmi_pair_rows) gives the persistent kernel full
+    128-byte lines per K-step; same values -> every output byte equals the launch that reads W.  Two groups, ragged rows, the split epilogue
+    (plain, table and V^T tiles), three tiles per workgroup; fluxmi_pair_rows against the same permutation in torch."""
+    from fluxmi import _lib
+
+    torch.manual_seed(5)
+    Hh, K = 256, 768
+    N = 3 * Hh + 1024
+    Ms = [5000, 333]
+    qs = torch.tensor(2.5, device=dev)
+    lut = ops.build_quant_lut(qs, E5M2, act=1)
+    one = torch.tensor(1.0, device=dev)
+    ws = [(torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn) for _ in Ms]
+    for w in ws:
+        ref = w.view(torch.uint8).view(N // 2, 2, K // 64, 64).permute(0, 2, 1, 3).contiguous().view(N, K)
+        assert torch.equal(ops.pair_rows(w).view(torch.uint8), ref)
+    a8s = [(torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2) for M in Ms]
+    bias = torch.randn(N, device=dev).bfloat16()
+
+    def run(pairs):
+        outs, groups, keep = [], [], []
+        for M, a, w in zip(Ms, a8s, ws):
+            Lp = (M + 63) // 64 * 64
+            o = torch.full((M, 3 * Hh), float("nan"), dtype=torch.bfloat16, device=dev)
+            o2 = torch.zeros(M, Hh + (N - 3 * Hh), dtype=torch.uint8, device=dev)
+            vt = torch.zeros(Hh, Lp, dtype=torch.bfloat16, device=dev)
+            kw = dict(C2=o2.data_ptr(), ldc2=o2.stride(0), split_n=3 * Hh, c2_col0=Hh, q_scale=qs.data_ptr(), q_lut=lut.data_ptr(),
+                      vt_out=vt.data_ptr(), vt_ld=Lp, tok0=0, vt_rows=Lp, kv_col0=Hh, heads=Hh // 128)
+            if pairs:
+                wp = ops.pair_rows(w)
+                keep.append(wp)
+                kw.update(W_pairs=wp.data_ptr())
+            outs += [o, o2, vt]
+            groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr(), one.data_ptr(), o.data_ptr(), M, K, o.stride(0), **kw))
+        ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_SPLIT, 18)
+        torch.cuda.synchronize()
+        return [x.view(torch.uint8) if x.dtype == torch.uint8 else x.view(torch.int16) for x in outs]
+
+    for i, (x, y) in enumerate(zip(run(False), run(True))):
+        assert torch.equal(x, y), f"output {i} differs with W_pairs"
+
+
+def test_gemm_one_wave_kernel_row_pair_weights(ops, dev):
+    """W_pairs through the one-wave-per-SIMD kernel (tile config 16: the step's mlp.2 / linear2 launches): gate * y + x in place, ragged rows,
+    two groups of which only ONE has a row-pair copy (a per-workgroup choice there); every byte equals the launch without copies."""
+    from fluxmi import _lib
+
+    torch.manual_seed(6)
+    N, K, Ms = 768, 2048, [700, 300]
+    one = torch.tensor(1.0, device=dev)
+    ws = [(torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn) for _ in Ms]
+    a8s = [(torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2) for M in Ms]
+    gate = torch.randn(N, device=dev).bfloat16()
+    x0 = [torch.randn(M, N, device=dev).bfloat16() for M in Ms]
+
+    def run(pairs):
+        outs, groups, keep = [], [], []
+        for gi, (M, a, w) in enumerate(zip(Ms, a8s, ws)):
+            o = x0[gi].clone()
+            kw = dict(gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N)
+            if pairs and gi == 0:
+                wp = ops.pair_rows(w)
+                keep.append(wp)
+                kw.update(W_pairs=wp.data_ptr())
+            outs.append(o)
+            groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), None, one.data_ptr(), one.data_ptr(), o.data_ptr(), M, K, N, **kw))
+        ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_GATE_RESID, 16)
+        torch.cuda.synchronize()
+        return outs
+
+    for x, y in zip(run(False), run(True)):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
 @pytest.mark.parametrize("k_f16", [False, True])
 @pytest.mark.parametrize("epi", ["bf16", "split"])
 def test_gemm_persistent_fused_k(ops, dev, k_f16, epi):

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--no-lut", action="store_true", help="quantising epilogues without the table (VALU GELU)")
     ap.add_argument("--check", action="store_true", help="with --ab: compare the outputs of the configs byte for byte")
     ap.add_argument("--timeline", action="store_true")
+    ap.add_argument("--pairs", action="store_true", help="give every group a row-pair copy of its weight (fluxmi_gemm_group_t.W_pairs, tile config 18 / 19)")
     ap.add_argument("--touch", default="none", choices=["none", "w", "a", "wa"], help="read these operands of the NEXT launch with a plain streaming kernel right "
                     "before it (emulates a weight prefetch into the memory-side cache; with --rotate)")
     ap.add_argument("--rotate-what", default="all", choices=["all", "w", "a"], help="which operands differ between the rotated sets (the others are shared)")
@@ -96,6 +97,10 @@ def main():
                     keep += [pe, kn]
                     outs.append(kt)
                     kw.update(k_out=kt.data_ptr(), pe=pe.data_ptr(), k_norm=kn.data_ptr(), k_rows=Mg, k_f16=True)
+            if args.pairs:
+                wp = ops.pair_rows(w)
+                keep.append(wp)
+                kw.update(W_pairs=wp.data_ptr())
             keep += [a, w, bias]
             aw.append((a, w))
             outs.append(o)
