@@ -31,6 +31,12 @@ import full_geometry as fg
 from parity_util import assert_close_mag, f8_ulp_diff, round_fp64_to_bf16, ulp_diff
 
 pytestmark = pytest.mark.gpu
+def _tuning(**knobs):
+    from fluxmi import _lib
+
+    return _lib.tuning(**knobs)
+
+
 def a8_min(H):
     """quantised attention output: required fraction of e5m2 bytes identical to the oracle's.  Measured 0.993-0.996 at the real geometry
     (hidden 3072; gate 0.988 = 3 x the spread seen across the pool's boxes below the worst measurement) and 0.987-0.991 on the hidden-256
@@ -253,12 +259,15 @@ def teacher_forced_double(ck, E, orc, tr, i, H, Lt, L, prev_img, prev_txt):
     ck.f8(f"{pre} LN+modulate -> qkv input", E.get("a8", (L, H), torch.uint8), cat(pre + ".txt_attn.qkv.x8", pre + ".img_attn.qkv.x8").view(torch.uint8), 0.9995, 2e-3)
     # stages 1-3 on the oracle's quantised input: qkv GEMM (grouped txt+img), K relayout, attention -> quantised proj input
     E.put("a8", cat(pre + ".txt_attn.qkv.x8", pre + ".img_attn.qkv.x8").view(torch.uint8).cuda()); E.run(0, i, 1, 3)
+    attn8_got = E.get("attn8", (L, H), torch.uint8)  # the default path: K (QKNorm + RoPE) and V^T straight from the GEMM epilogue
+    with _tuning(fuse_kv=1):  # the GEMM's own k columns are only visible when K goes through the qkv buffer (relayout kernel; same K bits)
+        E.run(0, i, 1, 1)
     qkv = E.get("qkv", (L, 3 * H), torch.bfloat16)
     ref_qkv = cat(pre + ".txt_attn.qkv.out", pre + ".img_attn.qkv.out")
     ck.bf16(f"{pre} qkv GEMM (q,k columns; V leaves as V^T)", qkv[:, :2 * H], ref_qkv[:, :2 * H], 0.980, 0.997, 2e-3)
     rows = torch.arange(Lt, L, max(1, (L - Lt) // 48))[:48]
     sampled_fp64_gemm(ck, f"{pre} img qkv GEMM", qkv[rows][:, :2 * H], tr[pre + ".img_attn.qkv.x8"], _q2(orc.lin[pre + ".img_attn.qkv"], 2 * H), rows - Lt)
-    ck.f8(f"{pre} attention -> proj input", E.get("attn8", (L, H), torch.uint8), cat(pre + ".txt_attn.proj.x8", pre + ".img_attn.proj.x8").view(torch.uint8), a8_min(H), 2e-2)
+    ck.f8(f"{pre} attention -> proj input", attn8_got, cat(pre + ".txt_attn.proj.x8", pre + ".img_attn.proj.x8").view(torch.uint8), a8_min(H), 2e-2)
     # stage 4 on the oracle's attention output: proj + gate*y + x
     E.put("attn8", cat(pre + ".txt_attn.proj.x8", pre + ".img_attn.proj.x8").view(torch.uint8).cuda()); E.put("x", x_in); E.run(0, i, 4, 4)
     mid = torch.cat((tr[pre + ".txt_mid"][0], tr[pre + ".img_mid"][0]), 0)
@@ -310,12 +319,14 @@ def teacher_forced_single(ck, E, orc, tr, i, depth, H, L, x_prev):
     ck.f8(f"{pre} LN+modulate -> linear1 input", E.get("a8", (L, H), torch.uint8), x8.view(torch.uint8), 0.9995, 2e-3)
     # stages 1-3: linear1 (N = 21504, split epilogue), K relayout, attention
     E.put("a8", x8.view(torch.uint8).cuda()); E.run(1, i, 1, 3)
+    cat8 = E.get("cat8", (L, HC), torch.uint8)  # the default path (fused K / V^T)
+    with _tuning(fuse_kv=1):  # k columns through the qkv buffer for the GEMM check (see the double block)
+        E.run(1, i, 1, 1)
     lin1 = tr[pre + ".linear1.out"]
     qkv = E.get("qkv", (L, 3 * H), torch.bfloat16)
     ck.bf16(f"{pre} linear1 GEMM (q,k columns)", qkv[:, :2 * H], lin1[:, :2 * H], 0.980, 0.997, 2e-3)
     rows = torch.arange(0, L, max(1, L // 48))[:48]
     sampled_fp64_gemm(ck, f"{pre} linear1 GEMM", qkv[rows][:, :2 * H], x8, _q2(orc.lin[pre + ".linear1"], 2 * H), rows)
-    cat8 = E.get("cat8", (L, HC), torch.uint8)
     ref_cat8 = tr[pre + ".linear2.x8"].view(torch.uint8)
     ck.f8(f"{pre} linear1 GEMM + GELU -> linear2 input (mlp part)", cat8[:, H:], ref_cat8[:, H:], 0.998, 5e-3)
     ck.f8(f"{pre} attention -> linear2 input (attn part)", cat8[:, :H], ref_cat8[:, :H], a8_min(H), 2e-2)
