@@ -1228,7 +1228,7 @@ int fluxmi_engine_copy_buffer(fluxmi_engine_t* e, const char* name, long long of
 
 int fluxmi_engine_workspace_bytes(fluxmi_engine_t* e, long long* bytes) {
   FLUXMI_REQUIRE(e && bytes, "engine_workspace_bytes: NULL argument");
-  *bytes = (long long)e->ws_bytes;
+  *bytes = (long long)(e->ws_bytes + e->pairs_bytes + e->mods_all_bytes);  // workspace + row-pair weight copies + modulation table
   return 0;
 }
 

@@ -324,7 +324,8 @@ int fluxmi_engine_last_timing(fluxmi_engine_t* e, float* ms, int* steps);
  * torch.distributed) and returns 0.  Calibrating steps only; never called from the captured graph.  hook = NULL uninstalls. */
 typedef int (*fluxmi_amax_hook_t)(void* user, int first, int count, void* stream);
 int fluxmi_engine_set_amax_exchange(fluxmi_engine_t* e, float* amax_dev, int n, fluxmi_amax_hook_t hook, void* user);
-/* introspection for tests / bench */
+/* introspection for tests / bench; workspace_bytes = every device byte the engine owns beside the caller's weights: the per-shape workspace,
+ * the step-ahead modulation table and the row-pair weight copies (fluxmi_gemm_group_t.W_pairs; 8 GB at Flux-dev, 0 with fluxmi_tuning_t.w_pairs = 0) */
 int fluxmi_engine_workspace_bytes(fluxmi_engine_t* e, long long* bytes);
 int fluxmi_engine_get_buffer(fluxmi_engine_t* e, const char* name, void** ptr, long long* bytes);
 /* Teacher-forced parity hooks (tests only).  run_block: stages [stage_from, stage_to] of DoubleStreamBlock (kind 0; stages
