@@ -24,7 +24,8 @@
 // successor's K-steps were issued before that point, so steps 0 and 1 of the next K loop open without a wait and the stores retire under
 // it; from step 2 on the counted vmcnt(4) is exact again (VMEM operations of a wave retire in order on gfx9).
 // Tile order = the XCD-aware order of the one-tile-per-workgroup kernels: workgroup b sits on XCD b % 8 and walks that XCD's contiguous
-// range of logical tile ids 32 at a time (GROUP_M = 8 rasterisation: 8 x 4 tiles share A / W panels through the XCD's L2).
+// range of logical tile ids 32 at a time (bands of four row tiles, column by column inside a band: 4 x 8 tiles share A / W panels through
+// the XCD's L2; launch_ps).
 #include <type_traits>
 
 #include "gemm_epilogue.h"
@@ -795,7 +796,14 @@ int launch_ps(FluxmiGemmParams& p, hipStream_t s) {
     t += (p.g[i].M + BM - 1) / BM;
   }
   p.tiles_m_total = t;
-  p.group_m = 8;
+  // bands of FOUR row tiles (the one-tile-per-workgroup kernels use 8): an XCD's 32 concurrent tiles are 4 rows x 8 columns, the four A
+  // panels of a band (3.1 MB at K = 3072) stay in its 4 MiB L2 while the band's columns stream by, and the fused-K / V^T tiles of a
+  // launch spread more evenly over the workgroups.  Measured: qkv 145.2 -> 136.5 us, linear1 296.9 -> 292.7 us, step 41.64 -> 41.30 ms
+  // (bands of 2: 307 us and +33 % fetch traffic, of 16: 316 us; profiles/r04_gemm_persist.txt section 11)
+#ifndef PS_GROUP_M
+#define PS_GROUP_M 4
+#endif
+  p.group_m = PS_GROUP_M;
   constexpr int SMEM = 5 * (BM + BN) * 64;  // five ring slots = all 160 KiB (the epilogue borrows the dead ones)
   auto kern = gemm_ps_kernel<FP8, ACT, ESEL, TIMING>;
   static bool attr_set = false;

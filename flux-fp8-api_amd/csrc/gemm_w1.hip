@@ -201,7 +201,12 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
     t += (p.g[i].M + BM - 1) / BM;
   }
   p.tiles_m_total = t;
-  p.group_m = 8;
+  // bands of six row tiles: the step's launches of this kernel have 18 (three equal bands instead of 8 + 8 + 2); in-step A/B of 8 / 4 / 6:
+  // 40.93 / 40.85 / 40.77 ms per step (profiles/r04_gemm_persist.txt section 11)
+#ifndef W1_GROUP_M
+#define W1_GROUP_M 6
+#endif
+  p.group_m = W1_GROUP_M;
   constexpr int SMEM = 4 * (BM + BN) * 64;
   auto kern = gemm_w1_kernel<FP8, ACT, ESEL>;
   static bool attr_set = false;
