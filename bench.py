@@ -352,16 +352,42 @@ def _clock_from_samples(c):
     return out
 
 
+def _pci_bdf(torch, dev):
+    """PCI address of a torch device as sysfs spells it, or None"""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    except Exception:  # noqa
+        return None
+
+
 class _PowerSampler:
     """Board power (and sclk, when hwmon exposes it) sampled from sysfs every 20 ms while a timed repeat runs.  Best effort: absent
-    files -> summary() is None.  Reading sysfs from a host thread does not touch the GPU queue."""
+    files -> summary() is None.  Reading sysfs from a host thread does not touch the GPU queue.
+    `pci_bdf` ("0000:c1:00.0") = the device the timed work runs on: its hwmon directory is the only trustworthy one -- on a multi-GPU node
+    whose other GPUs are hidden from the process, /sys/class/drm/card0 is usually ANOTHER GPU (round 4 read 245 / 320 / 635 W from such
+    neighbours next to 1258 - 1277 W from the right device).  Without a match the first hwmon found is used and the summary says so."""
 
-    def __init__(self):
+    def __init__(self, pci_bdf=None, sysfs_root="/sys"):
         import glob
         import threading
 
         self._threading = threading
-        cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+        self.matched = False
+        cands = []
+        if pci_bdf:
+            base = os.path.join(sysfs_root, "bus", "pci", "devices", pci_bdf.lower(), "hwmon", "hwmon*")
+            cands = sorted(glob.glob(os.path.join(base, "power1_average")) + glob.glob(os.path.join(base, "power1_input")))
+            self.matched = bool(cands)
+        if not cands:
+            base = os.path.join(sysfs_root, "class", "drm", "card*", "device", "hwmon", "hwmon*")
+            cands = sorted(glob.glob(os.path.join(base, "power1_average")) + glob.glob(os.path.join(base, "power1_input")))
+            if pci_bdf:  # a card whose device link resolves to the wanted PCI address
+                for c in cands:
+                    dev = os.path.realpath(os.path.join(os.path.dirname(c), "..", ".."))
+                    if os.path.basename(dev).lower() == pci_bdf.lower():
+                        cands, self.matched = [c], True
+                        break
         self.pfile = cands[0] if cands else None
         f = sorted(glob.glob(os.path.dirname(self.pfile) + "/freq1_input")) if self.pfile else []
         self.ffile = f[0] if f else None
@@ -395,7 +421,11 @@ class _PowerSampler:
     def summary(self):
         if not self.watts:
             return None
-        d = {"source": self.pfile, "samples": len(self.watts), "watts_mean": round(sum(self.watts) / len(self.watts), 1), "watts_max": round(max(self.watts), 1)}
+        d = {"source": self.pfile, "device_matched": self.matched, "samples": len(self.watts), "watts_mean": round(sum(self.watts) / len(self.watts), 1),
+             "watts_max": round(max(self.watts), 1)}
+        if not self.matched:
+            d["note"] = "hwmon directory not matched to the PCI address of the timed device: may belong to another GPU of the node"
+
         if self.mhz:
             d["hwmon_sclk_mhz_mean"] = round(sum(self.mhz) / len(self.mhz), 1)
         return d
@@ -618,7 +648,7 @@ def main():
         # slow box or a throttling one shows up here instead of as unexplained spread.  Board power / sclk from hwmon, when readable.
         R = max(1, args.requests)
         clk = None if dry else torch.zeros((R + 1) * 8 * 3, dtype=torch.int64, device=dev)
-        power = _PowerSampler() if (not dry and rank == 0) else None
+        power = _PowerSampler(_pci_bdf(torch, dev)) if (not dry and rank == 0) else None
         elapsed_each, finite = [], True
         out = None
         for rep in range(R):

@@ -499,3 +499,39 @@ def test_rocprof_summary_reads_csv_kernel_trace(tmp_path):
     assert line[-4:-1] == ["6", "0.6", "0.10"], line  # 6 calls, 600 ns = 0.6 us in total, 0.10 us each
     allk = subprocess.run([sys.executable, os.path.join(root, "tools", "rocprof_summary.py"), str(d)], capture_output=True, text=True, check=True).stdout
     assert [ln for ln in allk.splitlines() if ln.startswith("gemm_pp_kernel<true>")][0].split()[-4] == "7"
+
+
+def test_bench_power_sampler_reads_the_timed_devices_sensor(tmp_path):
+    """bench.py's board-power sampler must read the hwmon directory of the PCI device the work runs on: on a node whose other GPUs are
+    hidden from the process, card0 is usually another GPU (round 4: 245 / 320 / 635 W from neighbours beside 1258 - 1277 W).  Fake sysfs:
+    two devices, card0 = the wrong one; without a match the summary says so."""
+    import importlib.util
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sysfs = tmp_path / "sys"
+    for i, (bdf, uw) in enumerate((("0000:05:00.0", 245_000_000), ("0000:c1:00.0", 1_270_000_000))):
+        hw = sysfs / "bus" / "pci" / "devices" / bdf / "hwmon" / f"hwmon{i + 3}"
+        hw.mkdir(parents=True)
+        (hw / "power1_input").write_text(str(uw))
+        (hw / "freq1_input").write_text("2000000000")
+        card = sysfs / "class" / "drm" / f"card{i}"
+        card.mkdir(parents=True)
+        os.symlink(sysfs / "bus" / "pci" / "devices" / bdf, card / "device")
+
+    def sample(bdf):
+        ps = bench._PowerSampler(bdf, sysfs_root=str(sysfs))
+        ps.start()
+        time.sleep(0.1)
+        ps.stop()
+        return ps.summary()
+
+    right = sample("0000:C1:00.0")
+    assert right["device_matched"] and abs(right["watts_mean"] - 1270.0) < 1e-6 and "0000:c1:00.0" in right["source"] and "note" not in right
+    unknown = sample(None)
+    assert unknown["device_matched"] is False and "note" in unknown  # first hwmon found (card0 = the neighbour), flagged
+    assert abs(unknown["watts_mean"] - 245.0) < 1e-6
+    assert bench._PowerSampler("0000:ff:00.0", sysfs_root=str(tmp_path / "nothing")).summary() is None
