@@ -244,6 +244,12 @@ def test_bench_multi_rank_launch_paths(launcher):
 def test_bench_single_rank_dry_run_and_failed_exchange():
     r, out = _run_bench(["--gpus", "1"])
     assert r.returncode == 0 and len(out) == 1 and out[0]["n_gpus"] == 1 and out[0]["config"]["backend"] is None, r.stderr[-2000:]
+    # the headline is the MEDIAN of `requests` timed repeats of `steps` steps each; every repeat and the range are in the line
+    d = out[0]
+    each = d["ms_per_step_each"]
+    assert d["requests"] == len(each) == 3 and d["ms_per_step"] == sorted(each)[1]
+    assert d["value_range"][0] <= d["value"] <= d["value_range"][1]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 2e-2
     # a rank whose calibration exchange breaks must take the whole job down with a non-zero status (no silent per-rank fallback)
     r, out = _run_bench(["--gpus", "2"], env={"FLUXMI_BENCH_FAIL_RANK": "1"}, timeout=400)
     assert r.returncode != 0 and not out, (r.returncode, r.stdout[-500:])
