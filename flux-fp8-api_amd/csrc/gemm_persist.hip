@@ -13,11 +13,14 @@
 // successor and issues the third and fourth right after its table reads.
 //
 // K loop = gemm_pp.hip's (ring of 64-byte K-steps filled by `buffer_load ... lds`, ONE raw s_barrier per step, counted vmcnt, the two
-// waves of a SIMD in opposite phase) with two changes.  (1) FIVE slots, filled FOUR steps ahead -- all 160 KiB of LDS: the loop is bound
-// by the round trip of its LDS-DMA, not by the matrix pipes (with 3 steps in flight a step takes 0.77 us, with 2 steps 0.91 us, the MFMAs
-// of a step 0.59 us at the clock the chip holds: profiles/r04_gemm_persist.txt; Little's law puts the loaded L2 / Infinity-Cache round
-// trip at ~1.8 us).  Ring slots are run-time values (48 K-steps per tile do not divide by five).  (2) The refill pieces and group 0's
-// next fragments are interleaved with the MFMAs instead of following them as a block.
+// waves of a SIMD in opposite phase) with three changes.  (1) FIVE slots, filled FOUR steps ahead -- all 160 KiB of LDS (with 2 / 3 / 4
+// K-steps in flight a tile's loop takes 85.9 / 62.5 / 62.0 K cycles: beyond three the loop no longer waits for latency).  Ring slots are
+// run-time values (48 K-steps per tile do not divide by five).  (2) The refill pieces and group 0's next fragments are interleaved with
+// the MFMAs instead of following them as a block.  (3) W may arrive in the ROW-PAIR layout (fluxmi_gemm_group_t.W_pairs): what bounded the
+// loop at depth 3+ was L2 LINE traffic -- a 64-byte K-step of a row is half a 128-byte line, the other half is the next K-step's and is
+// fetched again (the 32 KiB L1 does not keep it), so the operand panels crossed L2 -> CU twice per tile and the data movement alone took
+// longer than the MFMAs (ablation builds PS_ABL below; profiles/r04_gemm_persist.txt sections 9 - 10).  With the K-steps of two rows
+// sharing a line every W line is fetched once: 62.4 K -> 56.5 K cycles per tile.
 // vmcnt protocol across tiles: every path of the epilogue converts its accumulators (VALU only), then waits vmcnt(0) ONCE -- as the
 // builtin, so that hipcc's own wait-count pass knows it: with LDS-DMA pending in its model it puts vmcnt(0) in front of every scratch
 // access it cannot prove disjoint, i.e. drains the epilogue's stores block by block -- and only then touches LDS and stores.  The
