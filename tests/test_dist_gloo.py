@@ -249,7 +249,8 @@ def test_bench_single_rank_dry_run_and_failed_exchange():
     each = d["ms_per_step_each"]
     assert d["requests"] == len(each) == 3 and d["ms_per_step"] == sorted(each)[1]
     assert d["value_range"][0] <= d["value"] <= d["value_range"][1]
-    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 2e-2
+    # value = steps / time of the median request (ms_per_step is rounded to a microsecond: the stub engine's steps take ~20 of them)
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] <= 0.0006 / d["ms_per_step"] + 1e-3
     # a rank whose calibration exchange breaks must take the whole job down with a non-zero status (no silent per-rank fallback)
     r, out = _run_bench(["--gpus", "2"], env={"FLUXMI_BENCH_FAIL_RANK": "1"}, timeout=400)
     assert r.returncode != 0 and not out, (r.returncode, r.stdout[-500:])
