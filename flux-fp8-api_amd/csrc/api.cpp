@@ -303,6 +303,10 @@ int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void
 int fluxmi_pair_rows(const void* in, void* out, int rows, long long row_bytes, void* stream) {
   return fluxmi_k_pair_rows(in, out, rows, row_bytes, (hipStream_t)stream);
 }
+int fluxmi_attention_plan(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces) {
+  return fluxmi_attn_plan_export(B, L, H, n_per_x, full_per_x, npieces, pieces);
+}
+
 int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, const void* qn_scale0, const void* qn_scale1, const void* K,
                           const void* VT, void* out, long long ld_out, int col_off, int out_fp8, const float* q_scale0,
                           const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, int k_f16, void* stream) {

@@ -31,6 +31,12 @@
 // Correctness of the deferred rescale with a pending tile: when the branch fires with f = 2^((m_old - m_new) c), everything still at
 // the old max is scaled exactly once -- O (tiles <= j-2), l (tiles <= j-1) and the bf16 fragments of P_{j-1} (re-rounded) -- and
 // P_j is exponentiated after the decision.  tests/test_ops_gpu.py forces the branch (spiked key rows) and sweeps THR.
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "attention_common.h"
 
 namespace {
@@ -68,11 +74,35 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hi = lane >> 5;
   const int nqb = (a.L + QB - 1) / QB;
-  if ((int)blockIdx.x >= nqb * a.H * a.B) {  // extra workgroups behind the grid: weight prefetch for the launches that follow
-    fluxmi_prefetch_ranges(a.pf, (int)blockIdx.x - nqb * a.H * a.B, a.pf.wgs, tid, NW2 * 64);
+  const int ntiles_all = (a.L + KT - 1) / KT;
+  // ---- which task, which of its key tiles: a whole task, or (balanced grid, AttnSplit) one piece of a leftover task ---------------------
+  const bool split = FOLD && a.sp.on;
+  const int main_wgs = split ? 8 * (a.sp.full_per_x + a.sp.npieces) : nqb * a.H * a.B;
+  if ((int)blockIdx.x >= main_wgs) {  // extra workgroups behind the grid: weight prefetch for the launches that follow
+    fluxmi_prefetch_ranges(a.pf, (int)blockIdx.x - main_wgs, a.pf.wgs, tid, NW2 * 64);
     return;
   }
-  const int lid = xcd_remap(blockIdx.x, nqb * a.H * a.B);  // whole heads per XCD: a head's K / V^T (2.4 MB at L = 4608) is fetched into one 4 MiB L2 once and shared by its q-blocks
+  int lid, tb = 0, ntiles = ntiles_all;
+  AttnPiece pc = {0, 0, 1, 0, 0, 0};
+  if (split) {
+    const int x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
+    lid = x * a.sp.n_per_x + i;
+    if (i >= a.sp.full_per_x) {
+      // entry i - full_per_x of the launch-ordered piece table, one 8-byte scalar load from the kernarg segment (indexing `a` itself
+      // with a run-time index would make hipcc copy the whole argument struct to scratch)
+      typedef const __attribute__((address_space(4))) unsigned long long* kern_u64;
+      const unsigned long long raw = ((kern_u64)((const __attribute__((address_space(4))) unsigned char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                 __builtin_offsetof(AttnArgs, sp.pieces)))[i - a.sp.full_per_x];
+      pc = __builtin_bit_cast(AttnPiece, raw);
+      lid = x * a.sp.n_per_x + a.sp.full_per_x + pc.tloc;
+      tb = pc.tb;
+      ntiles = pc.len;
+      if (a.sp.pf_fold && a.pf.n > 0) fluxmi_prefetch_ranges(a.pf, (int)blockIdx.x - 8 * a.sp.full_per_x, 8 * a.sp.npieces, tid, NW2 * 64);
+    }
+  } else {
+    lid = xcd_remap(blockIdx.x, nqb * a.H * a.B);  // whole heads per XCD: a head's K / V^T (2.4 MB at L = 4608) is fetched into one 4 MiB L2 once and shared by its q-blocks
+  }
+  const int L_rel = a.L - tb * KT;  // keys from this piece's first tile to the end of the sequence (masking of a ragged last tile)
   const int bhid = lid / nqb;
   const int h = bhid % a.H, b = bhid / a.H;
   const int q0 = (lid - bhid * nqb) * QB + wave * 32;
@@ -132,7 +162,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kv0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        st[t][r] = key < a.L ? st[t][r] : -1e30f;
+        st[t][r] = key < L_rel ? st[t][r] : -1e30f;
       }
   };
   auto finish_max = [&](float mx) -> float {  // the other 32 keys of the row sit in lane ^ 32
@@ -141,8 +171,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     return fmaxf(__uint_as_float(sw2[0]), __uint_as_float(sw2[1]));
   };
 
-  const int ntiles = (a.L + KT - 1) / KT;
-  const bool ragged = (a.L % KT) != 0;
+  const bool ragged = (a.L % KT) != 0 && tb + ntiles == ntiles_all;  // this piece ends with the sequence's partial tile
 
   // ---- prologue: K0 K1 V0 K2 V1 K3 in flight (step j issues K_{j+4} then V_{j+2}); S_0 and its row max ---------------------------
   // Every issue is unconditional: a tile past the end of the sequence reads zeros (descriptor bounds check) or harmless bytes of
@@ -150,8 +179,8 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   // has no branch (a wave-uniform branch per refill split the step into basic blocks and let MachineSink drag the pinned VALU
   // work out of its MFMA gaps).
   {
-    auto iss_k = [&](int t) { dma_k(t, t * KT, 0); dma_k(t, t * KT, 1); };
-    auto iss_v = [&](int t) { dma_v(t, t * KT, 0); dma_v(t, t * KT, 1); };
+    auto iss_k = [&](int t) { dma_k(t, (tb + t) * KT, 0); dma_k(t, (tb + t) * KT, 1); };
+    auto iss_v = [&](int t) { dma_v(t, (tb + t) * KT, 0); dma_v(t, (tb + t) * KT, 1); };
     if constexpr (MIDBAR) { iss_k(0); iss_k(1); iss_k(2); iss_v(0); iss_k(3); }
     else { iss_k(0); iss_k(1); iss_v(0); iss_k(2); iss_v(1); iss_k(3); }
   }
@@ -315,14 +344,14 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
         gapwork(std::integral_constant<int, s>{});
         // refills ride in the QK^T half (in the PV half: -0.4 %, profiles/r02_attention_ab.txt)
         if constexpr (MIDBAR) {
-          if constexpr (s == 3) dma_v(KS, (j + 1) * KT, 0);  // V_{j+1} into slot (j + 1) % 4 (held V_{j-3})
-          if constexpr (s == 7) dma_v(KS, (j + 1) * KT, 1);
+          if constexpr (s == 3) dma_v(KS, (tb + j + 1) * KT, 0);  // V_{j+1} into slot (j + 1) % 4 (held V_{j-3})
+          if constexpr (s == 7) dma_v(KS, (tb + j + 1) * KT, 1);
           if constexpr (!FIRST && s >= 12) vpre[s - 12] = v_frag(VS, 0, s - 12);
         } else {
-          if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
-          if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
-          if constexpr (s == 11) dma_v(VR, (j + 2) * KT, 0);
-          if constexpr (s == 15) dma_v(VR, (j + 2) * KT, 1);
+          if constexpr (s == 3) dma_k(PAR, (tb + j + 4) * KT, 0);
+          if constexpr (s == 7) dma_k(PAR, (tb + j + 4) * KT, 1);
+          if constexpr (s == 11) dma_v(VR, (tb + j + 2) * KT, 0);
+          if constexpr (s == 15) dma_v(VR, (tb + j + 2) * KT, 1);
         }
         fence();
       });
@@ -343,8 +372,8 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     auto midbar_pv_gap = [&](auto SC) {
       constexpr int s = decltype(SC)::value;
       if constexpr (MIDBAR) {
-        if constexpr (s == 3) dma_k(PAR, (j + 4) * KT, 0);
-        if constexpr (s == 7) dma_k(PAR, (j + 4) * KT, 1);
+        if constexpr (s == 3) dma_k(PAR, (tb + j + 4) * KT, 0);
+        if constexpr (s == 7) dma_k(PAR, (tb + j + 4) * KT, 1);
         if constexpr (s >= 12) kpre[(s - 12) >> 1][(s - 12) & 1] = k_frag(KSN, (s - 12) >> 1, (s - 12) & 1);
       }
     };
@@ -416,20 +445,186 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   }
   const float l_part = (l4[0] + l4[1]) + (l4[2] + l4[3]);
   const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
-  const float inv = 1.0f / l_tot;
-  store_o<FMT>(a, o, inv, b, h, qrow, hi);
+  if (ntiles == ntiles_all) {  // the piece is the task
+    const float inv = 1.0f / l_tot;
+    store_o<FMT>(a, o, inv, b, h, qrow, hi);
+  } else if constexpr (FOLD) {
+    // ---- a piece of a task: (O, m, l) -> its slot; the piece that arrives last merges all pieces of the task in piece order -------------
+    const int x = (int)blockIdx.x & 7;
+    float* slot0 = a.sp.part + (size_t)(x * ATTN_MAX_PIECES + pc.base) * ATTN_PART_FLOATS;  // the task's first piece; its others follow
+    {
+      float* sl = slot0 + (size_t)pc.pidx * ATTN_PART_FLOATS;
+      v4f* po = (v4f*)sl + (wave * 16) * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v4f v;
+        v[0] = o[i >> 2][(i & 3) * 4 + 0]; v[1] = o[i >> 2][(i & 3) * 4 + 1]; v[2] = o[i >> 2][(i & 3) * 4 + 2]; v[3] = o[i >> 2][(i & 3) * 4 + 3];
+        po[i * 64] = v;
+      }
+      v2f ml;
+      ml[0] = m_cur; ml[1] = l_tot;
+      ((v2f*)(sl + ATTN_PART_O_FLOATS))[wave * 64 + lane] = ml;
+    }
+    __threadfence();  // release: the partial is visible to the whole device before the arrival is counted
+    __syncthreads();
+    unsigned* cnt = a.sp.cnt + x * 32 + pc.tloc;
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      *(volatile int*)smem = old == (unsigned)(pc.np - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (*(volatile int*)smem) {
+      __threadfence();  // acquire: the other pieces' partials
+      const int np = pc.np;
+      float M = -3.0e38f;
+      for (int pi = 0; pi < np; ++pi) M = fmaxf(M, ((const v2f*)(slot0 + (size_t)pi * ATTN_PART_FLOATS + ATTN_PART_O_FLOATS))[wave * 64 + lane][0]);
+      v16f acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      float lsum = 0.f;
+      for (int pi = 0; pi < np; ++pi) {
+        const float* sl = slot0 + (size_t)pi * ATTN_PART_FLOATS;
+        const v2f ml = ((const v2f*)(sl + ATTN_PART_O_FLOATS))[wave * 64 + lane];
+        const float f = __builtin_amdgcn_exp2f(ml[0] - M);
+        lsum = __builtin_fmaf(ml[1], f, lsum);
+        const v4f* po = (const v4f*)sl + (wave * 16) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const v4f v = po[i * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i >> 2][(i & 3) * 4 + e] = __builtin_fmaf(v[e], f, acc[i >> 2][(i & 3) * 4 + e]);
+        }
+      }
+      if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero between launches
+      store_o<FMT>(a, acc, 1.0f / lsum, b, h, qrow, hi);
+    }
+  }
 }
 
 }  // namespace
 
-template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(const AttnArgs& a, int fmt, hipStream_t s) {
+// ---- balanced grid: plan + scratch -----------------------------------------------------------------------------------------------------
+// first tile (in one XCD's leftover tile sequence [0, T)) of bin k: equal shares, edges within ATTN_SPLIT_SNAP tiles of a task edge moved onto it
+static int attn_bin_start(int k, int T, int nb, int ntiles) {
+  int s = (int)((long long)k * T / nb);
+  const int r = s % ntiles;
+  if (r <= ATTN_SPLIT_SNAP) s -= r;
+  else if (ntiles - r <= ATTN_SPLIT_SNAP) s += ntiles - r;
+  return s;
+}
+// Pure arithmetic on (tasks, tiles per task).  Off unless the leftover round is worth splitting: tasks fill the XCDs evenly, 1 <= rem <= 26
+// of an XCD's 32 CUs (a fuller last round gains < 10 %), >= 16 key tiles per task, bins of >= 8 tiles, no task in more than
+// ATTN_SPLIT_MAXP pieces.
+AttnSplit fluxmi_attn_plan(int tasks, int ntiles, int cus) {
+  AttnSplit sp;
+  memset(&sp, 0, sizeof(sp));
+  if (cus != 256 || tasks % 8 || ntiles < 16 || ntiles > 65535) return sp;
+  const int n = tasks / 8, rem = n % 32;
+  if (rem == 0 || rem > 26) return sp;
+  const int T = rem * ntiles;
+  int nb = std::min(32, rem * 4);
+  while (nb > rem && T / nb < 8) --nb;
+  if (T / nb < 8) return sp;
+  // canonical pieces (ascending tile position) and, per piece, whether it is the first of its bin
+  struct P { int tloc, tb, len, first; };
+  std::vector<P> ps;
+  for (int k = 0; k < nb; ++k) {
+    int pos = attn_bin_start(k, T, nb, ntiles);
+    const int end = k + 1 == nb ? T : attn_bin_start(k + 1, T, nb, ntiles);
+    for (int first = 1; pos < end; first = 0) {
+      const int t = pos / ntiles, e = std::min(end, (t + 1) * ntiles);
+      ps.push_back(P{t, pos - t * ntiles, e - pos, first});
+      pos = e;
+    }
+  }
+  if ((int)ps.size() > ATTN_MAX_PIECES) return sp;
+  std::vector<AttnPiece> canon(ps.size());
+  for (size_t c = 0; c < ps.size(); ++c) {
+    size_t b = c, e = c;
+    while (b > 0 && ps[b - 1].tloc == ps[c].tloc) --b;
+    while (e + 1 < ps.size() && ps[e + 1].tloc == ps[c].tloc) ++e;
+    if (e - b + 1 > (size_t)ATTN_SPLIT_MAXP) return sp;
+    canon[c] = AttnPiece{(unsigned char)ps[c].tloc, (unsigned char)(c - b), (unsigned char)(e - b + 1), (unsigned char)b, (unsigned short)ps[c].tb,
+                         (unsigned short)ps[c].len};
+  }
+  // launch order: the bins' first pieces, longest first, then the others, longest first (stable: equal lengths keep their tile order)
+  std::vector<int> order(ps.size());
+  for (size_t c = 0; c < ps.size(); ++c) order[c] = (int)c;
+  std::stable_sort(order.begin(), order.end(), [&](int u, int v) {
+    if (ps[u].first != ps[v].first) return ps[u].first > ps[v].first;
+    return ps[u].len > ps[v].len;
+  });
+  for (size_t c = 0; c < ps.size(); ++c) sp.pieces[c] = canon[order[c]];
+  sp.on = 1; sp.n_per_x = n; sp.full_per_x = n - rem; sp.npieces = (int)ps.size();
+  return sp;
+}
+
+namespace {
+// scratch of the balanced grid: partial (O, m, l) slots + the arrival counters (zeroed once, kept zero by the kernel).  Per (device, stream)
+// like the split-K scratch (gemm_pp.hip), never allocated under stream capture -- the launch then simply runs the unsplit grid.
+thread_local void* t_attn_override = nullptr;
+std::mutex g_attn_mu;
+std::map<std::pair<int, hipStream_t>, void*> g_attn_ws;
+void* attn_workspace(hipStream_t s) {
+  if (t_attn_override) return t_attn_override;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_attn_mu);
+  auto it = g_attn_ws.find({dev, s});
+  if (it == g_attn_ws.end()) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s && hipStreamIsCapturing(s, &cap) != hipSuccess) return nullptr;
+    if (cap != hipStreamCaptureStatusNone) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, ATTN_SPLIT_WS_BYTES) != hipSuccess || hipMemset(p, 0, ATTN_SPLIT_WS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    it = g_attn_ws.emplace(std::make_pair(dev, s), p).first;
+  }
+  return it->second;
+}
+}  // namespace
+void fluxmi_set_attn_scratch(void* p) { t_attn_override = p; }
+int fluxmi_attn_plan_any(int B, int L, int H) { return fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256).on; }
+int fluxmi_attn_plan_export(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces) {
+  if (B < 1 || L < 1 || H < 1) return 0;
+  const AttnSplit sp = fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256);
+  if (!sp.on) return 0;
+  if (n_per_x) *n_per_x = sp.n_per_x;
+  if (full_per_x) *full_per_x = sp.full_per_x;
+  if (npieces) *npieces = sp.npieces;
+  if (pieces) memcpy(pieces, sp.pieces, sizeof(AttnPiece) * sp.npieces);
+  return 1;
+}
+int fluxmi_attn_split_on(int B, int L, int H) { return fluxmi_tuning().attn_split ? fluxmi_attn_plan_any(B, L, H) : 0; }
+
+template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArgs a, int fmt, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
     FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, MIDBAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
     FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, MIDBAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * A_STAGE));
     attr = true;
   }
-  const dim3 grid(((a.L + 255) / 256) * a.H * a.B + (a.pf.n > 0 ? a.pf.wgs : 0));
+  memset(&a.sp, 0, sizeof(a.sp));
+  const int tasks = ((a.L + 255) / 256) * a.H * a.B;
+  const fluxmi_tuning_t tun = fluxmi_tuning();
+  if (FOLD && tun.attn_split) {
+    AttnSplit sp = fluxmi_attn_plan(tasks, (a.L + KT - 1) / KT, 256);
+    void* ws = sp.on ? attn_workspace(s) : nullptr;
+    if (sp.on && ws) {
+      sp.part = (float*)ws;
+      sp.cnt = (unsigned*)((char*)ws + (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4);
+      // no CU idles in the last round any more: the weight prefetch rides in front of the piece workgroups (attn_split = 1) or is dropped (2)
+      sp.pf_fold = tun.attn_split == 1;
+      a.sp = sp;
+      a.pf.wgs = 0;
+      if (!sp.pf_fold) a.pf.n = 0;
+    }
+  }
+  const dim3 grid((a.sp.on ? 8 * (a.sp.full_per_x + a.sp.npieces) : tasks) + (a.pf.n > 0 ? a.pf.wgs : 0));
   if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, a);
   else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, a);
   FLUXMI_LAUNCH_CHECK();

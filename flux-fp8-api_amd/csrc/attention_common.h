@@ -6,6 +6,41 @@
 #include "common.h"
 #include "fluxmi_internal.h"
 
+// ---- balanced grid (round 5) ------------------------------------------------------------------------------------------------------
+// One workgroup = one TASK = 256 query rows of one head over all key tiles; the chip runs 256 of them at a time (128 KiB of LDS each: one
+// per CU), so 432 tasks (Flux-dev 1024^2: 24 heads x 18 row blocks) take TWO rounds with 80 CUs idle in the second, and 264 (768^2) take
+// two rounds for 1.03 rounds of work.  With `on`, every XCD (32 CUs; whole heads per XCD as before) runs its first `full_per_x` tasks
+// whole and cuts the key range of the remaining `rem` (< 32) into PIECES, one workgroup each: the concatenated tile sequence rem x ntiles
+// is divided into `nb` contiguous bins of equal length -- the work of one CU -- and a bin that straddles a task boundary is two pieces.
+// The pieces are launched longest first (first pieces of the bins, then the second pieces, each group by descending length): the CU that
+// finishes the shortest first piece picks up the longest second piece, so every CU ends up with one bin's worth of tiles without any
+// workgroup looping over pieces (a loop around the kernel body keeps the next piece's arguments alive across the step loop, which sits
+// at exactly 256 VGPRs: 121 spilled registers, measured in round 5).  A piece that is not a whole task writes (O, m, l) in fp32 to its
+// slot of `part`; the piece that arrives LAST at the task's counter merges all of them in piece order (log-sum-exp in the exp2 domain:
+// the result does not depend on which piece arrives last) and stores the rows.
+// Grid = 8 x (full_per_x + npieces) workgroups, workgroup b runs on XCD b % 8.
+constexpr int ATTN_MAX_PIECES = 64;                                   // per XCD: at most two per CU
+struct AttnPiece { unsigned char tloc, pidx, np, base; unsigned short tb, len; };  // task (leftover index), piece of np, canonical index of the task's first piece, tiles [tb, tb + len)
+struct AttnSplit {
+  int on;
+  int n_per_x;     // tasks per XCD (= tasks / 8)
+  int full_per_x;  // of which run whole (a multiple of 32)
+  int npieces;     // pieces per XCD (launch order = order of `pieces`)
+  int pf_fold;     // 1: the weight prefetch rides in front of the piece workgroups instead of on extra workgroups (no CU idles any more)
+  int pad;
+  float* part;     // [8][ATTN_MAX_PIECES] slots of ATTN_PART_FLOATS floats (slot = canonical piece index)
+  unsigned* cnt;   // [8][32] arrival counters, zero between launches (the merging piece resets its task's)
+  AttnPiece pieces[ATTN_MAX_PIECES];
+};
+static_assert(sizeof(AttnPiece) == 8, "AttnPiece is read as one 8-byte scalar load");
+constexpr int ATTN_PART_O_FLOATS = 8 * 16 * 64 * 4;                  // per slot: [wave][i < 16][lane] float4 = the 64 accumulator floats of every lane
+constexpr int ATTN_PART_FLOATS = ATTN_PART_O_FLOATS + 8 * 64 * 2;    // + [wave][lane] (m, l)
+constexpr int ATTN_SPLIT_SNAP = 3;                                    // bin edges within 3 tiles of a task edge move onto it (no 1..3-tile pieces)
+constexpr int ATTN_SPLIT_MAXP = 8;                                    // pieces per task the plan accepts
+constexpr size_t ATTN_SPLIT_WS_BYTES = (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4 + 8 * 32 * 4;
+static_assert(ATTN_SPLIT_WS_BYTES == FLUXMI_ATTN_SPLIT_WS_BYTES, "scratch size of the balanced grid (fluxmi_internal.h)");
+AttnSplit fluxmi_attn_plan(int tasks, int ntiles, int cus);
+
 // launch arguments of both attention kernels
 struct AttnArgs {
   const u16* Q; const u16* K; const u16* VT;
@@ -19,6 +54,7 @@ struct AttnArgs {
   float defer_log2;  // the running max is updated (O, l, pending P rescaled) only when a row max grew by more than 2^defer_log2 (exp2 domain)
   int k_f16;  // K holds fp16: the folded kernel (scale * log2 e in Q, -max in the accumulator init), f16 MFMAs for QK^T
   FluxmiPrefetch pf;  // weights of the following GEMMs, read by pf.wgs extra workgroups behind the attention grid (fluxmi_internal.h)
+  AttnSplit sp;       // balanced grid: the last, partial round of workgroups split along the keys (see AttnSplit)
   int abl;  // A/B knobs (FLUXMI_ATTN_ABL, read per call): 2 = no barrier in the 8-wave kernel (timing only), 8 = fp8 output through 16 x 4 B
             // stores per lane (also taken when the output rows are not 16-byte aligned)
 };

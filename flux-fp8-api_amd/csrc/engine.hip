@@ -810,12 +810,21 @@ bool needs_splitk(E* e) {
   return false;
 }
 // the engine's split-K scratch for every launch of this thread while an engine entry point runs
+// ... and its scratch for attention's balanced grid; a prefetch left pending by an error return between set_pf and the launch that
+// would have consumed it is dropped here, on entry and on exit (it points into weights the caller may free afterwards)
 struct SplitkScope {
   explicit SplitkScope(E* e) {
     auto it = e->bufs.find("splitk");
     fluxmi_set_splitk_scratch(it != e->bufs.end() && it->second.n >= FLUXMI_SPLITK_WS_BYTES ? (float*)it->second.p : nullptr);
+    auto ia = e->bufs.find("attn_part");
+    fluxmi_set_attn_scratch(ia != e->bufs.end() && ia->second.n >= FLUXMI_ATTN_SPLIT_WS_BYTES ? ia->second.p : nullptr);
+    fluxmi_set_prefetch(nullptr);
   }
-  ~SplitkScope() { fluxmi_set_splitk_scratch(nullptr); }
+  ~SplitkScope() {
+    fluxmi_set_splitk_scratch(nullptr);
+    fluxmi_set_attn_scratch(nullptr);
+    fluxmi_set_prefetch(nullptr);
+  }
 };
 
 void free_ws(E* e) {
@@ -975,6 +984,9 @@ int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void*
         // split-K partial tiles of the bf16 small-M launches (api.cpp: bf16 operands, >= 192 K-steps): owned by the engine, because its step
         // graph is captured on a private stream and replayed on the caller's -- a scratch keyed by stream would be nobody's
         {"splitk", needs_splitk(e) ? FLUXMI_SPLITK_WS_BYTES : 256},
+        // partial softmax states + arrival counters of attention's balanced grid (attention2.hip, AttnSplit; 69 MB), when this shape uses it.
+        // Zeroed with the rest of the workspace below; the kernel leaves the counters at zero.
+        {"attn_part", fluxmi_attn_plan_any(B, L, e->d.heads) ? FLUXMI_ATTN_SPLIT_WS_BYTES : 256},
     };
     size_t total = 0;
     for (auto& it : items) total += (it.bytes + 255) & ~(size_t)255;

@@ -101,6 +101,14 @@ int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int 
 // its step graph is captured on a private stream and replayed on the caller's, so the scratch must belong to the engine, not to a stream.
 constexpr size_t FLUXMI_SPLITK_WS_BYTES = (size_t)256 << 20;
 void fluxmi_set_splitk_scratch(float* p);
+// scratch of attention's balanced grid (attention2.hip, AttnSplit: partial softmax states of the key bins + arrival counters, which must be
+// ZERO when handed over and are left zero by every launch): thread-local like the split-K scratch, an engine owns one; nullptr = the library's own
+// per-(device, stream) buffer.  fluxmi_attn_split_on: does a launch of this shape use the balanced grid under the current tuning?
+constexpr size_t FLUXMI_ATTN_SPLIT_WS_BYTES = (size_t)8 * 64 * (8 * 16 * 64 * 4 + 8 * 64 * 2) * 4 + 8 * 32 * 4;
+void fluxmi_set_attn_scratch(void* p);
+int fluxmi_attn_split_on(int B, int L, int H);
+int fluxmi_attn_plan_any(int B, int L, int H);
+int fluxmi_attn_plan_export(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces);  // fluxmi_attention_plan  // the same for ANY tuning (what an engine sizes its workspace by: the knob may change later)
 // tile choice + (when it pays) the split of a grouped launch into a 256x256 and a 128x128 launch; any number of groups
 int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs, int n, int N, int K, int is_fp8, int act_fmt, int epi, hipStream_t s);
 int fluxmi_launch_gemv(const FluxmiGemvLayer* layers_dev, FluxmiGemvLayer* layers_host, int n_layers, int B, int total_blocks,

@@ -35,15 +35,22 @@ int validate(const fluxmi_tuning_t& t) {
                  "tuning: attn_defer_log2 %g outside [0, 16]", (double)t.attn_defer_log2);
   FLUXMI_REQUIRE(t.fuse_kv >= 0 && t.fuse_kv <= 2, "tuning: fuse_kv %d (0..2)", t.fuse_kv);
   FLUXMI_REQUIRE(t.ln_variant >= 1 && t.ln_variant <= 3, "tuning: ln_variant %d (1 = wave per row, 2 = streaming, 3 = streaming, two workgroups per CU)", t.ln_variant);
+  // the remaining switches: a value outside the documented set would be read as "on" by some call sites and as a variant number by others
+  struct { const char* name; int v, lo, hi; } sw[] = {
+      {"gemm_splitk", t.gemm_splitk, 0, 1}, {"gemm_hybrid", t.gemm_hybrid, 0, 1}, {"gemm_esel", t.gemm_esel, 0, 1}, {"gemm_persist", t.gemm_persist, 0, 2},
+      {"attn_var", t.attn_var, 0, 3},       {"attn_abl", t.attn_abl, 0, 15},      {"attn_f16k", t.attn_f16k, 0, 1}, {"qlut", t.qlut, 0, 1},
+      {"roctx", t.roctx, 0, 1},             {"prefetch", t.prefetch, 0, 2},       {"w_pairs", t.w_pairs, 0, 1},     {"log", t.log, 0, 1},
+      {"attn_split", t.attn_split, 0, 2}};
+  for (const auto& k : sw) FLUXMI_REQUIRE(k.v >= k.lo && k.v <= k.hi, "tuning: %s %d outside [%d, %d]", k.name, k.v, k.lo, k.hi);
   return 0;
 }
 
 void log_tuning(const fluxmi_tuning_t& t, const char* why) {
   fprintf(stderr,
           "fluxmi tuning (%s): gemm_cfg=%d splitk=%d hybrid=%d esel=%d persist=%d | attn var=%d abl=%d defer_log2=%g f16k=%d | "
-          "fuse_kv=%d qlut=%d ln=%d roctx=%d prefetch=%d w_pairs=%d\n",
+          "fuse_kv=%d qlut=%d ln=%d roctx=%d prefetch=%d w_pairs=%d attn_split=%d\n",
           why, t.gemm_cfg, t.gemm_splitk, t.gemm_hybrid, t.gemm_esel, t.gemm_persist, t.attn_var, t.attn_abl,
-          (double)t.attn_defer_log2, t.attn_f16k, t.fuse_kv, t.qlut, t.ln_variant, t.roctx, t.prefetch, t.w_pairs);
+          (double)t.attn_defer_log2, t.attn_f16k, t.fuse_kv, t.qlut, t.ln_variant, t.roctx, t.prefetch, t.w_pairs, t.attn_split);
 }
 
 void init_from_env() {
@@ -69,12 +76,17 @@ void init_from_env() {
   t.ln_variant = env_int("FLUXMI_LN_V", 2);
   t.roctx = env_int("FLUXMI_ROCTX", 0);
   t.log = env_int("FLUXMI_LOG", 0);
+  t.attn_split = env_int("FLUXMI_ATTN_SPLIT", 1);
   if (validate(t) != 0) {  // a bad environment must not silently change the arithmetic: say so and keep the compiled defaults for that knob
     fprintf(stderr, "fluxmi: ignoring invalid FLUXMI_* environment (%s)\n", fluxmi_last_error());
     if (!(isfinite(t.attn_defer_log2) && t.attn_defer_log2 >= 0.f && t.attn_defer_log2 <= 16.f)) t.attn_defer_log2 = 8.0f;
     if (t.fuse_kv < 0 || t.fuse_kv > 2) t.fuse_kv = 2;
     if (t.ln_variant < 1 || t.ln_variant > 3) t.ln_variant = 2;
     if (t.gemm_cfg < -1 || t.gemm_cfg > 200) t.gemm_cfg = -1;
+    auto fix = [](int& v, int lo, int hi, int dflt) { if (v < lo || v > hi) v = dflt; };
+    fix(t.gemm_splitk, 0, 1, 1); fix(t.gemm_hybrid, 0, 1, 1); fix(t.gemm_esel, 0, 1, 1); fix(t.gemm_persist, 0, 2, 1);
+    fix(t.attn_var, 0, 3, 0); fix(t.attn_abl, 0, 15, 0); fix(t.attn_f16k, 0, 1, 1); fix(t.qlut, 0, 1, 1); fix(t.roctx, 0, 1, 0);
+    fix(t.prefetch, 0, 2, 1); fix(t.w_pairs, 0, 1, 1); fix(t.log, 0, 1, 0); fix(t.attn_split, 0, 2, 1);
   }
   g_tuning = t;
   if (t.log) log_tuning(t, "environment");

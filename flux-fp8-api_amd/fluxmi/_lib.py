@@ -42,7 +42,7 @@ class Tuning(C.Structure):
     _fields_ = [
         ("struct_size", i32), ("gemm_cfg", i32), ("gemm_splitk", i32), ("gemm_hybrid", i32), ("gemm_esel", i32), ("gemm_persist", i32),
         ("attn_var", i32), ("attn_abl", i32), ("attn_defer_log2", f32), ("attn_f16k", i32), ("fuse_kv", i32), ("qlut", i32),
-        ("ln_variant", i32), ("roctx", i32), ("prefetch", i32), ("w_pairs", i32), ("log", i32),
+        ("ln_variant", i32), ("roctx", i32), ("prefetch", i32), ("w_pairs", i32), ("log", i32), ("attn_split", i32),
     ]
 
 
@@ -91,6 +91,7 @@ _SIGS = {
     "fluxmi_act_mul": ([vp, vp, i32, i32, i64, i64, i32, vp], i32),
     "fluxmi_text_attention": ([vp, vp, i64, vp, i64, vp, i64, vp, i32, vp, C.c_float, i32, i32, i32, i32, vp], i32),
     "fluxmi_attention": ([vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "fluxmi_attention_plan": ([i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_ulonglong)], i32),
     "fluxmi_attention_rawq": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_timestep_embedding": ([vp, vp, vp, i32, i32, f32, vp], i32),
     "fluxmi_euler": ([vp, vp, vp, vp, i64, vp], i32),
@@ -119,7 +120,7 @@ for _name, (_args, _res) in _SIGS.items():
     _fn.argtypes = _args
     _fn.restype = _res
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 if lib.fluxmi_abi_version() != ABI_VERSION:
     raise ImportError(f"fluxmi: ABI version mismatch ({lib.fluxmi_abi_version()} != {ABI_VERSION})")
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FLUXMI_ABI_VERSION 3
+#define FLUXMI_ABI_VERSION 4
 
 /* fp8 format codes (torch.float8_e4m3fn / torch.float8_e5m2, float8_quantize.py:39,43) */
 #define FLUXMI_E4M3 0
@@ -96,7 +96,7 @@ typedef struct fluxmi_gemm_group {
 const char* fluxmi_last_error(void);
 int fluxmi_abi_version(void);
 
-/* ---- kernel-selection knobs (ABI 3) --------------------------------------------------------------------------------------------
+/* ---- kernel-selection knobs (ABI 3; attn_split: ABI 4) --------------------------------------------------------------------------------------------
  * The reference has no counterpart (its only switches are the ModelSpec flags of util.py:40-77); these choose between kernels /
  * fusion levels that compute the same results.  They are resolved ONCE: the first call that needs a knob parses the FLUXMI_*
  * environment variables named below into this struct (csrc/tuning.cpp -- the only getenv site of the library);
@@ -122,6 +122,11 @@ typedef struct fluxmi_tuning {
   int w_pairs;           /* FLUXMI_W_PAIRS       1: the engine keeps a row-pair copy of the F8Linear weights its persistent GEMM launches read
                                                  (fluxmi_gemm_group_t.W_pairs: every L2 line of W fetched once per tile instead of twice) */
   int log;               /* FLUXMI_LOG           1: print the struct to stderr when it is resolved / set / an engine is created */
+  int attn_split;        /* FLUXMI_ATTN_SPLIT    1 (default): attention launches whose workgroups leave a partial last round (432 on 256 CUs at
+                                                 Flux-dev 1024^2) cut the key range of that round's tasks into one bin per CU and merge the partial
+                                                 softmax states (fp32 log-sum-exp; deterministic): every CU finishes together; the weight prefetch
+                                                 of such a launch rides in front of the bin workgroups.  2 = the same without that prefetch,
+                                                 0 = one workgroup per task (rounds 1 - 4) */
 } fluxmi_tuning_t;
 int fluxmi_get_tuning(fluxmi_tuning_t* out);
 int fluxmi_set_tuning(const fluxmi_tuning_t* in); /* validates every field (non-zero + fluxmi_last_error on a bad value) */
@@ -210,13 +215,23 @@ int fluxmi_qkv_rope(const void* qkv, long long ld, const void* pe, const void* q
 /* softmax(QK^T/sqrt(128))V -> [B,L,H*128] (bf16, or fp8 with the consumer's input scale)   flux_model.py:41-45
  * k_f16 != 0: K holds fp16 (fluxmi_qkv_rope(k_f16 = 1)).  The kernel then multiplies Q by 128^-0.5 * log2(e) while it builds its
  * fragments (fp16, 2^-11 relative rounding), runs QK^T on the f16 MFMA and starts every score accumulator from minus the running
- * maximum, so a score costs one exp2 instead of fma + exp2 (+4.7 % at L = 4608).  Q and V^T are bf16 either way.  Environment, read
- * per call: FLUXMI_ATTN_V=4 runs fp16-K calls on the 4-wave kernel (csrc/attention4.hip) instead of the 8-wave one (attention2.hip),
- * FLUXMI_ATTN_V=3 on the 8-wave kernel with its per-tile barrier between the two MFMA groups (bit-identical results, -1.6 %);
- * FLUXMI_ATTN_THR = log2 of the deferred-rescale threshold (default 8); FLUXMI_ATTN_VAR=2 = exact running max. */
+ * maximum, so a score costs one exp2 instead of fma + exp2 (+4.7 % at L = 4608).  Q and V^T are bf16 either way.  Knobs
+ * (fluxmi_tuning_t): attn_defer_log2 = log2 of the deferred-rescale threshold (default 8), attn_var bit 1 = exact running max,
+ * attn_split = the balanced grid of fluxmi_attention_plan (fp16-K calls). */
 int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
                      const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, int k_f16,
                      void* stream);
+
+/* The launch plan of the kernel above for B x H heads of L keys on a 256-CU part (host arithmetic only, no GPU needed; tests + bench notes).
+ * The kernel runs one workgroup of 256 query rows per (head, row block) -- a TASK -- and one workgroup per CU at a time, so 432 tasks take two
+ * rounds with 80 CUs idle in the second.  Under fluxmi_tuning_t.attn_split (default on; fp16-K calls only) every XCD runs full_per_x of
+ * its n_per_x tasks whole and the remaining ones as `npieces` PIECES of their key range, launched longest first, so that every CU ends
+ * up with the same number of key tiles; a piece writes its softmax state (O, m, l; fp32) to a scratch slot and the piece that arrives
+ * last at the task's counter merges them in piece order -- the result does not depend on the arrival order.  Returns 1 when such a plan
+ * exists for the shape (and fills the outputs), 0 when the launch runs one workgroup per task.  pieces[i] (i < npieces <= 64), in launch
+ * order: bits 0-7 leftover-task index, 8-15 piece index within the task, 16-23 pieces of the task, 24-31 canonical index of the
+ * task's first piece (= its scratch slot), 32-47 first key tile, 48-63 key tiles. */
+int fluxmi_attention_plan(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces);
 
 /* The same with Q taken RAW from the qkv GEMM output (q at column 0 of `qkv`, row stride ld_qkv): QKNorm (qn_scale0 for rows
  * < split, qn_scale1 otherwise) + RoPE (pe) are applied while the query fragments are loaded, so Q never round-trips through HBM.

@@ -3,6 +3,7 @@ returns errors instead of crashing, and the host-side mirror of the reference AP
 import ctypes as C
 import glob
 import json
+import math
 import os
 import re
 
@@ -26,7 +27,51 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), f"libfluxmi.so does not export {s}"
     assert set(_lib.EXPORTS) == set(syms), f"ctypes table out of sync with the header: {set(_lib.EXPORTS) ^ set(syms)}"
-    assert _lib.lib.fluxmi_abi_version() == 3
+    assert _lib.lib.fluxmi_abi_version() == 4
+
+
+@pytest.mark.parametrize("B,L,H", [(1, 4608, 24), (1, 2816, 24), (2, 4608, 24), (8, 4608, 24), (1, 1100, 8), (3, 4608, 24), (1, 8192, 24), (1, 512, 24),
+                                   (1, 4608, 3), (1, 1100, 16), (1, 6000, 24)])
+def test_attention_balanced_grid_plan(B, L, H):
+    """fluxmi_attention_plan (host arithmetic, no GPU): the pieces of the balanced attention grid tile every leftover task's key range
+    exactly once, piece bookkeeping (index, count, scratch slot) is consistent, and replaying the launch order on 32 CUs -- each
+    finished CU takes the next piece -- gives every CU one bin's worth of key tiles (flux_model.py:41-45 is unchanged by any of it)."""
+    from fluxmi import ops
+
+    plan = ops.attention_plan(B, L, H)
+    tasks, nt = (L + 255) // 256 * H * B, (L + 63) // 64
+    rem = (tasks // 8) % 32 if tasks % 8 == 0 else 0
+    if tasks % 8 or nt < 16 or rem == 0 or rem > 26:
+        assert plan is None
+        return
+    assert plan is not None and plan["n_per_x"] == tasks // 8 and plan["full_per_x"] == tasks // 8 - rem and plan["full_per_x"] % 32 == 0
+    ps = plan["pieces"]
+    assert 1 <= len(ps) <= 64
+    by_task = {}
+    for p in ps:
+        assert p["len"] >= 1 and p["tb"] + p["len"] <= nt and p["tloc"] < rem
+        by_task.setdefault(p["tloc"], []).append(p)
+    assert sorted(by_task) == list(range(rem))
+    slots = set()
+    for t, pl in by_task.items():
+        pl.sort(key=lambda p: p["tb"])
+        assert [p["pidx"] for p in pl] == list(range(len(pl))) and all(p["np"] == len(pl) and p["base"] == pl[0]["base"] for p in pl) and len(pl) <= 8
+        pos = 0
+        for p in pl:  # contiguous, disjoint, complete
+            assert p["tb"] == pos
+            pos += p["len"]
+            slot = p["base"] + p["pidx"]
+            assert slot < 64 and slot not in slots
+            slots.add(slot)
+        assert pos == nt
+    # list scheduling of the launch order on an XCD's 32 CUs
+    free = [0] * 32
+    for p in ps:
+        i = min(range(32), key=lambda c: free[c])
+        free[i] += p["len"]
+    # one bin = 1/32 of the leftover tiles, but never less than a quarter task (a task is cut into at most four bins) or 8 tiles; + the edge snap
+    assert max(free) <= max(math.ceil(rem * nt / 32), math.ceil(nt / 4), 8) + 4, (max(free), rem * nt / 32)
+    assert max(free) < nt  # the grid it replaces spends one whole task per CU on this round
 
 
 def test_errors_are_returned_not_thrown():

@@ -683,6 +683,58 @@ def test_attention_deferred_rescale_branch(ops, dev, L):
           f"deferred == exact on {same:.4f}, == fold on {same_f:.4f} of the outputs")
 
 
+@pytest.mark.parametrize("B,H,L", [(1, 8, 1100), (1, 24, 2816), (1, 24, 4608), (2, 24, 4608)])
+def test_attention_balanced_grid(ops, dev, B, H, L):
+    """fluxmi_tuning_t.attn_split (round 5): the workgroups of the last, partial round are replaced by PIECES of their tasks' key range
+    (fluxmi_attention_plan); every piece keeps its own running max / row sum / O and the last arriver of a task merges them.  Checks:
+    the plan is on for these shapes; bf16 and fused-fp8 outputs of the balanced grid == one workgroup per task up to fp32 summation order
+    (same gates as between the other kernel builds); repeated launches are bit-identical (the merge order is fixed, not arrival order) and
+    leave the arrival counters at zero (a second, third launch gives the same bits); key rows spiked in different pieces give row maxima
+    that differ by far more than the deferred-rescale threshold between the pieces of a task; the small shape is also checked against fp64
+    (sequence not a multiple of 64: the last piece masks its partial tile).                                     flux_model.py:41-45"""
+    from fluxmi import _lib
+
+    plan = ops.attention_plan(B, L, H)
+    assert plan is not None and any(p["np"] > 1 for p in plan["pieces"])
+    torch.manual_seed(82)
+    q = torch.randn(B, H, L, 128).bfloat16()
+    k = torch.randn(B, H, L, 128).bfloat16()
+    v = torch.randn(B, H, L, 128).bfloat16()
+    nt = (L + 63) // 64
+    # spikes: every query row of the LAST row block of the last head (a leftover task) sees its maximum in another piece
+    for t_i, (row, tile, gain) in enumerate([(L - 1, 0, 6.0), (L - 2, nt // 2, 8.0), (L - 3, nt - 1, 9.0), (L - 200, nt // 3, 7.0), (L - 201, 2 * nt // 3, 7.0)]):
+        k[:, H - 1, min(tile * 64 + 7 + t_i, L - 1)] = (q[:, H - 1, row].float() * gain).bfloat16()
+    k = torch.where(k.abs() < 6.2e-5, torch.zeros_like(k), k)
+    VT = _vt_layout(v, L)
+    d = lambda t: t.to(dev)
+    qd, kd, vd = d(q), d(k.half()), d(VT)
+    s0, s1 = d(torch.tensor(3000.0)), d(torch.tensor(9000.0))
+    with _lib.tuning(attn_split=0):
+        ref = ops.attention(qd, kd, vd).cpu()
+        ref8 = ops.attention(qd, kd, vd, q_scale0=s0, q_scale1=s1, split=L // 3).cpu()
+    outs = []
+    for split in (1, 2, 1):
+        with _lib.tuning(attn_split=split):
+            outs.append((ops.attention(qd, kd, vd).cpu(), ops.attention(qd, kd, vd, q_scale0=s0, q_scale1=s1, split=L // 3).cpu()))
+    got, got8 = outs[0]
+    for o, o8 in outs[1:]:
+        assert torch.equal(o.view(torch.int16), got.view(torch.int16)) and torch.equal(o8.view(torch.uint8), got8.view(torch.uint8)), "balanced grid: launches differ"
+    assert torch.isfinite(got).all()
+    vmax = v.abs().max().item()
+    diff = (got.float() - ref.float()).abs().max().item()
+    same = (got == ref).float().mean().item()
+    same8 = (got8.view(torch.uint8) == ref8.view(torch.uint8)).float().mean().item()
+    print(f"B={B} H={H} L={L}: {len(plan['pieces'])} pieces per XCD after {plan['full_per_x']} whole tasks; balanced vs one workgroup per task: max |diff| {diff:.2e}, "
+          f"bf16 identical {same:.5f}, fp8 bytes identical {same8:.5f}")
+    assert diff <= 1e-2 * vmax and same >= 0.97 and same8 >= 0.995
+    if L <= 1100:
+        ref64 = fo.attention_fp64(q, k, v).transpose(1, 2).reshape(B, L, H * 128)
+        e_s, e_u = (got.double() - ref64).abs().max().item(), (ref.double() - ref64).abs().max().item()
+        r_s, r_u = ((got.double() - ref64).norm() / ref64.norm()).item(), ((ref.double() - ref64).norm() / ref64.norm()).item()
+        print(f"   vs fp64: balanced max |err| {e_s:.2e} rel-L2 {r_s:.3e}; one workgroup per task {e_u:.2e} / {r_u:.3e}")
+        assert e_s <= 2e-2 * vmax and r_s <= 1.05 * r_u + 1e-5
+
+
 @pytest.mark.parametrize("L,Lt", [(320, 64), (200, 40)])
 def test_attention_rawq(ops, dev, L, Lt):
     """Raw-Q mode: QKNorm + RoPE applied to the query rows inside the attention kernel == qkv_rope's Q followed by attention
