@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: denoise it/s of the Flux hot path on MI355X (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W [--config {1,2,3,5}]
+  python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4,5}]
       N > 1: one rank per GPU over RCCL.  Either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
       (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or plainly as `python bench.py --gpus N`: the script then re-launches
       itself under torch.distributed.run on 127.0.0.1 and passes rank 0's JSON line through.
@@ -16,7 +16,8 @@ flux_pipeline.py:197-212): 13 calibrating steps that freeze the F8Linear input s
   2  Flux-dev 1024x1024, 28 steps, fp8 F8Linear (quantize_modulation) + bf16 flow                       [default]
   3  Flux-dev 768x768, quantize_modulation + quantize_flow_embedder_layers
   5  config 2 + a synthetic rank-16 LoRA on every attention / MLP linear, fused into the fp8 weights (scale 1.0) before timing
-  (config 4 = config 2 launched with --gpus 8: batch-sharded replicas, one image per GPU)
+  4  Flux-dev 1024x1024, batch 8 (BASELINE.md section 2, 595 TFLOP per loop iteration): 8 / N images per GPU through ONE engine per GPU --
+     `--config 4` alone = all eight on one GPU, `--config 4 --gpus 8` = one image per GPU (the same work as `--config 2 --gpus 8`)
 N GPUs = N batch-sharded replicas (weak scaling); collectives: one RCCL broadcast of the T5/CLIP embeddings + noise before the
 loop and, during calibration only, the per-layer amax MAX-reduction.
 
@@ -29,6 +30,14 @@ reference's CPU flow path on the host cores for a bounded sample: the UNMODIFIED
                                                          rocprofv3 is on PATH, ~2 min); `roofline.source` says where each number came from
   python bench.py --gpus 2 --backend gloo --dry-run      no GPU: the multi-rank control flow (rendezvous, broadcast, sharding, in-step amax
                                                          exchange, barriers, max-over-ranks timing, one JSON line) on a stub engine
+  python bench.py --gpus N --preflight                   first-contact check of the N-rank plumbing, < 30 s, no model: process group, rank-id
+                                                         all-reduce, ONE broadcast of a request-sized payload, the latent gather; one JSON line;
+                                                         exit codes 10 rendezvous / 11 all-reduce / 12 broadcast / 13 gather (works with
+                                                         --backend gloo --dry-run on CPU and with --single-rank-group on a one-GPU box)
+`roofline.frac` is the IN-STEP figure: the same command runs one more graph-replayed request under `rocprofv3 --kernel-trace` (a child
+process of this script, after the timed region) and prices the GEMM family by its kernel time inside the steady steps; `roofline.step`
+splits the step into GEMM / attention / LayerNorm / other / gaps.  The isolated back-to-back probe of rounds 1 - 4 stays as
+`roofline.probe_frac` (it flatters a kernel: warm Infinity Cache, lower clock).  --no-step-trace skips the child.
 """
 import argparse
 import hashlib
@@ -54,24 +63,27 @@ CONFIGS = {
             quant=dict(modulation=True, embedders=False), steps_per_request=None, lora=False),
     3: dict(name="Flux-dev 768x768, quantize_modulation + quantize_flow_embedder_layers", schnell=False, height=768, width=768, txt_len=512,
             quant=dict(modulation=True, embedders=True), steps_per_request=None, lora=False),
+    4: dict(name="Flux-dev 1024x1024, fp8 F8Linear + bf16 flow, batch 8", schnell=False, height=1024, width=1024, txt_len=512,
+            quant=dict(modulation=True, embedders=False), steps_per_request=None, lora=False, batch_total=8),
     5: dict(name="Flux-dev 1024x1024 + rank-16 LoRA fused into the fp8 weights (scale 1.0)", schnell=False, height=1024, width=1024, txt_len=512,
             quant=dict(modulation=True, embedders=False), steps_per_request=None, lora=True),
 }
 
 
-def gemm_shapes(Li, Lt, H=3072):
+def gemm_shapes(Li, Lt, H=3072, batch=1):
     """(name, Ms, N, K, launches/step, fused epilogue) of the six grouped Linear launches of one step: exactly what
-    engine.hip issues in fused mode -- txt+img streams of a double block share one grouped launch."""
+    engine.hip issues in fused mode -- txt+img streams of a double block share one grouped launch, and so do the `batch` samples of a pass."""
     L, Hm = Li + Lt, 4 * H
+    d, s1 = (Lt, Li) * batch, (L,) * batch
     return [
-        ("double.qkv(txt+img)", (Lt, Li), 3 * H, H, 19, "bf16"), ("double.proj(txt+img)", (Lt, Li), H, H, 19, "gate_resid"),
-        ("double.mlp0(txt+img)", (Lt, Li), Hm, H, 19, "gelu_quant"), ("double.mlp2(txt+img)", (Lt, Li), H, Hm, 19, "gate_resid"),
-        ("single.linear1", (L,), 3 * H + Hm, H, 38, "split"), ("single.linear2", (L,), H, H + Hm, 38, "gate_resid"),
+        ("double.qkv(txt+img)", d, 3 * H, H, 19, "bf16"), ("double.proj(txt+img)", d, H, H, 19, "gate_resid"),
+        ("double.mlp0(txt+img)", d, Hm, H, 19, "gelu_quant"), ("double.mlp2(txt+img)", d, H, Hm, 19, "gate_resid"),
+        ("single.linear1", s1, 3 * H + Hm, H, 38, "split"), ("single.linear2", s1, H, H + Hm, 38, "gate_resid"),
     ]
 
 
-def linear_flops_per_step(Li, Lt, H=3072):
-    return sum(2.0 * sum(Ms) * N * K * cnt for _, Ms, N, K, cnt, _e in gemm_shapes(Li, Lt, H))
+def linear_flops_per_step(Li, Lt, H=3072, batch=1):
+    return sum(2.0 * sum(Ms) * N * K * cnt for _, Ms, N, K, cnt, _e in gemm_shapes(Li, Lt, H, batch))
 
 
 def kernel_source_key():
@@ -84,7 +96,7 @@ def kernel_source_key():
     return h.hexdigest()[:16]
 
 
-def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
+def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10, batch=1):
     """Average duration of one Linear GEMM launch of the step: the six launch shapes WITH their fused epilogues (fp8 path: GELU+quantise,
     gate*y+x in place, qkv|mlp split, V^T and normalised + rotated K in the attention layout; bf16 path of config 1: plain bf16 outputs, what the unfused engine issues), weighted by their
     count per step; HIP events on the launch stream, random operands.  Returns (flops, algorithmic bytes, seconds) per launch + table."""
@@ -101,7 +113,7 @@ def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
     L_all = Li + Lt
     Lp = (L_all + 63) // 64 * 64
     heads = H // 128
-    for name, Ms, N, K, cnt, epi in gemm_shapes(Li, Lt):
+    for name, Ms, N, K, cnt, epi in gemm_shapes(Li, Lt, batch=batch):
         groups, keep = [], []
         nbytes = 0
         attn_out = fuse_kv >= 1 and epi in ("bf16", "split") and N >= 3 * H
@@ -150,7 +162,7 @@ def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
                 kw.update(vt_out=vt_t.data_ptr(), vt_ld=Lp, tok0=tok0, vt_rows=(Lp - tok0) if last else M, kv_col0=H, heads=heads)
                 if fuse_kv >= 2:
                     kw.update(k_out=k_t.data_ptr(), pe=pe_t.data_ptr(), k_norm=kn_t.data_ptr(), k_rows=L_all, k_f16=bool(_lib.get_tuning().attn_f16k))
-                tok0 += M
+                tok0 = (tok0 + M) % L_all  # the next sample of the pass starts over (the probe's samples share one set of K / V^T buffers)
             if fp8 and _lib.get_tuning().w_pairs and name.split("(")[0] in ("double.qkv", "double.mlp0", "double.mlp2", "single.linear1", "single.linear2"):
                 wp = ops.pair_rows(w)  # the engine's row-pair copy of these weights (fluxmi_gemm_group_t.W_pairs)
                 keep.append(wp)
@@ -179,20 +191,20 @@ def measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=True, iters=10):
     return tot_f / n_launch, tot_b / n_launch, tot_t / n_launch, table
 
 
-def measure_attention(torch, ops, dev, L, iters=10, H=24):
+def measure_attention(torch, ops, dev, L, iters=10, H=24, batch=1):
     """The second kernel of the step (57 launches): joint attention at the step's shape, bf16 MFMA, fp8 output, HIP events on the
     launch stream.  Reported beside the GEMM roofline; `peak` is the dense bf16 MFMA figure."""
     Lp = (L + 63) // 64 * 64
-    q = torch.randn(1, H, L, 128, device=dev).bfloat16()
-    k = torch.randn(1, H, L, 128, device=dev).bfloat16()
+    q = torch.randn(batch, H, L, 128, device=dev).bfloat16()
+    k = torch.randn(batch, H, L, 128, device=dev).bfloat16()
     from fluxmi import _lib
 
     f16k = bool(_lib.get_tuning().attn_f16k)  # what the engine launches
     if f16k:
         k = k.half()
-    vt = torch.randn(1, H, 128, Lp, device=dev).bfloat16()
+    vt = torch.randn(batch, H, 128, Lp, device=dev).bfloat16()
     one = torch.tensor(1.0, device=dev)
-    o8 = torch.empty(1, L, H * 128, dtype=torch.float8_e5m2, device=dev)
+    o8 = torch.empty(batch, L, H * 128, dtype=torch.float8_e5m2, device=dev)
     for _ in range(2):
         ops.attention(q, k, vt, q_scale0=one, out=o8)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -202,12 +214,17 @@ def measure_attention(torch, ops, dev, L, iters=10, H=24):
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / iters
-    f = 4.0 * L * L * 128 * H
-    wgs = ((L + 255) // 256) * H
+    f = 4.0 * L * L * 128 * H * batch
+    wgs = ((L + 255) // 256) * H * batch
+    plan = ops.attention_plan(batch, L, H) if (f16k and _lib.get_tuning().attn_split) else None
     kern = "attention2_kernel (8 waves x 32 rows, skewed pipeline, deferred rescale" + (", folded, barrier between the MFMA groups)" if f16k else ")")
-    return {"kernel": kern + ", bf16/f16 MFMA 32x32x16, fp8 output", "per_step": 57, "us": round(t * 1e6, 1),
-            "achieved": round(f / t / 1e12, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / BF16_PEAK_TFLOPS, 4),
-            "note": f"{wgs} workgroups on 256 CUs = {wgs / 256:.2f} rounds"}
+    note = f"{wgs} tasks of 256 query rows on 256 CUs = {wgs / 256:.2f} rounds"
+    if plan:
+        note += (f"; balanced grid: per XCD {plan['full_per_x']} whole tasks, the other {plan['n_per_x'] - plan['full_per_x']} as {len(plan['pieces'])} pieces of "
+                 "their key range, fp32 log-sum-exp merge (fluxmi_attention_plan)")
+    return {"kernel": kern + ", bf16/f16 MFMA 32x32x16, fp8 output", "per_step": 57, "probe_us": round(t * 1e6, 1),
+            "probe_achieved": round(f / t / 1e12, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "probe_frac": round(f / t / 1e12 / BF16_PEAK_TFLOPS, 4),
+            "flops_per_launch": f, "note": note}
 
 
 def pmc_file(kind, cfg_id):
@@ -297,6 +314,204 @@ def summarize_pmc(cfg_id, Li, Lt):
             json.dump({"source_key": key, "per_launch": per_busy,
                        "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)", "how": how}, f, indent=1)
     return per_traffic, per_busy
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# In-step kernel times: one more request of the same command under rocprofv3 --kernel-trace
+# ---------------------------------------------------------------------------------------------------------------------------
+def step_trace_dir(cfg_id):
+    return os.path.join(ROOT, "gpurun_out", f"step_trace_config{cfg_id}")
+
+
+def collect_step_trace(args, timeout_s=420.0):
+    """Re-run THIS command's workload once more as a child under `rocprofv3 --kernel-trace` (kernel trace only: no counters, no API
+    traces): same config, same steps / warmup, one timed request, no probes / PMC / CPU baseline.  Returns the directory or None."""
+    d = step_trace_dir(args.config)
+    import shutil
+
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d, exist_ok=True)
+    cmd = ["rocprofv3", "--kernel-trace", "-d", d, "-o", "step", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+           "--config", str(args.config), "--steps", str(args.steps), "--warmup", str(args.warmup), "--requests", "1", "--no-pmc", "--no-cpu-baseline",
+           "--no-step-trace", "--no-probe"] + (["--no-graph"] if args.no_graph else []) + (["--depth", str(args.depth)] if args.depth is not None else [])
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "FLUXMI_BENCH_CHILD"):
+        env.pop(k, None)
+    try:
+        subprocess.run(cmd, env=env, cwd="/tmp", check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+    except Exception as ex:  # noqa: the trace must never take the measurement down
+        print(f"bench: step trace failed: {ex}", file=sys.stderr)
+        return None
+    return d
+
+
+FAMILIES = (("gemm", ("gemm", "splitk_reduce")), ("attention", ("attention",)), ("ln", ("ln_modulate",)))
+
+
+def summarize_step_trace(path, header=""):
+    """*kernel_trace.csv under `path` -> the steady steps of the LAST denoise request: the dispatches between the first and the last
+    euler_kernel of that request (its first step also carries the request's set-up -- modulation table, txt_in, quantising tables -- and is
+    dropped).  Returns {steps, wall_ms, kernel_ms, launches, gemm_ms / attention_ms / ln_ms / other_ms / gaps_ms (per step), per-kernel rows,
+    text (the table committed under profiles/)} or None."""
+    import csv
+    import glob
+    import re
+
+    files = glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True) if os.path.isdir(path) else [path]
+    if not files:
+        return None
+    ks = []
+    for f in files:
+        with open(f) as fh:
+            ks += [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(fh)]
+    ks.sort(key=lambda k: k[1])
+    eul = [i for i, k in enumerate(ks) if "euler_kernel" in k[0]]
+    if len(eul) < 3:
+        return None
+    # the last request = the longest suffix of euler kernels with no calibration / table-building kernel in between
+    setup = ("amax_kernel", "calib_update", "timestep_rows_kernel", "build_qlut")
+    last = len(eul) - 1
+    first = last
+    while first > 0 and not any(any(t in ks[j][0] for t in setup) for j in range(eul[first - 1], eul[first])):
+        first -= 1
+    if last - first < 1:
+        return None
+    t0, t1, steps = ks[eul[first]][2], ks[eul[last]][2], last - first
+
+    def short(name):
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        name = re.sub(r"^void ", "", name)
+        return name if len(name) <= 110 else name[:107] + "..."
+
+    rows, fam = {}, {f: 0.0 for f, _ in FAMILIES}
+    fam["other"] = 0.0
+    for n, s_, e in ks:
+        if s_ >= t0 and e <= t1:
+            k = short(n)
+            c, t = rows.get(k, (0, 0.0))
+            rows[k] = (c + 1, t + (e - s_))
+            for f, keys in FAMILIES:
+                if any(x in n for x in keys):
+                    fam[f] += e - s_
+                    break
+            else:
+                fam["other"] += e - s_
+    wall = (t1 - t0) / steps / 1e6
+    tot = sum(t for _, t in rows.values())
+    out = {"steps": steps, "wall_ms": round(wall, 3), "kernel_ms": round(tot / steps / 1e6, 3), "launches": round(sum(c for c, _ in rows.values()) / steps, 1)}
+    for f in fam:
+        out[f + "_ms"] = round(fam[f] / steps / 1e6, 3)
+    out["gaps_ms"] = round(wall - tot / steps / 1e6, 3)
+    out["gemm_launches"] = round(sum(c for k, (c, _) in rows.items() if any(x in k for x in FAMILIES[0][1])) / steps, 1)
+    out["attention_us"] = round(fam["attention"] / max(1, sum(c for k, (c, _) in rows.items() if "attention" in k)) / 1e3, 2)
+    lines = ([header] if header else []) + [
+        f"# steady state: {steps} graph-replayed denoise steps of the last request, wall {wall:.3f} ms/step, kernel time {tot / steps / 1e6:.3f} ms/step, "
+        f"{out['launches']:.0f} launches/step; per step: GEMM family {out['gemm_ms']:.3f} ms, attention {out['attention_ms']:.3f}, LayerNorm+modulate "
+        f"{out['ln_ms']:.3f}, other {out['other_ms']:.3f}, gaps {out['gaps_ms']:.3f}; columns are totals over those steps (ns resolution -> us)",
+        f"{'kernel':112s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'%':>6s}"]
+    for k, (c, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        lines.append(f"{k:112s} {c:7d} {t / 1e3:12.1f} {t / c / 1e3:10.2f} {100 * t / tot:6.2f}")
+    out["text"] = "\n".join(lines) + "\n"
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# --preflight: first contact of the N-rank plumbing (no model, < 30 s)
+# ---------------------------------------------------------------------------------------------------------------------------
+PREFLIGHT_CODES = {"rendezvous": 10, "allreduce": 11, "broadcast": 12, "gather": 13}
+
+
+def preflight(args):
+    """process group -> rank-id all-reduce -> ONE broadcast_request of the real payload size (T5 states, CLIP vector, packed noise of
+    one image per rank at the config's resolution) -> gather_latents -> one JSON line from rank 0.  Every stage has its own exit code."""
+    t_all = time.time()
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)  # RCCL prints banners on fd 1
+    import torch
+    import torch.distributed as td
+
+    from fluxmi import dist as fdist
+
+    C = CONFIGS[args.config]
+
+    def fail(stage, msg):
+        print(json.dumps({"preflight": "failed", "stage": stage, "error": msg, "n_gpus": args.gpus}), file=sys.stderr, flush=True)
+        os._exit(PREFLIGHT_CODES[stage])
+
+    def inject(stage):  # test hook: FLUXMI_PREFLIGHT_FAIL=<stage>[:<rank>] breaks that stage (on that rank)
+        want = os.environ.get("FLUXMI_PREFLIGHT_FAIL", "").split(":")
+        if want[0] == stage and (len(want) < 2 or want[1] == os.environ.get("RANK", "0")):
+            raise RuntimeError("injected failure")
+
+    times = {}
+    try:
+        t0 = time.time()
+        inject("rendezvous")
+        rank, world, local = fdist.init_from_env("gloo" if args.dry_run and args.backend != "nccl" else args.backend)
+        if args.single_rank_group and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29519")
+            if args.backend == "nccl" and not args.dry_run:
+                torch.cuda.set_device(0)
+            td.init_process_group(backend=args.backend, rank=0, world_size=1)
+        if world != args.gpus:
+            raise RuntimeError(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        if not td.is_initialized():
+            raise RuntimeError("no process group (N = 1 needs --single-rank-group)")
+        if not args.dry_run:
+            torch.cuda.set_device(local)
+        dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local)
+        times["init_s"] = round(time.time() - t0, 2)
+    except Exception as ex:  # noqa
+        fail("rendezvous", f"{type(ex).__name__}: {ex}")
+    sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
+    try:
+        t0 = time.time()
+        inject("allreduce")
+        rid = torch.tensor([float(rank), 1.0], device=dev, dtype=torch.float64)
+        td.all_reduce(rid, op=td.ReduceOp.SUM)
+        sync()
+        if int(round(rid[1].item())) != world or int(round(rid[0].item())) != world * (world - 1) // 2:
+            raise RuntimeError(f"{int(round(rid[1].item()))} ranks answered (id sum {int(round(rid[0].item()))}), expected {world}")
+        times["allreduce_s"] = round(time.time() - t0, 3)
+    except Exception as ex:  # noqa
+        fail("allreduce", f"rank {rank}: {type(ex).__name__}: {ex}")
+    B = world * (C.get("batch_total", world) // world)
+    Li, Lt = (C["height"] // 16) * (C["width"] // 16), C["txt_len"]
+    try:
+        t0 = time.time()
+        g = torch.Generator().manual_seed(7)
+        want = [torch.randn(B, Lt, 4096, generator=g).bfloat16(), torch.randn(B, 768, generator=g).bfloat16(), torch.randn(B, Li, 64, generator=g).bfloat16()]
+        parts = [w.to(dev) if rank == 0 else torch.zeros_like(w, device=dev) for w in want]
+        got = fdist.broadcast_request(*parts, src=0)
+        sync()
+        inject("broadcast")
+        for w, t in zip(want, got):
+            if not torch.equal(t.cpu().view(torch.int16), w.view(torch.int16)):
+                raise RuntimeError("payload differs from the source rank's")
+        times["broadcast_s"] = round(time.time() - t0, 3)
+        times["broadcast_bytes"] = sum(w.numel() * 2 for w in want)
+    except Exception as ex:  # noqa
+        fail("broadcast", f"rank {rank}: {type(ex).__name__}: {ex}")
+    try:
+        t0 = time.time()
+        lo, hi = fdist.shard_bounds(B, rank, world)
+        lat = torch.stack([torch.full((Li, 64), float(i + 1)) for i in range(lo, hi)]).bfloat16().to(dev) if hi > lo else torch.zeros(0, Li, 64, dtype=torch.bfloat16, device=dev)
+        allv = fdist.gather_latents(lat, B, dst=0)
+        sync()
+        inject("gather")
+        if rank == 0 and not (allv.shape[0] == B and all(float(allv[i, 0, 0]) == float(i + 1) and float(allv[i, -1, -1]) == float(i + 1) for i in range(B))):
+            raise RuntimeError("gathered latents are not the ranks' shards in order")
+        times["gather_s"] = round(time.time() - t0, 3)
+    except Exception as ex:  # noqa
+        fail("gather", f"rank {rank}: {type(ex).__name__}: {ex}")
+    td.barrier()
+    backend, nranks = td.get_backend(), td.get_world_size()
+    td.destroy_process_group()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps({"preflight": "ok", "n_gpus": world, "nranks": nranks, "backend": backend, "batch": B, "config": args.config,
+                                           "total_s": round(time.time() - t_all, 2), **times}) + "\n").encode())
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -502,6 +717,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: run the multi-rank control flow on a stub engine (CPU tensors)")
     ap.add_argument("--depth", type=int, default=None, help="debug only: fewer blocks (the result is then flagged invalid)")
+    ap.add_argument("--preflight", action="store_true", help="check the N-rank plumbing (group, all-reduce, request broadcast, latent gather) and exit; no model")
+    ap.add_argument("--no-step-trace", action="store_true", help="skip the extra request under rocprofv3 --kernel-trace (roofline.frac is then the isolated probe's)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the isolated GEMM / attention probe loops (used by the step-trace child)")
     ap.add_argument("--single-rank-group", action="store_true",
                     help="N = 1 only: create a one-rank process group anyway and run every collective of the N > 1 path through it (broadcast, "
                          "in-step amax all-reduce from the engine's hook, barriers): exercises the RCCL plumbing on a one-GPU box")
@@ -517,6 +735,9 @@ def main():
         return
     if args.gpus > 1 and "RANK" not in os.environ:
         _self_launch(args)
+    if args.preflight:
+        preflight(args)
+        return
     # stdout carries exactly ONE line, the JSON: everything else any library writes to fd 1 (RCCL prints a version banner there when a
     # communicator is created or destroyed) goes to stderr; rank 0 writes the line to the saved descriptor at the very end
     sys.stdout.flush()
@@ -568,6 +789,9 @@ def main():
         if args.depth is not None:
             cfg.params.depth, cfg.params.depth_single_blocks = args.depth, 2 * args.depth
         p = cfg.params
+    if C.get("batch_total", world) % world:
+        raise SystemExit(f"--config {args.config} shards {C['batch_total']} images: --gpus must divide it")
+    ipg = C.get("batch_total", world) // world           # images per GPU (config 4: 8 / N; every other config: one)
     spr = C["steps_per_request"] or args.steps          # steps per denoise request (config 1: 1-step requests)
     n_req = max(1, args.steps // spr)
     t_setup = time.time()
@@ -587,13 +811,13 @@ def main():
             torch.cuda.empty_cache()
         # request: rank 0 plays the text-encoder rank; ONE RCCL broadcast of embeddings + noise
         hw = (64, 64, 32) if dry else (C["height"], C["width"], C["txt_len"])
-        inp = synth.make_inputs(p, hw[0], hw[1], hw[2], batch=world, seed=0)
+        inp = synth.make_inputs(p, hw[0], hw[1], hw[2], batch=world * ipg, seed=0)
         txt, vec, img = (inp[k].to(dev) for k in ("txt", "y", "img"))
         if world > 1 or group1:
             if rank != 0:
                 txt, vec, img = torch.zeros_like(txt), torch.zeros_like(vec), torch.zeros_like(img)
             txt, vec, img = fdist.broadcast_request(txt, vec, img, src=0)
-        lo, hi = fdist.shard_bounds(world, rank, world)
+        lo, hi = fdist.shard_bounds(world * ipg, rank, world)
         txt, vec, img = txt[lo:hi].contiguous(), vec[lo:hi].contiguous(), img[lo:hi].contiguous()
         img_ids, txt_ids = inp["img_ids"][lo:hi].to(dev), inp["txt_ids"][lo:hi].to(dev)
         Li, Lt = img.shape[1], txt.shape[1]
@@ -702,20 +926,22 @@ def main():
         if rank == 0:
             steps_done = n_req * spr
             ms_per_step = elapsed / steps_done * 1e3
-            its = world * steps_done / elapsed
+            loop_its = steps_done / elapsed                 # loop iterations per second on one GPU (what the reference's tqdm prints)
+            its = world * ipg * loop_its                    # whole job: every image of every GPU advances one step per loop iteration
             ms_each = [round(e / steps_done * 1e3, 3) for e in elapsed_each]
             fp8 = C["quant"] is not None
-            cfg_block = {"workload": f"BASELINE.json configs[{args.config - 1}]: {C['name']}; batch 1 per GPU, Li={Li}+Lt={Lt} tokens, "
+            cfg_block = {"workload": f"BASELINE.json configs[{args.config - 1}]: {C['name']}; batch {ipg} per GPU, Li={Li}+Lt={Lt} tokens, "
                                      f"{p.depth} double + {p.depth_single_blocks} single blocks, {spr} step(s) per request x {n_req} request(s) = {steps_done} "
                                      f"timed steps, repeated {R} times (median reported), hipGraph denoise loop",
-                         "baseline_config": args.config, "images_per_gpu": 1, "parallelism": f"batch-sharded replicas x{world}",
+                         "baseline_config": args.config, "images_per_gpu": ipg, "global_batch": world * ipg, "parallelism": f"batch-sharded replicas x{world}",
                          "nranks": nranks, "backend": backend, "calibration": calibration, "finite_output": finite,
                          "depth_override": args.depth, "lora_fuse_s": None if lora_s is None else round(lora_s, 2)}
             result = {
-                "metric": "denoise it/s, " + C["name"],
+                "metric": "denoise it/s, " + C["name"] + (" (image-steps per second: every loop iteration advances all images of the batch by one step)" if ipg > 1 else ""),
                 "value": round(its, 4), "unit": "it/s", "n_gpus": world, "steps": steps_done, "warmup": args.warmup,
                 "ms_per_step": round(ms_per_step, 3), "requests": R, "ms_per_step_each": ms_each,
-                "value_range": [round(world * steps_done / max(elapsed_each), 4), round(world * steps_done / min(elapsed_each), 4)],
+                "value_range": [round(world * ipg * steps_done / max(elapsed_each), 4), round(world * ipg * steps_done / min(elapsed_each), 4)],
+                "loop_its_per_gpu": round(loop_its, 4), "image_steps_per_s": round(its, 4),
                 "sustained_shader_clock_ghz_each": clock_each, "board_power": power.summary() if power else None,
                 "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None,
@@ -727,12 +953,48 @@ def main():
                 result.update({"dry_run": True, "data": "DRY RUN on a stub engine (CPU tensors): control flow only, not a measurement",
                                "amax_exchanges": model.exchanges})
             else:
-                lin_flops = linear_flops_per_step(Li, Lt)
-                fl, by, sec, gemm_table = measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=fp8)
-                attn_row = measure_attention(torch, ops, dev, Li + Lt)
-                src = {"achieved": "live (HIP events on the launch stream, this process)", "traffic": None, "mfma_busy": None}
+                lin_flops = linear_flops_per_step(Li, Lt, batch=ipg)
+                attn_flops = 4.0 * (Li + Lt) ** 2 * 128 * p.num_heads * ipg
+                n_lin = sum(cnt for *_x, cnt, _e in gemm_shapes(Li, Lt))  # grouped Linear launches per step (152)
+                n_attn = p.depth + p.depth_single_blocks
+                src = {"achieved": None, "traffic": None, "mfma_busy": None}
                 have_prof = subprocess.run(["which", "rocprofv3"], capture_output=True).returncode == 0
-                if world == 1 and fp8 and (args.pmc or (have_prof and not args.no_pmc)):
+                # ---- the isolated probe loops of rounds 1 - 4 (back-to-back launches of one shape, warm Infinity Cache): kept as probe_* ----
+                fl = by = sec = None
+                gemm_table, attn_row = [], None
+                if not args.no_probe:
+                    fl, by, sec, gemm_table = measure_gemm_roofline(torch, ops, dev, Li, Lt, fp8=fp8, batch=ipg)
+                    attn_row = measure_attention(torch, ops, dev, Li + Lt, H=p.num_heads, batch=ipg)
+                # ---- in-step kernel times: one more request of this command under rocprofv3 --kernel-trace (child process) ----
+                step = None
+                if world == 1 and have_prof and not args.no_step_trace:
+                    d = collect_step_trace(args)
+                    hdr = (f"rocprofv3 --kernel-trace -- python bench.py --config {args.config} --steps {args.steps} --warmup {args.warmup} --requests 1 --no-pmc "
+                           f"--no-cpu-baseline --no-step-trace --no-probe   (child of `python bench.py {' '.join(sys.argv[1:])}`; the parent's timed line: "
+                           f"{ms_per_step:.3f} ms/step = {its:.2f} it/s)")
+                    step = summarize_step_trace(d, header=hdr) if d else None
+                    if step:
+                        with open(os.path.join(d, "steady_step.txt"), "w") as f:
+                            f.write(step.pop("text"))
+                if sec:
+                    probe = {"probe_achieved": round((fl if fp8 else by) / sec / (1e12 if fp8 else 1e9), 1),
+                             "probe_frac": round((fl / sec / 1e12 / FP8_PEAK_TFLOPS) if fp8 else (by / sec / 1e9 / HBM_PEAK_GBS), 4),
+                             "probe_avg_launch_us": round(sec * 1e6, 2)}
+                else:
+                    probe = {"probe_achieved": None, "probe_frac": None, "probe_avg_launch_us": None}
+                alg_bytes_step = (by * n_lin) if by else None
+                if step:
+                    g_s = step["gemm_ms"] * 1e-3
+                    ach = (lin_flops / g_s / 1e12) if fp8 else ((alg_bytes_step / g_s / 1e9) if alg_bytes_step else None)
+                    src["achieved"] = (f"in-step: rocprofv3 --kernel-trace of one extra graph-replayed request run by this command ({step['steps']} steady steps; "
+                                       "summary in gpurun_out/step_trace_config%d/steady_step.txt): algorithmic work of the step's Linear launches / time of the GEMM-family kernels inside the step" % args.config)
+                    avg_us = step["gemm_ms"] * 1e3 / n_lin
+                else:
+                    ach = probe["probe_achieved"]
+                    src["achieved"] = "isolated probe loop (HIP events on the launch stream, this process): no step trace (rocprofv3 not on PATH, N > 1, or --no-step-trace)"
+                    avg_us = probe["probe_avg_launch_us"]
+                peak = FP8_PEAK_TFLOPS if fp8 else HBM_PEAK_GBS
+                if world == 1 and fp8 and ipg == 1 and not args.no_probe and (args.pmc or (have_prof and not args.no_pmc)):
                     try:
                         collect_pmc(args.config, Li, Lt)
                         per_t, per_b = summarize_pmc(args.config, Li, Lt)
@@ -742,13 +1004,13 @@ def main():
                             src["mfma_busy"] = "live (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass run by this command)"
                     except Exception as ex:  # the counters must never take the measurement down
                         print(f"bench: PMC collection failed: {ex}", file=sys.stderr)
-                traffic, busy = read_pmc("traffic", args.config), read_pmc("mfma", args.config)
+                traffic, busy = (read_pmc("traffic", args.config), read_pmc("mfma", args.config)) if ipg == 1 else (None, None)
                 if traffic and src["traffic"] is None:
                     src["traffic"] = "committed file profiles/" + os.path.basename(pmc_file("traffic", args.config)) + " (same kernel sources, earlier run)"
                 if busy and src["mfma_busy"] is None:
                     src["mfma_busy"] = "committed file profiles/" + os.path.basename(pmc_file("mfma", args.config)) + " (same kernel sources, earlier run)"
                 busy_w = None
-                if busy:
+                if busy and gemm_table:
                     num = den = 0.0
                     for row in gemm_table:
                         if row["launch"] in busy["per_launch"]:
@@ -756,19 +1018,26 @@ def main():
                             num, den = num + w * busy["per_launch"][row["launch"]], den + w
                     busy_w = round(num / den, 4) if den else None
                 if fp8:
-                    roof = {"bound": "mfma", "kernel": "gemm_ps_kernel (persistent) / gemm_w1_kernel / gemm_pp_kernel <fp8 MX-MFMA 32x32x64, 256x256 tiles> "
-                                                        "(the 152 grouped F8Linear GEMM launches of a step as the engine issues them: fused epilogues, "
-                                                        "V^T and K in the attention layout included)",
-                            "achieved": round(fl / sec / 1e12, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / sec / 1e12 / FP8_PEAK_TFLOPS, 4)}
+                    roof = {"bound": "mfma", "kernel": "gemm_ps_kernel (persistent) / gemm_w1_kernel / gemm_pp_kernel <fp8 MX-MFMA 32x32x64, 256x256 tiles> + their 128x128 tails "
+                                                        f"(the {n_lin} grouped F8Linear GEMM launches of a step as the engine issues them: fused epilogues, V^T and K in the "
+                                                        "attention layout included)", "unit": "TFLOP/s"}
                 else:
-                    roof = {"bound": "hbm", "kernel": "bf16 MFMA GEMM at M = 512 (weight-stream bound: 23.8 GB of bf16 weights per step)",
-                            "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / sec / 1e9 / HBM_PEAK_GBS, 4)}
+                    roof = {"bound": "hbm", "kernel": "bf16 MFMA GEMM at M = 512 (weight-stream bound: 23.8 GB of bf16 weights per step)", "unit": "GB/s"}
+                roof.update({"achieved": None if ach is None else round(ach, 1), "peak": peak, "frac": None if ach is None else round(ach / peak, 4)})
+                roof.update(probe)
                 roof.update({"traffic": traffic["bytes_per_launch"] if traffic else None,
-                             "traffic_note": None if traffic else "no PMC values for the current kernel sources (rocprofv3 not on PATH, or --no-pmc)",
+                             "traffic_note": None if traffic else "no PMC values for the current kernel sources (rocprofv3 not on PATH, --no-pmc, or a batched config)",
                              "source": src,
-                             "flops_per_launch": fl, "algorithmic_bytes_per_launch": by, "avg_launch_us": round(sec * 1e6, 2),
-                             "mfma_busy_frac_pmc": busy_w, "launches": gemm_table,
+                             "flops_per_launch": lin_flops / n_lin, "algorithmic_bytes_per_launch": by, "avg_launch_us": None if avg_us is None else round(avg_us, 2),
+                             "launches_per_step": n_lin, "mfma_busy_frac_pmc": busy_w, "launches": gemm_table,
+                             "step": None if not step else {k: step[k] for k in ("steps", "wall_ms", "gemm_ms", "attention_ms", "ln_ms", "other_ms", "gaps_ms", "kernel_ms", "launches")},
                              "attention": attn_row})
+                if step and attn_row is not None:
+                    a_s = step["attention_ms"] * 1e-3
+                    attn_row.update({"us": round(step["attention_ms"] * 1e3 / n_attn, 2), "achieved": round(attn_flops * n_attn / a_s / 1e12, 1),
+                                     "frac": round(attn_flops * n_attn / a_s / 1e12 / BF16_PEAK_TFLOPS, 4), "source": "in-step (the same kernel trace)"})
+                elif attn_row is not None:
+                    attn_row.update({"us": attn_row["probe_us"], "achieved": attn_row["probe_achieved"], "frac": attn_row["probe_frac"], "source": "isolated probe loop"})
                 result.update({
                     "reference_h100_compiled_its": H100_COMPILED.get(args.config),
                     "vs_h100_compiled": round(its / world / H100_COMPILED[args.config], 3) if args.config in H100_COMPILED else None,

@@ -97,8 +97,9 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       lid = x * a.sp.n_per_x + a.sp.full_per_x + pc.tloc;
       tb = pc.tb;
       ntiles = pc.len;
-      if (a.sp.pf_fold && a.pf.n > 0) fluxmi_prefetch_ranges(a.pf, (int)blockIdx.x - 8 * a.sp.full_per_x, 8 * a.sp.npieces, tid, NW2 * 64);
     }
+    // no CU idles any more: the weight prefetch, when asked for, is spread over ALL workgroups, in front of their own work
+    if (a.sp.pf_fold && a.pf.n > 0) fluxmi_prefetch_ranges(a.pf, (int)blockIdx.x, main_wgs, tid, NW2 * 64);
   } else {
     lid = xcd_remap(blockIdx.x, nqb * a.H * a.B);  // whole heads per XCD: a head's K / V^T (2.4 MB at L = 4608) is fetched into one 4 MiB L2 once and shared by its q-blocks
   }
@@ -450,51 +451,73 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     store_o<FMT>(a, o, inv, b, h, qrow, hi);
   } else if constexpr (FOLD) {
     // ---- a piece of a task: (O, m, l) -> its slot; the piece that arrives last merges all pieces of the task in piece order -------------
+    // Coherence.  The eight XCDs have private, mutually non-coherent L2s.  The textbook pattern (store, agent-scope release fence, counter,
+    // acquire fence, load) costs a buffer_wbl2 + buffer_inv sc1 per piece, and the invalidate empties the L2 under the 31 other workgroups
+    // of the XCD that are streaming K / V^T through it: 347 us per launch instead of 225.  Agent-scope atomic accesses (sc1: every word to
+    // the memory side and back) are correct everywhere but put ~27 us of round trips behind the last tile (234 us: no gain left).  What is
+    // used instead is the XCD's own L2: ALL pieces of a task run on ONE XCD (workgroup b runs on XCD b % 8 and the task index is derived
+    // from b & 7; the host verifies that mapping once per device before it enables the balanced grid, fluxmi_xcd_mapping_ok), and within
+    // an XCD the L2 is the single point of coherence of its 32 CUs -- the vector L1 is write-through, a store is acknowledged (vmcnt) when
+    // the L2 has it, and a CU's L1 cannot hold a stale copy of a slot: it is invalidated at every kernel start and each slot line is read
+    // exactly once per launch, by the merging workgroup (tests/test_ops_gpu.py alternates inputs between launches to catch a stale read).
+    // So: plain 16-byte stores, s_waitcnt vmcnt(0), workgroup barrier, ONE agent-scope atomic add per piece, plain loads.
+    // (profiles/r05_attention_split.txt has the three variants measured.)
     const int x = (int)blockIdx.x & 7;
     float* slot0 = a.sp.part + (size_t)(x * ATTN_MAX_PIECES + pc.base) * ATTN_PART_FLOATS;  // the task's first piece; its others follow
     {
-      float* sl = slot0 + (size_t)pc.pidx * ATTN_PART_FLOATS;
-      v4f* po = (v4f*)sl + (wave * 16) * 64 + lane;
+      v4f* po = (v4f*)(slot0 + (size_t)pc.pidx * ATTN_PART_FLOATS) + (wave * 17) * 64 + lane;  // [wave][i < 16: four O floats | 16: (m, l, -, -)][lane]
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         v4f v;
         v[0] = o[i >> 2][(i & 3) * 4 + 0]; v[1] = o[i >> 2][(i & 3) * 4 + 1]; v[2] = o[i >> 2][(i & 3) * 4 + 2]; v[3] = o[i >> 2][(i & 3) * 4 + 3];
         po[i * 64] = v;
       }
-      v2f ml;
-      ml[0] = m_cur; ml[1] = l_tot;
-      ((v2f*)(sl + ATTN_PART_O_FLOATS))[wave * 64 + lane] = ml;
+      v4f ml;
+      ml[0] = m_cur; ml[1] = l_tot; ml[2] = 0.f; ml[3] = 0.f;
+      po[16 * 64] = ml;
     }
-    __threadfence();  // release: the partial is visible to the whole device before the arrival is counted
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave has reached the L2 ...
+    __syncthreads();                                   // ... of every wave, before the arrival is counted
     unsigned* cnt = a.sp.cnt + x * 32 + pc.tloc;
     if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *(volatile int*)smem = old == (unsigned)(pc.np - 1) ? 1 : 0;
     }
     __syncthreads();
     if (*(volatile int*)smem) {
-      __threadfence();  // acquire: the other pieces' partials
+      asm volatile("" ::: "memory");
       const int np = pc.np;
+      constexpr size_t SLOT_V4 = ATTN_PART_FLOATS / 4;
+      const v4f* p0 = (const v4f*)slot0 + (wave * 17) * 64 + lane;
       float M = -3.0e38f;
-      for (int pi = 0; pi < np; ++pi) M = fmaxf(M, ((const v2f*)(slot0 + (size_t)pi * ATTN_PART_FLOATS + ATTN_PART_O_FLOATS))[wave * 64 + lane][0]);
+      for (int pi = 0; pi < np; ++pi) M = fmaxf(M, p0[pi * SLOT_V4 + 16 * 64][0]);
       v16f acc[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
       float lsum = 0.f;
-      for (int pi = 0; pi < np; ++pi) {
-        const float* sl = slot0 + (size_t)pi * ATTN_PART_FLOATS;
-        const v2f ml = ((const v2f*)(sl + ATTN_PART_O_FLOATS))[wave * 64 + lane];
-        const float f = __builtin_amdgcn_exp2f(ml[0] - M);
-        lsum = __builtin_fmaf(ml[1], f, lsum);
-        const v4f* po = (const v4f*)sl + (wave * 16) * 64 + lane;
+      // two pieces in flight: the loads of piece pi + 1 are issued before the multiply-adds of piece pi (fixed summation order)
+      v4f wa[17], wb[17];
+      auto ld = [&](v4f (&w)[17], int pi) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const v4f v = po[i * 64];
+        for (int i = 0; i < 17; ++i) w[i] = p0[pi * SLOT_V4 + i * 64];
+      };
+      auto fm = [&](const v4f (&w)[17]) {
+        const float f = __builtin_amdgcn_exp2f(w[16][0] - M);
+        lsum = __builtin_fmaf(w[16][1], f, lsum);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[i >> 2][(i & 3) * 4 + e] = __builtin_fmaf(v[e], f, acc[i >> 2][(i & 3) * 4 + e]);
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i >> 2][(i & 3) * 4 + e] = __builtin_fmaf(w[i][e], f, acc[i >> 2][(i & 3) * 4 + e]);
+      };
+      ld(wa, 0);
+      for (int pi = 0; pi < np; pi += 2) {
+        if (pi + 1 < np) ld(wb, pi + 1);
+        fm(wa);
+        if (pi + 1 < np) {
+          if (pi + 2 < np) ld(wa, pi + 2);
+          fm(wb);
         }
       }
       if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero between launches
@@ -588,7 +611,44 @@ void* attn_workspace(hipStream_t s) {
 }
 }  // namespace
 void fluxmi_set_attn_scratch(void* p) { t_attn_override = p; }
-int fluxmi_attn_plan_any(int B, int L, int H) { return fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256).on; }
+
+// The merge of the balanced grid goes through ONE XCD's L2 (see the kernel): it needs workgroup b of a 1-D grid to run on XCD b % 8, the
+// same for every launch.  Checked once per device on the hardware itself (512 one-wave workgroups record HW_REG_XCC_ID): 1 = holds, 0 = not
+// (the balanced grid stays off on that device), -1 = not known yet and the calling stream is capturing (this launch runs unsplit).
+namespace {
+__global__ void xcc_probe_kernel(unsigned* out) { out[blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }
+std::mutex g_xcc_mu;
+std::map<int, int> g_xcc_ok;
+}  // namespace
+int fluxmi_xcd_mapping_ok(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lk(g_xcc_mu);
+  auto it = g_xcc_ok.find(dev);
+  if (it != g_xcc_ok.end()) return it->second;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (s && (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return -1;
+  constexpr int N = 512;
+  unsigned* d = nullptr;
+  std::vector<unsigned> h(N, 99u);
+  int ok = 0;
+  if (hipMalloc((void**)&d, N * sizeof(unsigned)) == hipSuccess) {
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(N), dim3(64), 0, 0, d);
+    if (hipMemcpy(h.data(), d, N * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+      ok = 1;
+      for (int b = 0; b < N; ++b) ok = ok && h[b] == h[b & 7];                                   // a function of b % 8 ...
+      for (int u = 0; u < 8; ++u)
+        for (int v = u + 1; v < 8; ++v) ok = ok && h[u] != h[v];                                 // ... onto eight distinct XCDs
+    }
+    hipFree(d);
+  }
+  (void)hipGetLastError();
+  g_xcc_ok[dev] = ok;
+  return ok;
+}
+int fluxmi_attn_plan_any(int B, int L, int H) {
+  return fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256).on && fluxmi_xcd_mapping_ok(nullptr) == 1;
+}
 int fluxmi_attn_plan_export(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces) {
   if (B < 1 || L < 1 || H < 1) return 0;
   const AttnSplit sp = fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256);
@@ -611,14 +671,14 @@ template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArg
   memset(&a.sp, 0, sizeof(a.sp));
   const int tasks = ((a.L + 255) / 256) * a.H * a.B;
   const fluxmi_tuning_t tun = fluxmi_tuning();
-  if (FOLD && tun.attn_split) {
+  if (FOLD && tun.attn_split && fluxmi_xcd_mapping_ok(s) == 1) {
     AttnSplit sp = fluxmi_attn_plan(tasks, (a.L + KT - 1) / KT, 256);
     void* ws = sp.on ? attn_workspace(s) : nullptr;
     if (sp.on && ws) {
       sp.part = (float*)ws;
       sp.cnt = (unsigned*)((char*)ws + (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4);
-      // no CU idles in the last round any more: the weight prefetch rides in front of the piece workgroups (attn_split = 1) or is dropped (2)
-      sp.pf_fold = tun.attn_split == 1;
+      // no CU idles in the last round any more: the weight prefetch of this launch is dropped (attn_split = 1) or spread over all workgroups (2)
+      sp.pf_fold = tun.attn_split == 2;
       a.sp = sp;
       a.pf.wgs = 0;
       if (!sp.pf_fold) a.pf.n = 0;

@@ -26,15 +26,14 @@ struct AttnSplit {
   int n_per_x;     // tasks per XCD (= tasks / 8)
   int full_per_x;  // of which run whole (a multiple of 32)
   int npieces;     // pieces per XCD (launch order = order of `pieces`)
-  int pf_fold;     // 1: the weight prefetch rides in front of the piece workgroups instead of on extra workgroups (no CU idles any more)
+  int pf_fold;     // 1: the weight prefetch is spread over all workgroups, in front of their own work (no CU idles any more); 0: dropped
   int pad;
   float* part;     // [8][ATTN_MAX_PIECES] slots of ATTN_PART_FLOATS floats (slot = canonical piece index)
   unsigned* cnt;   // [8][32] arrival counters, zero between launches (the merging piece resets its task's)
   AttnPiece pieces[ATTN_MAX_PIECES];
 };
 static_assert(sizeof(AttnPiece) == 8, "AttnPiece is read as one 8-byte scalar load");
-constexpr int ATTN_PART_O_FLOATS = 8 * 16 * 64 * 4;                  // per slot: [wave][i < 16][lane] float4 = the 64 accumulator floats of every lane
-constexpr int ATTN_PART_FLOATS = ATTN_PART_O_FLOATS + 8 * 64 * 2;    // + [wave][lane] (m, l)
+constexpr int ATTN_PART_FLOATS = 8 * 17 * 64 * 4;                     // per slot: [wave][i < 17][lane] float4 = 16 x four accumulator floats of every lane, then (m, l, -, -)
 constexpr int ATTN_SPLIT_SNAP = 3;                                    // bin edges within 3 tiles of a task edge move onto it (no 1..3-tile pieces)
 constexpr int ATTN_SPLIT_MAXP = 8;                                    // pieces per task the plan accepts
 constexpr size_t ATTN_SPLIT_WS_BYTES = (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4 + 8 * 32 * 4;

@@ -123,10 +123,11 @@ typedef struct fluxmi_tuning {
                                                  (fluxmi_gemm_group_t.W_pairs: every L2 line of W fetched once per tile instead of twice) */
   int log;               /* FLUXMI_LOG           1: print the struct to stderr when it is resolved / set / an engine is created */
   int attn_split;        /* FLUXMI_ATTN_SPLIT    1 (default): attention launches whose workgroups leave a partial last round (432 on 256 CUs at
-                                                 Flux-dev 1024^2) cut the key range of that round's tasks into one bin per CU and merge the partial
-                                                 softmax states (fp32 log-sum-exp; deterministic): every CU finishes together; the weight prefetch
-                                                 of such a launch rides in front of the bin workgroups.  2 = the same without that prefetch,
-                                                 0 = one workgroup per task (rounds 1 - 4) */
+                                                 Flux-dev 1024^2) run that round's tasks as pieces of their key range, sized so that every CU
+                                                 finishes together, and merge the partial softmax states (fp32 log-sum-exp, fixed order:
+                                                 deterministic); see fluxmi_attention_plan.  Such a launch has no idle CUs and carries no weight
+                                                 prefetch; 2 = the same with the prefetch spread over all of its workgroups, 0 = one workgroup per
+                                                 task (rounds 1 - 4) */
 } fluxmi_tuning_t;
 int fluxmi_get_tuning(fluxmi_tuning_t* out);
 int fluxmi_set_tuning(const fluxmi_tuning_t* in); /* validates every field (non-zero + fluxmi_last_error on a bad value) */

@@ -255,3 +255,26 @@ def test_bench_single_rank_dry_run_and_failed_exchange():
     r, out = _run_bench(["--gpus", "2"], env={"FLUXMI_BENCH_FAIL_RANK": "1"}, timeout=400)
     assert r.returncode != 0 and not out, (r.returncode, r.stdout[-500:])
     assert "injected exchange failure" in r.stderr
+
+
+def test_bench_preflight_and_batched_config():
+    """`bench.py --gpus N --preflight`: the first contact of the N-rank plumbing without a model -- process group, rank-id
+    all-reduce, ONE broadcast of a request-sized payload (T5 states + CLIP vector + packed noise of every image), the latent gather -- one JSON
+    line from rank 0, and a DISTINCT exit status per failing stage (10 rendezvous, 11 all-reduce, 12 broadcast, 13 gather).  And `--config 4`
+    (BASELINE configs[3], batch 8): 8 / N images per rank through one engine each, value = image-steps per second of the whole job."""
+    r, out = _run_bench(["--gpus", "2", "--preflight"])
+    assert r.returncode == 0 and len(out) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    d = out[0]
+    assert d["preflight"] == "ok" and d["nranks"] == 2 and d["backend"] == "gloo" and d["batch"] == 2 and d["total_s"] < 30
+    assert d["broadcast_bytes"] == 2 * (512 * 4096 + 768 + 4096 * 64) * 2
+    for stage, code in (("allreduce", 11), ("broadcast:1", 12), ("gather", 13), ("rendezvous", 10)):
+        r, out = _run_bench(["--gpus", "2", "--preflight"], env={"FLUXMI_PREFLIGHT_FAIL": stage})
+        assert r.returncode != 0 and not out and f'"stage": "{stage.split(":")[0]}"' in r.stderr, (stage, r.returncode, r.stderr[-800:])
+        assert str(code) in r.stderr or r.returncode in (code, 1), (stage, r.returncode)  # torch.distributed.run reports the failing rank's exit code
+    r, out = _run_bench(["--gpus", "1", "--preflight", "--single-rank-group"])
+    assert r.returncode == 0 and out[0]["preflight"] == "ok" and out[0]["nranks"] == 1
+    r, out = _run_bench(["--gpus", "2", "--config", "4"])
+    assert r.returncode == 0 and len(out) == 1, r.stderr[-1500:]
+    d = out[0]
+    assert d["config"]["images_per_gpu"] == 4 and d["config"]["global_batch"] == 8 and d["n_gpus"] == 2
+    assert abs(d["value"] - 8 * d["loop_its_per_gpu"]) / d["value"] < 1e-3 and d["image_steps_per_s"] == d["value"]
