@@ -98,8 +98,6 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       tb = pc.tb;
       ntiles = pc.len;
     }
-    // no CU idles any more: the weight prefetch, when asked for, is spread over ALL workgroups, in front of their own work
-    if (a.sp.pf_fold && a.pf.n > 0) fluxmi_prefetch_ranges(a.pf, (int)blockIdx.x, main_wgs, tid, NW2 * 64);
   } else {
     lid = xcd_remap(blockIdx.x, nqb * a.H * a.B);  // whole heads per XCD: a head's K / V^T (2.4 MB at L = 4608) is fetched into one 4 MiB L2 once and shared by its q-blocks
   }
@@ -659,7 +657,12 @@ int fluxmi_attn_plan_export(int B, int L, int H, int* n_per_x, int* full_per_x, 
   if (pieces) memcpy(pieces, sp.pieces, sizeof(AttnPiece) * sp.npieces);
   return 1;
 }
-int fluxmi_attn_split_on(int B, int L, int H) { return fluxmi_tuning().attn_split ? fluxmi_attn_plan_any(B, L, H) : 0; }
+int fluxmi_attn_split_on(int B, int L, int H) {
+  const int mode = fluxmi_tuning().attn_split;
+  if (!mode || !fluxmi_attn_plan_any(B, L, H)) return 0;
+  const AttnSplit sp = fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256);
+  return mode == 2 || sp.n_per_x - sp.full_per_x <= 8;
+}
 
 template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArgs a, int fmt, hipStream_t s) {
   static bool attr = false;
@@ -673,15 +676,17 @@ template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArg
   const fluxmi_tuning_t tun = fluxmi_tuning();
   if (FOLD && tun.attn_split && fluxmi_xcd_mapping_ok(s) == 1) {
     AttnSplit sp = fluxmi_attn_plan(tasks, (a.L + KT - 1) / KT, 256);
+    // attn_split = 1: only THIN last rounds (at most 8 of an XCD's 32 CUs busy: every piece starts at once on a CU of its own).  Fuller
+    // ones were measured not to pay on this chip -- Flux-dev 1024^2, 22 of 32: 236 vs 223 - 235 us isolated, +3.4 % per step
+    // (profiles/r05_attention_split.txt); 2 forces the balanced grid wherever a plan exists (tests, probes)
+    if (sp.on && tun.attn_split == 1 && sp.n_per_x - sp.full_per_x > 8) sp.on = 0;
     void* ws = sp.on ? attn_workspace(s) : nullptr;
     if (sp.on && ws) {
       sp.part = (float*)ws;
       sp.cnt = (unsigned*)((char*)ws + (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4);
-      // no CU idles in the last round any more: the weight prefetch of this launch is dropped (attn_split = 1) or spread over all workgroups (2)
-      sp.pf_fold = tun.attn_split == 2;
       a.sp = sp;
+      a.pf.n = 0;  // no CU idles in the last round any more: nothing for the weight prefetch to ride on
       a.pf.wgs = 0;
-      if (!sp.pf_fold) a.pf.n = 0;
     }
   }
   const dim3 grid((a.sp.on ? 8 * (a.sp.full_per_x + a.sp.npieces) : tasks) + (a.pf.n > 0 ? a.pf.wgs : 0));

@@ -26,8 +26,7 @@ struct AttnSplit {
   int n_per_x;     // tasks per XCD (= tasks / 8)
   int full_per_x;  // of which run whole (a multiple of 32)
   int npieces;     // pieces per XCD (launch order = order of `pieces`)
-  int pf_fold;     // 1: the weight prefetch is spread over all workgroups, in front of their own work (no CU idles any more); 0: dropped
-  int pad;
+  int pad[2];
   float* part;     // [8][ATTN_MAX_PIECES] slots of ATTN_PART_FLOATS floats (slot = canonical piece index)
   unsigned* cnt;   // [8][32] arrival counters, zero between launches (the merging piece resets its task's)
   AttnPiece pieces[ATTN_MAX_PIECES];

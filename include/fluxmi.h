@@ -122,12 +122,11 @@ typedef struct fluxmi_tuning {
   int w_pairs;           /* FLUXMI_W_PAIRS       1: the engine keeps a row-pair copy of the F8Linear weights its persistent GEMM launches read
                                                  (fluxmi_gemm_group_t.W_pairs: every L2 line of W fetched once per tile instead of twice) */
   int log;               /* FLUXMI_LOG           1: print the struct to stderr when it is resolved / set / an engine is created */
-  int attn_split;        /* FLUXMI_ATTN_SPLIT    1 (default): attention launches whose workgroups leave a partial last round (432 on 256 CUs at
-                                                 Flux-dev 1024^2) run that round's tasks as pieces of their key range, sized so that every CU
-                                                 finishes together, and merge the partial softmax states (fp32 log-sum-exp, fixed order:
-                                                 deterministic); see fluxmi_attention_plan.  Such a launch has no idle CUs and carries no weight
-                                                 prefetch; 2 = the same with the prefetch spread over all of its workgroups, 0 = one workgroup per
-                                                 task (rounds 1 - 4) */
+  int attn_split;        /* FLUXMI_ATTN_SPLIT    1 (default): attention launches whose last round of workgroups is THIN (at most 8 of an XCD's
+                                                 32 CUs busy: 264 tasks on 256 CUs at Flux-dev 768^2) run that round's tasks as pieces of
+                                                 their key range and merge the partial softmax states (fp32 log-sum-exp in a fixed order:
+                                                 deterministic); see fluxmi_attention_plan.  2 = wherever such a plan exists (fuller last
+                                                 rounds: measured not to pay, Flux-dev 1024^2 +3.4 % per step), 0 = one workgroup per task */
 } fluxmi_tuning_t;
 int fluxmi_get_tuning(fluxmi_tuning_t* out);
 int fluxmi_set_tuning(const fluxmi_tuning_t* in); /* validates every field (non-zero + fluxmi_last_error on a bad value) */
@@ -224,8 +223,8 @@ int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, lo
                      void* stream);
 
 /* The launch plan of the kernel above for B x H heads of L keys on a 256-CU part (host arithmetic only, no GPU needed; tests + bench notes).
- * The kernel runs one workgroup of 256 query rows per (head, row block) -- a TASK -- and one workgroup per CU at a time, so 432 tasks take two
- * rounds with 80 CUs idle in the second.  Under fluxmi_tuning_t.attn_split (default on; fp16-K calls only) every XCD runs full_per_x of
+ * The kernel runs one workgroup of 256 query rows per (head, row block) -- a TASK -- and one workgroup per CU at a time, so 264 tasks take two
+ * rounds for 1.03 rounds of work.  Under fluxmi_tuning_t.attn_split (fp16-K calls only; 1 = thin last rounds, 2 = always) every XCD runs full_per_x of
  * its n_per_x tasks whole and the remaining ones as `npieces` PIECES of their key range, launched longest first, so that every CU ends
  * up with the same number of key tiles; a piece writes its softmax state (O, m, l; fp32) to a scratch slot and the piece that arrives
  * last at the task's counter merges them in piece order -- the result does not depend on the arrival order.  Returns 1 when such a plan

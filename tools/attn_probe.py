@@ -8,7 +8,7 @@ from fluxmi import ops
 ap = argparse.ArgumentParser(); ap.add_argument("--L", type=int, default=4608); ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--B", type=int, default=1)
 ap.add_argument("--bf16-k", action="store_true", help="bf16 K (unfolded kernel) instead of the engine's fp16 K (folded kernel)")
-ap.add_argument("--split", default=None, help="comma list of fluxmi_tuning_t.attn_split values to time in turn, e.g. 0,1 (default: the library's setting)")
+ap.add_argument("--split", default=None, help="comma list of fluxmi_tuning_t.attn_split values to time in turn, e.g. 0,2 (2 = balanced grid wherever a plan exists; default: the library's setting)")
 a = ap.parse_args()
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 B, H, L = a.B, 24, a.L
@@ -34,6 +34,8 @@ for sp in ([None] if a.split is None else [int(x) for x in a.split.split(",")] *
             ts.append(e0.elapsed_time(e1) / a.iters * 1e-3)
     t = sorted(ts)[len(ts) // 2]
     plan = ops.attention_plan(B, L, H) if (sp is None or sp) and not a.bf16_k else None
+    if plan and (sp is None or sp == 1) and plan["n_per_x"] - plan["full_per_x"] > 8:
+        plan = None  # attn_split = 1: thin last rounds only
     print(f"attention B={B} H={H} L={L} attn_split={'default' if sp is None else sp}"
           f" ({'balanced grid: %d whole tasks + %d pieces per XCD' % (plan['full_per_x'], len(plan['pieces'])) if plan else 'one workgroup per task'}): "
           f"{4 * L * L * 128 * H * B / t / 1e12:7.1f} TF/s ({t * 1e6:.1f} us)", flush=True)
