@@ -22,8 +22,11 @@ void fluxmi_set_error(const char* fmt, ...) {
 // Tile choice: minimise (#waves of tiles over the 256 CUs) x (per-tile cost).  Relative per-tile
 // efficiencies were measured on MI355X (profiles/r01_kernel_sweep.txt); fluxmi_tuning_t.gemm_cfg overrides.
 int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8) {
+  // a forced tile config (FLUXMI_GEMM_CFG) is taken where it applies; the persistent kernel (18 / its timing build 19) has conditions on
+  // the operand format and the epilogue that this function does not see: run_gemm_chunk applies it after fluxmi_gemm_persist_ok, and a
+  // launch it does not fit falls back to the cost model below instead of failing in the launcher
   const int forced = fluxmi_tuning().gemm_cfg;
-  if (forced >= 0 && fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, forced)) return forced;
+  if (forced >= 0 && forced != 18 && forced != 19 && fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, forced)) return forced;
   // candidates, in order of preference at equal cost; eff = measured relative rate per flop on MI355X at full occupancy
   // (profiles/r01_kernel_sweep.txt): 13 = 256x256 ping-pong ring (1 block/CU), 2 = 128x128 double-buffered (2 blocks/CU), 15 = 128x64
   // (narrow N).  Cost = (number of block waves) x (time of one wave of blocks).
@@ -66,6 +69,10 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
   for (int i = 0; i < n; ++i) p.g[i] = gs[i];
   p.N = N; p.K = K; p.epi = epi;
   int cfg = force_cfg >= 0 && fluxmi_gemm_tile_ok(N, K, is_fp8, force_cfg) ? force_cfg : fluxmi_gemm_auto_cfg(p, is_fp8);
+  {
+    const int forced = fluxmi_tuning().gemm_cfg;
+    if (force_cfg < 0 && (forced == 18 || forced == 19) && fluxmi_gemm_tile_ok(N, K, is_fp8, 13) && fluxmi_gemm_persist_ok(p, is_fp8, act_fmt)) cfg = forced;
+  }
   // small-M launches (M <= 512: schnell 256x256, the text encoders, the modulation GEMMs): 24-96 tiles of 256x256 for 256 CUs, weight-stream
   // bound -> split K over several workgroups per tile (fp32 partials + a reduce / epilogue pass).  fluxmi_tuning_t.gemm_splitk = 0 turns it off;
   // fluxmi_gemm_grouped(tile_cfg = 113 + S) forces S splits (tests).

@@ -176,11 +176,20 @@ int ensure_pairs(E* e, hipStream_t s) {
       for (int sl : {D_IMG_QKV, D_TXT_QKV, D_IMG_MLP0, D_TXT_MLP0, D_IMG_MLP2, D_TXT_MLP2}) want(DLi(e, i, sl));
     for (int i = 0; i < e->d.depth_single; ++i) { want(SLi(e, i, S_LIN1)); want(SLi(e, i, S_LIN2)); }
   }
+  if (total == 0 && e->pairs) {  // switched off (fluxmi_tuning_t.w_pairs = 0): give the memory back
+    FLUXMI_CHECK_HIP(hipStreamSynchronize(s));
+    hipFree(e->pairs);
+    e->pairs = nullptr; e->pairs_bytes = 0;
+  }
   if (total > e->pairs_bytes) {
     if (e->pairs) hipFree(e->pairs);
     e->pairs = nullptr; e->pairs_bytes = 0;
-    if (hipMalloc((void**)&e->pairs, total) != hipSuccess) {
-      // no room for the copies: run without them (same results)
+    // The copies are an optimisation (same results without them): they must not take the memory the caller still needs -- the torch
+    // allocator's next block, the VAE's 5.9 GB of patch matrices -- so they are only made while at least as much again (and 4 GiB) stays free
+    size_t free_b = 0, total_b = 0;
+    const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= 2 * total + ((size_t)4 << 30);
+    if (!room || hipMalloc((void**)&e->pairs, total) != hipSuccess) {
+      // no room for the copies: run without them
       (void)hipGetLastError();
       e->pairs_off.assign(n, -1);
       e->pairs_dirty = false;
@@ -938,7 +947,18 @@ int fluxmi_engine_rebind(fluxmi_engine_t* e, const fluxmi_linear_t* linears, int
   e->txt_emb_valid = false;
   e->pairs_dirty = true;
   e->qlut_valid = false;
-  if (e->ws) return build_gemv_table(e, 0);
+  if (e->ws) {
+    // the split-K scratch is sized by the linears' kinds (bf16 linears with long K): a rebind that introduces such linears (an fp8
+    // model re-bound to bf16 weights) drops the workspace, and the next fluxmi_engine_prepare allocates one with the scratch
+    auto it = e->bufs.find("splitk");
+    const bool have = it != e->bufs.end() && it->second.n >= FLUXMI_SPLITK_WS_BYTES;
+    if (needs_splitk(e) && !have) {
+      FLUXMI_CHECK_HIP(hipDeviceSynchronize());
+      free_ws(e);
+      return 0;
+    }
+    return build_gemv_table(e, 0);
+  }
   return 0;
 }
 

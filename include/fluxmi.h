@@ -312,7 +312,13 @@ int fluxmi_engine_destroy(fluxmi_engine_t* e);
 /* constant tables computed by the host with the reference's own expressions: timestep frequencies
  * exp(-ln(1e4)*i/128) (flux_model.py:106-110), RoPE omega per pair and the id axis each pair uses (flux_model.py:50-51,84-90) */
 int fluxmi_engine_set_tables(fluxmi_engine_t* e, const float* freqs128, const float* omega64, const int* axis64);
-/* re-read weight pointers / kinds after a LoRA fuse or dtype swap (float8_quantize.py:209-212) */
+/* re-read weight pointers / kinds after a LoRA fuse or dtype swap (float8_quantize.py:209-212).  MANDATORY after ANY write to a weight
+ * the engine was created / last re-bound with, even an in-place one that keeps the pointer: the engine SNAPSHOTS weights -- its GEMMs read a
+ * row-pair copy of the block linears' fp8 weights (fluxmi_tuning_t.w_pairs, rebuilt on the first launch after a rebind), the 64 KiB
+ * quantising-epilogue tables and the captured step graph are derived from the scales.  A write without a rebind is silently ignored.
+ * The copies are made only while the device has at least twice their size + 4 GiB free (else the GEMMs read the caller's weights: same
+ * results) and are freed when w_pairs is switched off.  A rebind that changes which linears are bf16 may drop the workspace: call
+ * fluxmi_engine_prepare again before the next forward (the host wrapper does, per call). */
 int fluxmi_engine_rebind(fluxmi_engine_t* e, const fluxmi_linear_t* linears, int n_linears);
 /* per-request setup: (re)allocates the workspace for (B, Li, Lt), builds the RoPE table from the position ids
  * (step-invariant: flux_model.py:701-702) */

@@ -344,6 +344,69 @@ def test_gemm_persistent_matches_ping_pong(ops, dev, case):
         assert torch.isfinite(results[18][-1].view(torch.bfloat16).float()[:, :Hh]).all()
 
 
+@pytest.mark.parametrize("epi_name", ["bf16", "gate_resid", "gelu table", "split"])
+def test_gemm_persistent_store_canary(ops, dev, epi_name):
+    """Canary for the code-generation hazards gemm_persist.hip works around: hipcc 7.2 omits the data-VGPR-overwrite hazard of
+    a 128-bit buffer_store whose soffset is a register -- 300 to 35 000 wrong bytes PER LAUNCH, different ones every time -- so the kernel
+    keeps soffset at 0 and nothing at build time would notice a toolchain that brings the problem back.  Twenty back-to-back launches of the
+    persistent kernel (tile config 18) per epilogue, on row counts whose tile bands are PARTIAL (7 + 11 row tiles: 18 % PS_GROUP_M(4) != 0,
+    ragged last tiles), every output byte of every launch against config 13's; and the one-wave-per-SIMD kernel (config 16) on a launch whose
+    last band is partial for ITS band height (7 row tiles % W1_GROUP_M(6) = 1).                             float8_quantize.py:284-292"""
+    from fluxmi import _lib
+
+    torch.manual_seed(29)
+    Hh, K = 512, 1024
+    one, qs = torch.tensor(1.0, device=dev), torch.tensor(41.0, device=dev)
+    lut = ops.build_quant_lut(qs, E5M2, act=1)
+    epi, N = {"bf16": (_lib.EPI_BF16, 2048), "gate_resid": (_lib.EPI_GATE_RESID, 3072), "gelu table": (_lib.EPI_GELU_QUANT, 4096),
+              "split": (_lib.EPI_SPLIT, 3 * Hh + 4096)}[epi_name]
+    Ms = [1800, 2600]  # 8 + 11 row tiles, both ragged
+    a = [(torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2) for M in Ms]
+    w = [(torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn) for _ in Ms]
+    bias = torch.randn(N, device=dev).bfloat16()
+    gate = torch.randn(N, device=dev).bfloat16()
+    resid = [torch.randn(M, N, device=dev).bfloat16() for M in Ms]
+    sar = torch.tensor(0.41, device=dev)
+
+    def launch(cfg):
+        groups, outs = [], []
+        for gi, M in enumerate(Ms):
+            kw = {}
+            if epi == _lib.EPI_BF16:
+                o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            elif epi == _lib.EPI_GELU_QUANT:
+                o = torch.zeros(M, N, dtype=torch.uint8, device=dev).view(torch.float8_e5m2)
+                kw = dict(q_scale=qs.data_ptr(), q_lut=lut.data_ptr())
+            elif epi == _lib.EPI_GATE_RESID:
+                o = resid[gi].clone()
+                kw = dict(gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N)
+            else:
+                o = torch.full((M, 3 * Hh), float("nan"), dtype=torch.bfloat16, device=dev)
+                o2 = torch.zeros(M, Hh + (N - 3 * Hh), dtype=torch.uint8, device=dev).view(torch.float8_e5m2)
+                outs.append(o2)
+                kw = dict(C2=o2.data_ptr(), ldc2=o2.stride(0), split_n=3 * Hh, c2_col0=Hh, q_scale=qs.data_ptr(), q_lut=lut.data_ptr())
+            outs.append(o)
+            groups.append(ops.make_group(a[gi].data_ptr(), w[gi].data_ptr(), bias.data_ptr(), sar.data_ptr(), one.data_ptr(), o.data_ptr(), M, K, o.stride(0), **kw))
+        ops.gemm_grouped(groups, N, K, True, E5M2, epi, cfg)
+        torch.cuda.synchronize()
+        return [o.view(torch.uint8).clone() for o in outs]
+
+    ref = launch(13)
+    bad = 0
+    for it in range(20):
+        for x13, x18 in zip(ref, launch(18)):
+            bad += int((x13 != x18).sum())
+    assert bad == 0, f"{epi_name}: {bad} bytes of 20 persistent-kernel launches differ from config 13"
+    if epi in (_lib.EPI_BF16, _lib.EPI_GATE_RESID):  # config 16 carries these two epilogues in the step (mlp.2, linear2): partial last band of 6
+        Ms[:] = [1700]  # 7 row tiles
+        a[:] = [(torch.randn(1700, K, device=dev) * 2).to(torch.float8_e5m2)]
+        resid[:] = [torch.randn(1700, N, device=dev).bfloat16()]
+        ref = launch(13)
+        for it in range(5):
+            for x13, x16 in zip(ref, launch(16)):
+                assert torch.equal(x13, x16), f"{epi_name}: config 16 differs from config 13 on a launch with a partial last tile band"
+
+
 def test_gemm_persistent_quantising_paths_exhaustive(ops, dev):
     """The persistent kernel's table epilogue (table DMA issued inside the last K-step into ring slots 2 / 3, gather, transposition through
     the per-wave scratch) over EVERY bf16 input: A = 0, so h = bf16(0 * s + bias) is the bias pattern itself; the bias runs through all
