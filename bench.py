@@ -722,6 +722,7 @@ def main():
     ap.add_argument("--depth", type=int, default=None, help="debug only: fewer blocks (the result is then flagged invalid)")
     ap.add_argument("--preflight", action="store_true", help="check the N-rank plumbing (group, all-reduce, request broadcast, latent gather) and exit; no model")
     ap.add_argument("--no-step-trace", action="store_true", help="skip the extra request under rocprofv3 --kernel-trace (roofline.frac is then the isolated probe's)")
+    ap.add_argument("--keep-trace", action="store_true", help="keep the raw rocprofv3 CSVs of the step trace under gpurun_out/step_trace_config<id>/")
     ap.add_argument("--no-probe", action="store_true", help="skip the isolated GEMM / attention probe loops (used by the step-trace child)")
     ap.add_argument("--single-rank-group", action="store_true",
                     help="N = 1 only: create a one-rank process group anyway and run every collective of the N > 1 path through it (broadcast, "
@@ -979,6 +980,11 @@ def main():
                     if step:
                         with open(os.path.join(d, "steady_step.txt"), "w") as f:
                             f.write(step.pop("text"))
+                    if d and not args.keep_trace:  # the raw trace is ~13 MB per run; the summary is what gets committed under profiles/
+                        import glob
+
+                        for f in glob.glob(os.path.join(d, "**", "*.csv"), recursive=True):
+                            os.remove(f)
                 if sec:
                     probe = {"probe_achieved": round((fl if fp8 else by) / sec / (1e12 if fp8 else 1e9), 1),
                              "probe_frac": round((fl / sec / 1e12 / FP8_PEAK_TFLOPS) if fp8 else (by / sec / 1e9 / HBM_PEAK_GBS), 4),
