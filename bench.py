@@ -231,7 +231,7 @@ def measure_attention(torch, ops, dev, L, iters=10, H=24, batch=1):
 
 
 def pmc_file(kind, cfg_id):
-    return os.path.join(ROOT, "profiles", f"r04_{kind}_config{cfg_id}.json")
+    return os.path.join(ROOT, "profiles", f"r05_{kind}_config{cfg_id}.json")
 
 
 def read_pmc(kind, cfg_id):
@@ -274,7 +274,7 @@ def collect_pmc(cfg_id, Li, Lt):
 
 
 def summarize_pmc(cfg_id, Li, Lt):
-    """raw CSVs -> profiles/r04_{traffic,mfma}_config<id>.json, keyed by the kernel-source hash.  HBM bytes per launch =
+    """raw CSVs -> profiles/r05_{traffic,mfma}_config<id>.json, keyed by the kernel-source hash.  HBM bytes per launch =
     (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 tallies a 128-B fabric read at 64 B: MI355X_MICROARCH.md 'HBM'); matrix-pipe busy fraction =
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs).  The first dispatch of every kernel (cold caches, lazy init) is
     dropped; the 256x256 kernels of a launch are summed with its 128x128 peel."""
@@ -377,8 +377,15 @@ def summarize_step_trace(path, header=""):
     first = last
     while first > 0 and not any(any(t in ks[j][0] for t in setup) for j in range(eul[first - 1], eul[first])):
         first -= 1
+    whole_requests = False
     if last - first < 1:
-        return None
+        # one-step requests (config 1): there is no step without the request's set-up -- it IS part of every step of such a workload.
+        # Window = the last (up to 24) requests, everything between their euler kernels included
+        first, whole_requests = max(1, last - 24), True
+        while first < last and any(any(t in ks[j][0] for t in ("amax_kernel", "calib_update")) for j in range(eul[first - 1], eul[last])):
+            first += 1
+        if last - first < 1:
+            return None
     t0, t1, steps = ks[eul[first]][2], ks[eul[last]][2], last - first
 
     def short(name):
@@ -408,7 +415,7 @@ def summarize_step_trace(path, header=""):
     out["gemm_launches"] = round(sum(c for k, (c, _) in rows.items() if any(x in k for x in FAMILIES[0][1])) / steps, 1)
     out["attention_us"] = round(fam["attention"] / max(1, sum(c for k, (c, _) in rows.items() if "attention" in k)) / 1e3, 2)
     lines = ([header] if header else []) + [
-        f"# steady state: {steps} graph-replayed denoise steps of the last request, wall {wall:.3f} ms/step, kernel time {tot / steps / 1e6:.3f} ms/step, "
+        f"# steady state: {steps} graph-replayed denoise steps " + ("= one-step requests, each with its set-up (modulation table, txt_in)" if whole_requests else "of the last request") + f", wall {wall:.3f} ms/step, kernel time {tot / steps / 1e6:.3f} ms/step, "
         f"{out['launches']:.0f} launches/step; per step: GEMM family {out['gemm_ms']:.3f} ms, attention {out['attention_ms']:.3f}, LayerNorm+modulate "
         f"{out['ln_ms']:.3f}, other {out['other_ms']:.3f}, gaps {out['gaps_ms']:.3f}; columns are totals over those steps (ns resolution -> us)",
         f"{'kernel':112s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'%':>6s}"]
@@ -714,7 +721,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--pmc", action="store_true", help="force the live rocprofv3 PMC passes (default: on at N = 1 when rocprofv3 is on PATH)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (~2 min)")
-    ap.add_argument("--pmc-summarize", action="store_true", help="no GPU: rebuild profiles/r04_*_config<id>.json from gpurun_out/pmc_config<id>/")
+    ap.add_argument("--pmc-summarize", action="store_true", help="no GPU: rebuild profiles/r05_*_config<id>.json from gpurun_out/pmc_config<id>/")
     ap.add_argument("--requests", type=int, default=3, help="timed repeats of the K steps (each bracketed and timed on its own; the median is reported)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 (nccl = RCCL over xGMI)")
