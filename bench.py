@@ -426,6 +426,120 @@ def summarize_step_trace(path, header=""):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
+# --pmc-step: hardware counters of the kernels INSIDE the step (opt-in: three more child runs, ~1 min each)
+# ---------------------------------------------------------------------------------------------------------------------------
+STEP_PMC_PASSES = (["FETCH_SIZE"], ["WRITE_SIZE"], ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"])  # FETCH_SIZE and WRITE_SIZE do not fit one pass
+
+
+def step_source_key():
+    """content hash of every kernel source (the in-step counters cover all of them)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "flux-fp8-api_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def step_pmc_file(cfg_id):
+    return os.path.join(ROOT, "profiles", f"r05_step_pmc_config{cfg_id}.json")
+
+
+def collect_step_pmc(args, timeout_s=300.0):
+    """The workload once more per counter set, EAGER launches (one AQL dispatch per kernel, what the counter collection serialises anyway), a
+    short request: `rocprofv3 --kernel-trace --pmc <set>` -- counters in their own runs, never combined with API traces."""
+    import shutil
+
+    root = os.path.join(ROOT, "gpurun_out", f"step_pmc_config{args.config}")
+    shutil.rmtree(root, ignore_errors=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "FLUXMI_BENCH_CHILD"):
+        env.pop(k, None)
+    for pi, counters in enumerate(STEP_PMC_PASSES):
+        d = os.path.join(root, f"p{pi}")
+        os.makedirs(d, exist_ok=True)
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+               "--config", str(args.config), "--steps", "6" if CONFIGS[args.config]["steps_per_request"] is None else "8", "--warmup", "2", "--requests", "1",
+               "--no-graph", "--no-pmc", "--no-cpu-baseline", "--no-step-trace", "--no-probe"] + (["--depth", str(args.depth)] if args.depth is not None else [])
+        try:
+            subprocess.run(cmd, env=env, cwd="/tmp", check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        except Exception as ex:  # noqa
+            print(f"bench: step PMC pass {counters} failed: {ex}", file=sys.stderr)
+    return root
+
+
+def summarize_step_pmc(root, cfg_id, ms_per_step=None):
+    """counter_collection.csv of the three passes -> per kernel family, per steady step of the last request: HBM-side bytes
+    ((2 x FETCH_SIZE + WRITE_SIZE) KiB: gfx950 tallies a 128-byte fabric read at 64 B, MI355X_MICROARCH.md 'HBM'; Infinity-Cache hits count)
+    and the matrix-pipe busy fraction SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs).  Written to profiles/ with the
+    kernel-source hash."""
+    import csv
+    import glob
+
+    tot = {}
+    steps_seen = None
+    for pi, counters in enumerate(STEP_PMC_PASSES):
+        rows = {}
+        for path in glob.glob(os.path.join(root, f"p{pi}", "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for r in csv.DictReader(f):
+                    rows.setdefault(int(r["Dispatch_Id"]), [r["Kernel_Name"], {}])[1][r["Counter_Name"]] = float(r["Counter_Value"])
+        seq = [rows[k] for k in sorted(rows)]
+        eul = [i for i, (n, _c) in enumerate(seq) if "euler_kernel" in n]
+        if len(eul) < 2:
+            continue
+        setup = ("amax_kernel", "calib_update", "timestep_rows_kernel", "build_qlut")
+        last = len(eul) - 1
+        first = last
+        while first > 0 and not any(any(t in seq[j][0] for t in setup) for j in range(eul[first - 1], eul[first])):
+            first -= 1
+        if last - first < 1:
+            first = max(1, last - 6)  # one-step requests: whole requests, set-up included
+        steps = last - first
+        steps_seen = steps if steps_seen is None else min(steps_seen, steps)
+        for n, c in seq[eul[first] + 1: eul[last] + 1]:
+            fam = next((f for f, keys in FAMILIES if any(x in n for x in keys)), "other")
+            for cn, v in c.items():
+                tot.setdefault(fam, {}).setdefault(cn, 0.0)
+                tot[fam][cn] += v / steps
+    if not tot or steps_seen is None:
+        return None
+    out = {"source_key": step_source_key(), "steps": steps_seen,
+           "how": "bench.py --pmc-step: rocprofv3 --kernel-trace --pmc <set> -- python bench.py --no-graph --steps 6 ... (one child run per counter set), steady steps of the last request",
+           "formula": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)", "per_step": {}}
+    all_b = 0.0
+    all_busy = [0.0, 0.0]
+    for fam, c in tot.items():
+        e = {}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            e["hbm_bytes"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+            e["fetch_bytes"], e["write_bytes"] = 2.0 * c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
+            all_b += e["hbm_bytes"]
+        if c.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            e["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+            all_busy[0] += c["SQ_VALU_MFMA_BUSY_CYCLES"]
+            all_busy[1] += c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        out["per_step"][fam] = e
+    out["hbm_bytes_per_step"] = all_b
+    out["mfma_busy_frac_step"] = round(all_busy[0] / all_busy[1], 4) if all_busy[1] else None
+    if ms_per_step:
+        out["hbm_gbs_at_timed_ms_per_step"] = round(all_b / (ms_per_step * 1e-3) / 1e9, 1)
+        out["ms_per_step_timed"] = ms_per_step
+    with open(step_pmc_file(cfg_id), "w") as f:
+        json.dump(out, f, indent=1)
+    return out
+
+
+def read_step_pmc(cfg_id):
+    try:
+        with open(step_pmc_file(cfg_id)) as f:
+            d = json.load(f)
+        return d if d.get("source_key") == step_source_key() else None
+    except Exception:  # noqa
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 # --preflight: first contact of the N-rank plumbing (no model, < 30 s)
 # ---------------------------------------------------------------------------------------------------------------------------
 PREFLIGHT_CODES = {"rendezvous": 10, "allreduce": 11, "broadcast": 12, "gather": 13}
@@ -729,6 +843,8 @@ def main():
     ap.add_argument("--depth", type=int, default=None, help="debug only: fewer blocks (the result is then flagged invalid)")
     ap.add_argument("--preflight", action="store_true", help="check the N-rank plumbing (group, all-reduce, request broadcast, latent gather) and exit; no model")
     ap.add_argument("--no-step-trace", action="store_true", help="skip the extra request under rocprofv3 --kernel-trace (roofline.frac is then the isolated probe's)")
+    ap.add_argument("--pmc-step", action="store_true", help="also collect hardware counters of the kernels INSIDE the step (HBM-side bytes, matrix-pipe busy): three more "
+                    "child runs under rocprofv3 --pmc, ~1 min each; the result is kept in profiles/r05_step_pmc_config<id>.json and reported while the kernel sources match")
     ap.add_argument("--keep-trace", action="store_true", help="keep the raw rocprofv3 CSVs of the step trace under gpurun_out/step_trace_config<id>/")
     ap.add_argument("--no-probe", action="store_true", help="skip the isolated GEMM / attention probe loops (used by the step-trace child)")
     ap.add_argument("--single-rank-group", action="store_true",
@@ -1020,6 +1136,18 @@ def main():
                             src["mfma_busy"] = "live (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass run by this command)"
                     except Exception as ex:  # the counters must never take the measurement down
                         print(f"bench: PMC collection failed: {ex}", file=sys.stderr)
+                step_pmc = None
+                if world == 1 and have_prof and args.pmc_step:
+                    try:
+                        step_pmc = summarize_step_pmc(collect_step_pmc(args), args.config, ms_per_step=round(ms_per_step, 3))
+                    except Exception as ex:  # noqa
+                        print(f"bench: step PMC failed: {ex}", file=sys.stderr)
+                if step_pmc is None:
+                    step_pmc = read_step_pmc(args.config)
+                    if step_pmc is not None:
+                        step_pmc = dict(step_pmc, source="committed file profiles/" + os.path.basename(step_pmc_file(args.config)) + " (same kernel sources, earlier run)")
+                else:
+                    step_pmc = dict(step_pmc, source="live (bench.py --pmc-step)")
                 traffic, busy = (read_pmc("traffic", args.config), read_pmc("mfma", args.config)) if ipg == 1 else (None, None)
                 if traffic and src["traffic"] is None:
                     src["traffic"] = "committed file profiles/" + os.path.basename(pmc_file("traffic", args.config)) + " (same kernel sources, earlier run)"
@@ -1047,6 +1175,7 @@ def main():
                              "flops_per_launch": lin_flops / n_lin, "algorithmic_bytes_per_launch": by, "avg_launch_us": None if avg_us is None else round(avg_us, 2),
                              "launches_per_step": n_lin, "mfma_busy_frac_pmc": busy_w, "launches": gemm_table,
                              "step": None if not step else {k: step[k] for k in ("steps", "wall_ms", "gemm_ms", "attention_ms", "ln_ms", "other_ms", "gaps_ms", "kernel_ms", "launches")},
+                             "step_pmc": None if not step_pmc else {k: v for k, v in step_pmc.items() if k not in ("how", "formula")},
                              "attention": attn_row})
                 if step and attn_row is not None:
                     a_s = step["attention_ms"] * 1e-3
