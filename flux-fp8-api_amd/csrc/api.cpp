@@ -111,6 +111,18 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
     t256 *= N / 256;
     if (t256 > 256) cfg = fluxmi_tuning().gemm_persist == 2 ? 19 : 18;  // 2: the timing build (probes: fluxmi_gemm_debug_buffer)
   }
+  // gate*y+x launches of the one-wave-per-SIMD kernel whose 256-row tiling fills less than one round of the 256 CUs (Flux-dev 768^2: M = 2816 ->
+  // 11 x 12 = 132 tiles on mlp.2 / linear2): 192-row tiles (config 17, same kernel, same bits) are three quarters of the work each, and
+  // 15 x 12 = 180 of them still run in one round.  Taken when rounds x tile work drops by more than 5 % (the smaller tile reads 8 % more
+  // fragment bytes per MFMA); fluxmi_tuning_t.gemm_tile192 = 0 turns it off.
+  if (cfg == 16 && force_cfg < 0 && is_fp8 && act_fmt == FLUXMI_E5M2 && epi == FLUXMI_EPI_GATE_RESID && fluxmi_tuning().gemm_cfg < 0 &&
+      fluxmi_tuning().gemm_tile192 && fluxmi_gemm_tile_ok(N, K, is_fp8, 17)) {
+    long long t256 = 0, t192 = 0;
+    for (int i = 0; i < n; ++i) { t256 += (gs[i].M + 255) / 256; t192 += (gs[i].M + 191) / 192; }
+    t256 *= N / 256; t192 *= N / 256;
+    const double c256 = (double)((t256 + 255) / 256), c192 = (double)((t192 + 255) / 256) * 0.75 * 1.04;
+    if (c192 < 0.95 * c256) cfg = 17;
+  }
   const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0);
   if (cfg < 0 || !split_ok) return fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, s);
   return fluxmi_launch_gemm(p, is_fp8, act_fmt, cfg, s);

@@ -15,6 +15,11 @@
 //    that ring slots are immediates;
 //  * epilogue through LDS as in the ring kernels (the idle ring is the transposition scratch, 32 KiB per wave).
 // Requires K*bytes % 256 == 0 (four K-steps per unrolled iteration).
+//
+// Round 5: TM_ = 3 instantiates the same kernel on 192 x 256 tiles (wave tiles 96 x 128; tile config 17) for the gate*y+x launches whose
+// 256-row tiling leaves half the chip idle -- Flux-dev 768^2: M = 2816 gives 11 x 12 = 132 tiles for 256 CUs on mlp.2 / linear2 (9.7 of the
+// step's 30 ms at 48 % occupancy); 15 x 12 = 180 tiles of three quarters the work run in one round as well.  Same K loop, same MFMAs in
+// the same order: every output bit equals config 16's.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -28,11 +33,13 @@ struct W1Frags { v8i fw[4]; v8i fa[4]; };
 // ESEL >= 0: the kernel is compiled for ONE epilogue (the hot ones get their own instantiation: with the run-time switch over six inlined
 // epilogues hipcc allocates registers for all of them at once and spilled ~110 ACCUMULATOR pairs to scratch right after the K loop -- on every
 // path, each reload behind an s_waitcnt vmcnt(0)); ESEL = -1 keeps the switch (cold epilogues)
-template <bool FP8, int ACT_FMT, int ESEL>
+template <bool FP8, int ACT_FMT, int ESEL, int TM_ = 4>
 __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams P) {
-  constexpr int BM = 256, BN = 256, NT = 256, TM = 4, TN = 4, NS = 4;
+  constexpr int TM = TM_, TN = 4, BM = 2 * TM * 32, BN = 256, NT = 256, NS = 4;
   constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
-  constexpr int LPT = 8;  // LDS-DMA pieces per wave per K-step (4 of A, 4 of W)
+  constexpr int NA = TM;        // LDS-DMA pieces of A per wave per K-step (BM rows x 4 chunks / 256 lanes), 4 of W
+  constexpr int LPT = NA + 4;   // pieces per wave per K-step
+  constexpr int NFR = 4 + TM;   // fragments per K-step: 4 W tiles + TM A tiles, two 16-byte halves each
   constexpr int EB = FP8 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -73,15 +80,15 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-    a_voff[i] = (unsigned)(row * a_row_b + slot * 16);
+    a_voff[i] = (unsigned)(row * a_row_b + slot * 16);  // (i < NA is used)
     w_voff[i] = w_pairs ? (unsigned)((row >> 1) * 2 * w_row_b + (row & 1) * 64 + slot * 16) : (unsigned)(row * w_row_b + slot * 16);
   }
   const unsigned a_soff0 = uni_u32((unsigned)(m0 * a_row_b)), w_soff0 = uni_u32((unsigned)(n0 * w_row_b));
-  // piece q (0..7) of K-step kt into ring slot `slot`
+  // piece q (0..LPT-1: NA of A, then 4 of W) of K-step kt into ring slot `slot`
   auto dma_piece = [&](int q, int slot, int kt) {
     unsigned char* d = smem + slot * STAGE + wave * 1024;
-    if (q < 4) dma16_buf(ars, d + NT * 16 * q, a_voff[q], a_soff0 + kt * 64);
-    else dma16_buf(wrs, d + A_BYTES + NT * 16 * (q - 4), w_voff[q - 4], w_soff0 + kt * w_kstep);
+    if (q < NA) dma16_buf(ars, d + NT * 16 * q, a_voff[q], a_soff0 + kt * 64);
+    else dma16_buf(wrs, d + A_BYTES + NT * 16 * (q - NA), w_voff[q - NA], w_soff0 + kt * w_kstep);
   };
 
   v16f acc[TM][TN];
@@ -96,7 +103,7 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   // ds_read immediates are 16 bits, so slots 2 and 3 use a second base (+64 KiB).
   unsigned a_lo[2], a_hi[2], w_lo[2], w_hi[2];
   {
-    const int ra = wm * 128 + l31, ka = (ra >> 2) & 3;
+    const int ra = wm * (TM * 32) + l31, ka = (ra >> 2) & 3;
     const int rw = wn * 128 + l31, kw = (rw >> 2) & 3;
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
@@ -106,7 +113,7 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
       w_hi[h2] = (unsigned)(h2 * 2 * STAGE + A_BYTES + rw * 64 + (((hi * 2 + 1) ^ kw) << 4));
     }
   }
-  // half `hf` (0 = low 16 B, 1 = high 16 B) of fragment `f` (0..3 = W tiles, 4..7 = A tiles) of ring slot `slot`
+  // half `hf` (0 = low 16 B, 1 = high 16 B) of fragment `f` (0..3 = W tiles, 4..4+TM-1 = A tiles) of ring slot `slot`
   auto read_half = [&](W1Frags& F, int slot, int f, int hf) {
     const int h2 = slot >> 1, imm = (slot & 1) * STAGE + (f & 3) * 2048;
     const unsigned base = f < 4 ? (hf ? w_hi[h2] : w_lo[h2]) : (hf ? a_hi[h2] : a_lo[h2]);
@@ -139,27 +146,31 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   __builtin_amdgcn_s_barrier();
   W1Frags fa_, fb_;
 #pragma unroll
-  for (int f = 0; f < 8; ++f) {
+  for (int f = 0; f < NFR; ++f) {
     read_half(fa_, 0, f, 0);
     read_half(fa_, 0, f, 1);
   }
 
   // One K-step with compile-time ring slot S.  Entry: `cur` = fragments of step kt (LDS reads possibly still in flight), LDS-DMA of
-  // steps kt+1, kt+2 in flight.  16 MFMA slots; behind MFMA slot s: LDS read s of the NEXT step's fragments, and behind every even
-  // slot one LDS-DMA piece of step kt+3 (into the slot step kt-1 vacated).  Past the end of K the refill fetches don't-care bytes
+  // steps kt+1, kt+2 in flight.  TM x 4 MFMA slots; behind MFMA slot s: LDS read s of the NEXT step's fragments, and behind every even
+  // slot one LDS-DMA piece of step kt+3 (into the slot step kt-1 vacated).  TM = 3 has 12 slots for 14 fragment halves and 7 pieces: the
+  // first two slots read two halves, the last slot issues the seventh piece.  Past the end of K the refill fetches don't-care bytes
   // into a slot nobody reads any more and the "next" fragments are re-read from a stale slot: no branches in the body.
   auto step = [&](auto SLOT, W1Frags& cur, W1Frags& nxt, int kt) {
     constexpr int S = decltype(SLOT)::value, SN = (S + 1) & 3, SR = (S + 3) & 3;
     wait_vmcnt<LPT>();  // step kt+1 landed (own pieces); step kt+2 stays in flight
     __builtin_amdgcn_s_barrier();
     fence();
+    constexpr int NSLOT = TM * TN, NRD = 2 * NFR;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < NSLOT; ++s) {
       mma(cur, s >> 2, s & 3);
       fence();
       // next fragments: W halves first (needed by every MFMA row), then A
       read_half(nxt, SN, s >> 1, s & 1);
+      if (s + NSLOT < NRD) read_half(nxt, SN, (s + NSLOT) >> 1, (s + NSLOT) & 1);
       if ((s & 1) == 0) dma_piece(s >> 1, SR, kt + 3);
+      if (s == NSLOT - 1 && (NSLOT >> 1) < LPT) dma_piece(NSLOT >> 1, SR, kt + 3);
       fence();
     }
   };
@@ -175,8 +186,8 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   const float qs = load_scale_u(G.q_scale);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing don't-care refills must land before the ring is reused
   __builtin_amdgcn_s_barrier();
-  unsigned char* wbuf = smem + wave * (128 * 128 * 2);
-  const int mw = m0 + wm * 128, nw = n0 + wn * 128;
+  unsigned char* wbuf = smem + wave * (TM * 32 * 128 * 2);
+  const int mw = m0 + wm * (TM * 32), nw = n0 + wn * 128;
   if constexpr (ESEL >= 0) {
     lds_epilogue<ESEL, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane);
   } else {
@@ -192,9 +203,9 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   }
 }
 
-template <bool FP8, int ACT, int ESEL = -1>
+template <bool FP8, int ACT, int ESEL = -1, int TM_ = 4>
 int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
-  constexpr int BM = 256, BN = 256;
+  constexpr int BM = 64 * TM_, BN = 256;
   int t = 0;
   for (int i = 0; i < p.n_groups; ++i) {
     p.g[i].m_tile_start = t;
@@ -208,7 +219,7 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
 #endif
   p.group_m = W1_GROUP_M;
   constexpr int SMEM = 4 * (BM + BN) * 64;
-  auto kern = gemm_w1_kernel<FP8, ACT, ESEL>;
+  auto kern = gemm_w1_kernel<FP8, ACT, ESEL, TM_>;
   static bool attr_set = false;
   if (!attr_set) {
     FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -226,6 +237,17 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+// config 17 = the same kernel on 192 x 256 tiles: fp8 x e5m2 operands, gate*y+x epilogue (the launches it exists for)
+int fluxmi_launch_gemm_w1_192(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {
+  FLUXMI_REQUIRE(is_fp8 && act_fmt == FLUXMI_FMT_E5M2 && p.epi == FLUXMI_EPI_GATE_RESID,
+                 "gemm tile config 17 (192x256 one-wave-per-SIMD tiles): fp8 x e5m2 operands with the gate*y+x epilogue only (epi %d)", p.epi);
+  p.pf = fluxmi_take_prefetch();
+  if (!fluxmi_tuning().prefetch) p.pf.n = 0;
+  for (int i = 0; i < p.n_groups; ++i)
+    FLUXMI_REQUIRE((long long)p.g[i].M * p.g[i].lda < (1LL << 32) && (long long)p.N * p.K < (1LL << 32), "gemm_w1: operand larger than 4 GiB");
+  return launch_w1<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, 3>(p, s);
+}
 
 // config 16 = 256x256, one wave per SIMD
 int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {

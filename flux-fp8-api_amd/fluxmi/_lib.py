@@ -42,7 +42,7 @@ class Tuning(C.Structure):
     _fields_ = [
         ("struct_size", i32), ("gemm_cfg", i32), ("gemm_splitk", i32), ("gemm_hybrid", i32), ("gemm_esel", i32), ("gemm_persist", i32),
         ("attn_var", i32), ("attn_abl", i32), ("attn_defer_log2", f32), ("attn_f16k", i32), ("fuse_kv", i32), ("qlut", i32),
-        ("ln_variant", i32), ("roctx", i32), ("prefetch", i32), ("w_pairs", i32), ("log", i32), ("attn_split", i32),
+        ("ln_variant", i32), ("roctx", i32), ("prefetch", i32), ("w_pairs", i32), ("log", i32), ("gemm_tile192", i32), ("attn_split", i32),
     ]
 
 

@@ -122,6 +122,9 @@ typedef struct fluxmi_tuning {
   int w_pairs;           /* FLUXMI_W_PAIRS       1: the engine keeps a row-pair copy of the F8Linear weights its persistent GEMM launches read
                                                  (fluxmi_gemm_group_t.W_pairs: every L2 line of W fetched once per tile instead of twice) */
   int log;               /* FLUXMI_LOG           1: print the struct to stderr when it is resolved / set / an engine is created */
+  int gemm_tile192;      /* FLUXMI_GEMM_TILE192  1 (default): gate*y+x launches of the one-wave-per-SIMD kernel (K >= 8192) whose 256-row tiles fill less
+                                                 than one round of the CUs run on 192 x 256 tiles (tile config 17; same bits, 36 % more tiles of
+                                                 three quarters the work: Flux-dev 768^2 mlp.2 / linear2, 132 -> 180 tiles) */
   int attn_split;        /* FLUXMI_ATTN_SPLIT    1 (default): attention launches whose last round of workgroups is THIN (at most 8 of an XCD's
                                                  32 CUs busy: 264 tasks on 256 CUs at Flux-dev 768^2) run that round's tasks as pieces of
                                                  their key range and merge the partial softmax states (fp32 log-sum-exp in a fixed order:
@@ -142,7 +145,8 @@ int fluxmi_clock_sample(void* out24_dev_u64, void* stream);
 /* ---- F8Linear / Linear ------------------------------------------------------------------------- */
 /* Grouped linear.  is_fp8=1: A is `act_fmt` fp8, W is e4m3fn (torch._scaled_mm, float8_quantize.py:284-292);
  * is_fp8=0: A, W bf16 (F.linear).  tile_cfg: -1 auto (cost model + split of a thin last round, what the engine uses);
- * 13 = 256x256 ping-pong LDS ring (K*bytes % 64 == 0); 16 = 256x256 with one wave per SIMD (K*bytes % 256 == 0); 2 = 128x128 and 15 = 128x64
+ * 13 = 256x256 ping-pong LDS ring (K*bytes % 64 == 0); 16 = 256x256 with one wave per SIMD (K*bytes % 256 == 0), 17 = the same kernel on 192x256 tiles
+ * (fp8 x e5m2, gate*y+x epilogue only: launches with a thin single round of 256-row tiles); 2 = 128x128 and 15 = 128x64
  * double-buffered tiles (K*bytes % 128 == 0); 100 = generic any-shape kernel.  Every one of these computes the same bits.  (Other numbers
  * named kernel generations that were removed: they are rejected.)  18 = config 13 as a PERSISTENT kernel (one workgroup per CU walks the tiles;
  * fp8 x e5m2, N % 256 == 0, K % 256 == 0, K >= 512; the auto dispatch takes it for launches of more than 256 tiles), 19 = its timing build.

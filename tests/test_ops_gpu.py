@@ -407,6 +407,47 @@ def test_gemm_persistent_store_canary(ops, dev, epi_name):
                 assert torch.equal(x13, x16), f"{epi_name}: config 16 differs from config 13 on a launch with a partial last tile band"
 
 
+@pytest.mark.parametrize("Ms", [[512, 2304], [2816], [1000, 77]])
+def test_gemm_tile_config_17_matches_16(ops, dev, Ms):
+    """Tile config 17 (round 5) = the one-wave-per-SIMD kernel on 192 x 256 tiles for gate*y+x launches whose 256-row tiling fills less than one
+    round of the CUs (Flux-dev 768^2: mlp.2 grouped txt + img, linear2).  Same K loop, same MFMAs in the same order: every output byte must
+    equal config 16's and config 13's -- ragged last tiles (2816 = 14 x 192 + 128; 77 rows), two groups with their own weights, and the
+    automatic dispatch (tile_cfg -1 with and without fluxmi_tuning_t.gemm_tile192), which takes it for these shapes at K >= 8192.
+    float8_quantize.py:284-292, flux_model.py:387-396,484"""
+    from fluxmi import _lib
+
+    torch.manual_seed(31)
+    N, K = 3072, 8192
+    one = torch.tensor(1.0, device=dev)
+    a = [(torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2) for M in Ms]
+    w = [(torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn) for _ in Ms]
+    bias = torch.randn(N, device=dev).bfloat16()
+    gate = torch.randn(N, device=dev).bfloat16()
+    resid = [torch.randn(M, N, device=dev).bfloat16() for M in Ms]
+    sar = torch.tensor(0.013, device=dev)
+
+    def launch(cfg):
+        outs, groups = [], []
+        for gi, M in enumerate(Ms):
+            o = resid[gi].clone()
+            outs.append(o)
+            groups.append(ops.make_group(a[gi].data_ptr(), w[gi].data_ptr(), bias.data_ptr() if gi == 0 else None, sar.data_ptr(), one.data_ptr(), o.data_ptr(), M, K,
+                                         N, gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N))
+        ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_GATE_RESID, cfg)
+        torch.cuda.synchronize()
+        return [o.view(torch.int16).clone() for o in outs]
+
+    ref = launch(16)
+    for cfg in (17, 13, -1):
+        for x, y in zip(ref, launch(cfg)):
+            assert torch.equal(x, y), f"tile config {cfg} differs from config 16 (Ms = {Ms})"
+    with _lib.tuning(gemm_tile192=0):
+        for x, y in zip(ref, launch(-1)):
+            assert torch.equal(x, y)
+    for x in ref:
+        assert torch.isfinite(x.view(torch.bfloat16).float()).all()
+
+
 def test_gemm_persistent_quantising_paths_exhaustive(ops, dev):
     """The persistent kernel's table epilogue (table DMA issued inside the last K-step into ring slots 2 / 3, gather, transposition through
     the per-wave scratch) over EVERY bf16 input: A = 0, so h = bf16(0 * s + bias) is the bias pattern itself; the bias runs through all
