@@ -218,7 +218,7 @@ def measure_attention(torch, ops, dev, L, iters=10, H=24, batch=1):
     wgs = ((L + 255) // 256) * H * batch
     mode = _lib.get_tuning().attn_split if f16k else 0
     plan = ops.attention_plan(batch, L, H) if mode else None
-    if plan and mode == 1 and plan["n_per_x"] - plan["full_per_x"] > 8:
+    if plan and mode == 1 and not plan["thin"]:
         plan = None  # the default takes the balanced grid for thin last rounds only (include/fluxmi.h, attn_split)
     kern = "attention2_kernel (8 waves x 32 rows, skewed pipeline, deferred rescale" + (", folded, barrier between the MFMA groups)" if f16k else ")")
     note = f"{wgs} tasks of 256 query rows on 256 CUs = {wgs / 256:.2f} rounds"

@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave has reached the L2 ...
     __syncthreads();                                   // ... of every wave, before the arrival is counted
-    unsigned* cnt = a.sp.cnt + x * 32 + pc.tloc;
+    unsigned* cnt = a.sp.cnt + x * ATTN_SPLIT_MAXT + pc.tloc;
     if (tid == 0) {
       const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *(volatile int*)smem = old == (unsigned)(pc.np - 1) ? 1 : 0;
@@ -542,12 +542,19 @@ AttnSplit fluxmi_attn_plan(int tasks, int ntiles, int cus) {
   AttnSplit sp;
   memset(&sp, 0, sizeof(sp));
   if (cus != 256 || tasks % 8 || ntiles < 16 || ntiles > 65535) return sp;
-  const int n = tasks / 8, rem = n % 32;
-  if (rem == 0 || rem > 26) return sp;
+  const int n = tasks / 8, last = n % 32;  // tasks per XCD; tasks in the last round of its 32 CUs
+  if (last == 0 || last > 26) return sp;
+  // which tasks are binned: a THIN last round (<= 8 of 32 CUs) is folded into the full round in front of it -- 32 + last tasks over 32 bins, every
+  // CU gets (32 + last) / 32 tasks' worth of key tiles in one go (Flux-dev 768^2: 33 tasks of 44 tiles -> 45.4 tiles per CU instead of 44 + 11) --
+  // and so is a single partial round (n < 32: 512^2 runs 18 tasks on 32 CUs); a fuller last round is binned on its own
+  const bool thin = n < 32 || last <= 8;
+  const int rem = n < 32 ? n : (last <= 8 ? 32 + last : last);
+  if (rem > ATTN_SPLIT_MAXT) return sp;
   const int T = rem * ntiles;
   int nb = std::min(32, rem * 4);
-  while (nb > rem && T / nb < 8) --nb;
-  if (T / nb < 8) return sp;
+  while (nb > 1 && T / nb < 8) --nb;
+  if (T / nb < 8 || nb >= rem * 4 + 1) return sp;
+  if (nb == rem && n >= 32 && !(last <= 8)) return sp;  // nothing to balance: one bin per task
   // canonical pieces (ascending tile position) and, per piece, whether it is the first of its bin
   struct P { int tloc, tb, len, first; };
   std::vector<P> ps;
@@ -578,7 +585,10 @@ AttnSplit fluxmi_attn_plan(int tasks, int ntiles, int cus) {
     return ps[u].len > ps[v].len;
   });
   for (size_t c = 0; c < ps.size(); ++c) sp.pieces[c] = canon[order[c]];
-  sp.on = 1; sp.n_per_x = n; sp.full_per_x = n - rem; sp.npieces = (int)ps.size();
+  bool any_split = false;
+  for (const AttnPiece& c : canon) any_split |= c.np > 1;
+  if (!any_split) return sp;
+  sp.on = 1; sp.thin = thin; sp.n_per_x = n; sp.full_per_x = n - rem; sp.npieces = (int)ps.size();
   return sp;
 }
 
@@ -655,13 +665,13 @@ int fluxmi_attn_plan_export(int B, int L, int H, int* n_per_x, int* full_per_x, 
   if (full_per_x) *full_per_x = sp.full_per_x;
   if (npieces) *npieces = sp.npieces;
   if (pieces) memcpy(pieces, sp.pieces, sizeof(AttnPiece) * sp.npieces);
-  return 1;
+  return sp.thin ? 1 : 2;
 }
 int fluxmi_attn_split_on(int B, int L, int H) {
   const int mode = fluxmi_tuning().attn_split;
   if (!mode || !fluxmi_attn_plan_any(B, L, H)) return 0;
   const AttnSplit sp = fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256);
-  return mode == 2 || sp.n_per_x - sp.full_per_x <= 8;
+  return mode == 2 || sp.thin;
 }
 
 template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArgs a, int fmt, hipStream_t s) {
@@ -676,14 +686,14 @@ template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArg
   const fluxmi_tuning_t tun = fluxmi_tuning();
   if (FOLD && tun.attn_split && fluxmi_xcd_mapping_ok(s) == 1) {
     AttnSplit sp = fluxmi_attn_plan(tasks, (a.L + KT - 1) / KT, 256);
-    // attn_split = 1: only THIN last rounds (at most 8 of an XCD's 32 CUs busy: every piece starts at once on a CU of its own).  Fuller
-    // ones were measured not to pay on this chip -- Flux-dev 1024^2, 22 of 32: 236 vs 223 - 235 us isolated, +3.4 % per step
-    // (profiles/r05_attention_split.txt); 2 forces the balanced grid wherever a plan exists (tests, probes)
-    if (sp.on && tun.attn_split == 1 && sp.n_per_x - sp.full_per_x > 8) sp.on = 0;
+    // attn_split = 1: only THIN last rounds (at most 8 of an XCD's 32 CUs busy, folded into the round in front of them; or a single partial
+    // round).  Fuller ones were measured not to pay on this chip -- Flux-dev 1024^2, 22 of 32: 236 vs 223 - 235 us isolated, +3.4 % per
+    // step (profiles/r05_attention_split.txt); 2 forces the balanced grid wherever a plan exists (tests, probes)
+    if (sp.on && tun.attn_split == 1 && !sp.thin) sp.on = 0;
     void* ws = sp.on ? attn_workspace(s) : nullptr;
     if (sp.on && ws) {
       sp.part = (float*)ws;
-      sp.cnt = (unsigned*)((char*)ws + (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4);
+      sp.cnt = (unsigned*)((char*)ws + (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4);  // [8][ATTN_SPLIT_MAXT]
       a.sp = sp;
       a.pf.n = 0;  // no CU idles in the last round any more: nothing for the weight prefetch to ride on
       a.pf.wgs = 0;

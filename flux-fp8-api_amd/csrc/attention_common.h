@@ -26,16 +26,18 @@ struct AttnSplit {
   int n_per_x;     // tasks per XCD (= tasks / 8)
   int full_per_x;  // of which run whole (a multiple of 32)
   int npieces;     // pieces per XCD (launch order = order of `pieces`)
-  int pad[2];
+  int thin;        // 1: the binned tasks are a thin last round folded into the round in front of it, or a single partial round (what attn_split = 1 takes)
+  int pad;
   float* part;     // [8][ATTN_MAX_PIECES] slots of ATTN_PART_FLOATS floats (slot = canonical piece index)
-  unsigned* cnt;   // [8][32] arrival counters, zero between launches (the merging piece resets its task's)
+  unsigned* cnt;   // [8][ATTN_SPLIT_MAXT] arrival counters, zero between launches (the merging piece resets its task's)
   AttnPiece pieces[ATTN_MAX_PIECES];
 };
 static_assert(sizeof(AttnPiece) == 8, "AttnPiece is read as one 8-byte scalar load");
 constexpr int ATTN_PART_FLOATS = 8 * 17 * 64 * 4;                     // per slot: [wave][i < 17][lane] float4 = 16 x four accumulator floats of every lane, then (m, l, -, -)
 constexpr int ATTN_SPLIT_SNAP = 3;                                    // bin edges within 3 tiles of a task edge move onto it (no 1..3-tile pieces)
 constexpr int ATTN_SPLIT_MAXP = 8;                                    // pieces per task the plan accepts
-constexpr size_t ATTN_SPLIT_WS_BYTES = (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4 + 8 * 32 * 4;
+constexpr int ATTN_SPLIT_MAXT = 64;                                   // binned tasks per XCD (32 + a thin last round of <= 8, or <= 26)
+constexpr size_t ATTN_SPLIT_WS_BYTES = (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4 + 8 * ATTN_SPLIT_MAXT * 4;
 static_assert(ATTN_SPLIT_WS_BYTES == FLUXMI_ATTN_SPLIT_WS_BYTES, "scratch size of the balanced grid (fluxmi_internal.h)");
 AttnSplit fluxmi_attn_plan(int tasks, int ntiles, int cus);
 

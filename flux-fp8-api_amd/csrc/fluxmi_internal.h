@@ -105,7 +105,7 @@ void fluxmi_set_splitk_scratch(float* p);
 // scratch of attention's balanced grid (attention2.hip, AttnSplit: partial softmax states of the key bins + arrival counters, which must be
 // ZERO when handed over and are left zero by every launch): thread-local like the split-K scratch, an engine owns one; nullptr = the library's own
 // per-(device, stream) buffer.  fluxmi_attn_split_on: does a launch of this shape use the balanced grid under the current tuning?
-constexpr size_t FLUXMI_ATTN_SPLIT_WS_BYTES = (size_t)8 * 64 * (8 * 17 * 64 * 4) * 4 + 8 * 32 * 4;
+constexpr size_t FLUXMI_ATTN_SPLIT_WS_BYTES = (size_t)8 * 64 * (8 * 17 * 64 * 4) * 4 + 8 * 64 * 4;
 void fluxmi_set_attn_scratch(void* p);
 int fluxmi_attn_split_on(int B, int L, int H);
 int fluxmi_attn_plan_any(int B, int L, int H);

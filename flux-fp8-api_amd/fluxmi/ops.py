@@ -257,17 +257,18 @@ def attention(Q, K, VT, q_scale0=None, q_scale1=None, split=None, fmt=E5M2, out=
 
 def attention_plan(B: int, L: int, H: int):
     """fluxmi_attention_plan: None when an attention launch of this shape runs one workgroup per task, else a dict with the balanced
-    grid's geometry: n_per_x / full_per_x (tasks per XCD, of which whole) and `pieces` in launch order (dicts with tloc, pidx, np,
+    grid's geometry: n_per_x / full_per_x (tasks per XCD, of which whole), `thin` (the default takes the plan) and `pieces` in launch order (dicts with tloc, pidx, np,
     base, tb, len).  Host arithmetic only -- works without a GPU."""
     import ctypes as C
 
     n, f, npc = C.c_int(), C.c_int(), C.c_int()
     raw = (C.c_ulonglong * 64)()
-    if not _lib.lib.fluxmi_attention_plan(B, L, H, C.byref(n), C.byref(f), C.byref(npc), raw):
+    kind = _lib.lib.fluxmi_attention_plan(B, L, H, C.byref(n), C.byref(f), C.byref(npc), raw)
+    if not kind:
         return None
     pieces = [dict(tloc=v & 255, pidx=(v >> 8) & 255, np=(v >> 16) & 255, base=(v >> 24) & 255, tb=(v >> 32) & 0xFFFF, len=(v >> 48) & 0xFFFF)
               for v in list(raw)[: npc.value]]
-    return dict(n_per_x=n.value, full_per_x=f.value, pieces=pieces)
+    return dict(n_per_x=n.value, full_per_x=f.value, pieces=pieces, thin=kind == 1)  # thin: what fluxmi_tuning_t.attn_split = 1 takes
 
 
 def attention_rawq(qkv, pe, qn_scale0, K, VT, qn_scale1=None, q_scale0=None, q_scale1=None, split=None, fmt=E5M2, out=None, col_off=0):

@@ -228,13 +228,15 @@ int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, lo
 
 /* The launch plan of the kernel above for B x H heads of L keys on a 256-CU part (host arithmetic only, no GPU needed; tests + bench notes).
  * The kernel runs one workgroup of 256 query rows per (head, row block) -- a TASK -- and one workgroup per CU at a time, so 264 tasks take two
- * rounds for 1.03 rounds of work.  Under fluxmi_tuning_t.attn_split (fp16-K calls only; 1 = thin last rounds, 2 = always) every XCD runs full_per_x of
- * its n_per_x tasks whole and the remaining ones as `npieces` PIECES of their key range, launched longest first, so that every CU ends
- * up with the same number of key tiles; a piece writes its softmax state (O, m, l; fp32) to a scratch slot and the piece that arrives
- * last at the task's counter merges them in piece order -- the result does not depend on the arrival order.  Returns 1 when such a plan
- * exists for the shape (and fills the outputs), 0 when the launch runs one workgroup per task.  pieces[i] (i < npieces <= 64), in launch
- * order: bits 0-7 leftover-task index, 8-15 piece index within the task, 16-23 pieces of the task, 24-31 canonical index of the
- * task's first piece (= its scratch slot), 32-47 first key tile, 48-63 key tiles. */
+ * rounds for 1.03 rounds of work.  Under fluxmi_tuning_t.attn_split (fp16-K calls only) every XCD runs full_per_x of its n_per_x tasks whole
+ * and the remaining ones as `npieces` PIECES of their key range, launched longest first, so that every CU ends up with the same number of key
+ * tiles: a THIN last round (at most 8 of an XCD's 32 CUs) is folded into the full round in front of it (768^2: 33 tasks over 32 bins), a
+ * single partial round (fewer than 32 tasks per XCD) is spread over all CUs, a fuller last round is binned on its own.  A piece writes its
+ * softmax state (O, m, l; fp32) to a scratch slot and the piece that arrives last at the task's counter merges them in piece order -- the
+ * result does not depend on the arrival order.  Returns 0 when the launch runs one workgroup per task, 1 when a plan exists and
+ * attn_split = 1 takes it (thin / partial rounds), 2 when only attn_split = 2 does (fuller last rounds: measured not to pay).
+ * pieces[i] (i < npieces <= 64), in launch order: bits 0-7 index of the binned task, 8-15 piece index within the task, 16-23 pieces of
+ * the task, 24-31 canonical index of the task's first piece (= its scratch slot), 32-47 first key tile, 48-63 key tiles. */
 int fluxmi_attention_plan(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces);
 
 /* The same with Q taken RAW from the qkv GEMM output (q at column 0 of `qkv`, row stride ld_qkv): QKNorm (qn_scale0 for rows

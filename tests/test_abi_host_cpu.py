@@ -31,22 +31,31 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("B,L,H", [(1, 4608, 24), (1, 2816, 24), (2, 4608, 24), (8, 4608, 24), (1, 1100, 8), (3, 4608, 24), (1, 8192, 24), (1, 512, 24),
-                                   (1, 4608, 3), (1, 1100, 16), (1, 6000, 24)])
+                                   (1, 4608, 3), (1, 1100, 16), (1, 6000, 24), (1, 1536, 24), (1, 2048, 24), (1, 3072, 24)])
 def test_attention_balanced_grid_plan(B, L, H):
-    """fluxmi_attention_plan (host arithmetic, no GPU): the pieces of the balanced attention grid tile every leftover task's key range
-    exactly once, piece bookkeeping (index, count, scratch slot) is consistent, and replaying the launch order on 32 CUs -- each
-    finished CU takes the next piece -- gives every CU one bin's worth of key tiles (flux_model.py:41-45 is unchanged by any of it)."""
+    """fluxmi_attention_plan (host arithmetic, no GPU): the pieces of the balanced attention grid tile every binned task's key range
+    exactly once, piece bookkeeping (index, count, scratch slot) is consistent, and replaying the launch order on an XCD's 32 CUs -- each
+    finished CU takes the next piece -- gives every CU one bin's worth of key tiles.  A thin last round (<= 8 of 32 CUs) is folded into the
+    full round in front of it (768^2: 33 tasks over 32 bins), a single partial round is spread over all CUs, a fuller last round is binned on
+    its own (1024^2: 22 tasks over 32 bins; only with attn_split = 2).                                      flux_model.py:41-45 is unchanged by any of it"""
     from fluxmi import ops
 
     plan = ops.attention_plan(B, L, H)
     tasks, nt = (L + 255) // 256 * H * B, (L + 63) // 64
-    rem = (tasks // 8) % 32 if tasks % 8 == 0 else 0
-    if tasks % 8 or nt < 16 or rem == 0 or rem > 26:
+    n, last = tasks // 8, (tasks // 8) % 32
+    if tasks % 8 or nt < 16 or last == 0 or last > 26:
         assert plan is None
         return
-    assert plan is not None and plan["n_per_x"] == tasks // 8 and plan["full_per_x"] == tasks // 8 - rem and plan["full_per_x"] % 32 == 0
+    expect = {(1, 4608, 24): (32, 22), (1, 2816, 24): (0, 33), (2, 4608, 24): (96, 12), (8, 4608, 24): (416, 16), (1, 1100, 8): (0, 5), (1, 1536, 24): (0, 18),
+              (1, 3072, 24): (0, 36)}
+    if (B, L, H) in expect:
+        assert plan is not None and (plan["full_per_x"], plan["n_per_x"] - plan["full_per_x"]) == expect[(B, L, H)]
+    if plan is None:
+        return
+    rem = plan["n_per_x"] - plan["full_per_x"]
+    assert plan["n_per_x"] == n and plan["full_per_x"] % 32 == 0 and 1 <= rem <= 64
     ps = plan["pieces"]
-    assert 1 <= len(ps) <= 64
+    assert 1 <= len(ps) <= 64 and any(p["np"] > 1 for p in ps)
     by_task = {}
     for p in ps:
         assert p["len"] >= 1 and p["tb"] + p["len"] <= nt and p["tloc"] < rem
@@ -69,9 +78,10 @@ def test_attention_balanced_grid_plan(B, L, H):
     for p in ps:
         i = min(range(32), key=lambda c: free[c])
         free[i] += p["len"]
-    # one bin = 1/32 of the leftover tiles, but never less than a quarter task (a task is cut into at most four bins) or 8 tiles; + the edge snap
+    # one bin = 1/32 of the binned tiles, but never less than a quarter task (a task is cut into at most four bins) or 8 tiles; + the edge snap
     assert max(free) <= max(math.ceil(rem * nt / 32), math.ceil(nt / 4), 8) + 4, (max(free), rem * nt / 32)
-    assert max(free) < nt  # the grid it replaces spends one whole task per CU on this round
+    # the grid it replaces spends one whole task per CU on the last round (two for a thin round folded into the round in front of it)
+    assert max(free) < (2 * nt if rem > 32 else nt)
 
 
 def test_errors_are_returned_not_thrown():

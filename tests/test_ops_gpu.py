@@ -787,7 +787,7 @@ def test_attention_deferred_rescale_branch(ops, dev, L):
           f"deferred == exact on {same:.4f}, == fold on {same_f:.4f} of the outputs")
 
 
-@pytest.mark.parametrize("B,H,L", [(1, 8, 1100), (1, 24, 2816), (1, 24, 4608), (2, 24, 4608)])
+@pytest.mark.parametrize("B,H,L", [(1, 8, 1100), (1, 24, 1536), (1, 24, 2816), (1, 24, 4608), (2, 24, 4608)])
 def test_attention_balanced_grid(ops, dev, B, H, L):
     """fluxmi_tuning_t.attn_split (round 5; forced here, the default takes it for thin last rounds such as L = 2816): the workgroups of the
     last, partial round are replaced by PIECES of their tasks' key range

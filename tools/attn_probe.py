@@ -34,7 +34,7 @@ for sp in ([None] if a.split is None else [int(x) for x in a.split.split(",")] *
             ts.append(e0.elapsed_time(e1) / a.iters * 1e-3)
     t = sorted(ts)[len(ts) // 2]
     plan = ops.attention_plan(B, L, H) if (sp is None or sp) and not a.bf16_k else None
-    if plan and (sp is None or sp == 1) and plan["n_per_x"] - plan["full_per_x"] > 8:
+    if plan and (sp is None or sp == 1) and not plan["thin"]:
         plan = None  # attn_split = 1: thin last rounds only
     print(f"attention B={B} H={H} L={L} attn_split={'default' if sp is None else sp}"
           f" ({'balanced grid: %d whole tasks + %d pieces per XCD' % (plan['full_per_x'], len(plan['pieces'])) if plan else 'one workgroup per task'}): "
