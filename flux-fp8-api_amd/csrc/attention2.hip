@@ -545,9 +545,11 @@ AttnSplit fluxmi_attn_plan(int tasks, int ntiles, int cus) {
   const int n = tasks / 8, last = n % 32;  // tasks per XCD; tasks in the last round of its 32 CUs
   if (last == 0 || last > 26) return sp;
   // which tasks are binned: a THIN last round (<= 8 of 32 CUs) is folded into the full round in front of it -- 32 + last tasks over 32 bins, every
-  // CU gets (32 + last) / 32 tasks' worth of key tiles in one go (Flux-dev 768^2: 33 tasks of 44 tiles -> 45.4 tiles per CU instead of 44 + 11) --
-  // and so is a single partial round (n < 32: 512^2 runs 18 tasks on 32 CUs); a fuller last round is binned on its own
-  const bool thin = n < 32 || last <= 8;
+  // CU gets (32 + last) / 32 tasks' worth of key tiles in one go (Flux-dev 768^2: 33 tasks of 44 tiles -> 45.4 tiles per CU instead of 44 + 11);
+  // a single partial round (n < 32: 512^2 runs 18 tasks on 32 CUs) is spread over all CUs; a fuller last round is binned on its own
+  // (a single partial round does NOT pay: 512^2, 18 tasks on 32 CUs, 40 -> 51 us per launch, +7 % per step -- the second prologue, the
+  // hand-over and the merge cost a piece ~13 us, a third of such a task; it stays available under attn_split = 2)
+  const bool thin = n >= 32 && last <= 8;
   const int rem = n < 32 ? n : (last <= 8 ? 32 + last : last);
   if (rem > ATTN_SPLIT_MAXT) return sp;
   const int T = rem * ntiles;

@@ -234,7 +234,8 @@ int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, lo
  * single partial round (fewer than 32 tasks per XCD) is spread over all CUs, a fuller last round is binned on its own.  A piece writes its
  * softmax state (O, m, l; fp32) to a scratch slot and the piece that arrives last at the task's counter merges them in piece order -- the
  * result does not depend on the arrival order.  Returns 0 when the launch runs one workgroup per task, 1 when a plan exists and
- * attn_split = 1 takes it (thin / partial rounds), 2 when only attn_split = 2 does (fuller last rounds: measured not to pay).
+ * attn_split = 1 takes it (a thin last round behind at least one full one), 2 when only attn_split = 2 does (fuller last rounds and single
+ * partial rounds: measured not to pay).
  * pieces[i] (i < npieces <= 64), in launch order: bits 0-7 index of the binned task, 8-15 piece index within the task, 16-23 pieces of
  * the task, 24-31 canonical index of the task's first piece (= its scratch slot), 32-47 first key tile, 48-63 key tiles. */
 int fluxmi_attention_plan(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces);

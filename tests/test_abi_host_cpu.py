@@ -52,6 +52,7 @@ def test_attention_balanced_grid_plan(B, L, H):
         assert plan is not None and (plan["full_per_x"], plan["n_per_x"] - plan["full_per_x"]) == expect[(B, L, H)]
     if plan is None:
         return
+    assert plan["thin"] == (n >= 32 and last <= 8)
     rem = plan["n_per_x"] - plan["full_per_x"]
     assert plan["n_per_x"] == n and plan["full_per_x"] % 32 == 0 and 1 <= rem <= 64
     ps = plan["pieces"]
