@@ -101,6 +101,13 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
     for (int i = 0; i < n; ++i) { t256 += (gs[i].M + 255) / 256; fused_out |= (gs[i].vt_out || gs[i].k_out); }
     t256 *= N / 256;
     if (t256 > 128 && t256 <= 256 && (!fused_out || cfg == 13)) cfg = 16;
+    // ... and on 192-row tiles when those still fit one round (M = 512, N = 21504: 3 x 84 = 252 tiles of three quarters the work instead of 168)
+    if (cfg == 16 && !fused_out && (epi == FLUXMI_EPI_BF16 || epi == FLUXMI_EPI_GATE_RESID) && fluxmi_tuning().gemm_tile192) {
+      long long t192 = 0;
+      for (int i = 0; i < n; ++i) t192 += (gs[i].M + 191) / 192;
+      t192 *= N / 256;
+      if (t192 <= 256 && t192 > t256) cfg = 17;
+    }
   }
   // multi-round fp8 launches of the step (single-block linear1: 5.9 rounds of the 256 CUs, double-block mlp.0: 3.0, qkv: 2.25): one
   // persistent workgroup per CU walks the tiles -- no workgroup relaunch, cold prologue or store drain per tile (gemm_persist.hip).

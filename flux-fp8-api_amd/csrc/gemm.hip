@@ -321,7 +321,6 @@ int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg) {
   const int kb = K * (is_fp8 ? 1 : 2);
   const int kstep = (cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19) ? 256 : cfg == 13 ? 64 : 128;
   if ((cfg == 18 || cfg == 19) && kb < 512) return 0;
-  if (cfg == 17 && !is_fp8) return 0;
   return (N % bn == 0) && (kb % kstep == 0) && kb >= kstep;
 }
 

@@ -238,15 +238,24 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-// config 17 = the same kernel on 192 x 256 tiles: fp8 x e5m2 operands, gate*y+x epilogue (the launches it exists for)
+// config 17 = the same kernel on 192 x 256 tiles, for the launches it exists for: fp8 x e5m2 operands with the gate*y+x epilogue (Flux-dev
+// 768^2 mlp.2 / linear2) and bf16 operands with the plain or the gate*y+x epilogue (M = 512: Flux-schnell 256^2 linear1 runs 3 x 84 = 252
+// tiles instead of 2 x 84 = 168 for 256 CUs; the text encoders)
 int fluxmi_launch_gemm_w1_192(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {
-  FLUXMI_REQUIRE(is_fp8 && act_fmt == FLUXMI_FMT_E5M2 && p.epi == FLUXMI_EPI_GATE_RESID,
-                 "gemm tile config 17 (192x256 one-wave-per-SIMD tiles): fp8 x e5m2 operands with the gate*y+x epilogue only (epi %d)", p.epi);
+  const bool f8_ok = is_fp8 && act_fmt == FLUXMI_FMT_E5M2 && p.epi == FLUXMI_EPI_GATE_RESID;
+  const bool bf_ok = !is_fp8 && (p.epi == FLUXMI_EPI_BF16 || p.epi == FLUXMI_EPI_GATE_RESID);
+  FLUXMI_REQUIRE(f8_ok || bf_ok, "gemm tile config 17 (192x256 one-wave-per-SIMD tiles): fp8 x e5m2 operands with the gate*y+x epilogue, or bf16 operands "
+                 "with the plain / gate*y+x epilogue (fp8 %d, epi %d)", is_fp8, p.epi);
+  for (int i = 0; i < p.n_groups; ++i)
+    FLUXMI_REQUIRE(!p.g[i].vt_out && !p.g[i].k_out, "gemm tile config 17: no fused K / V^T outputs");
   p.pf = fluxmi_take_prefetch();
   if (!fluxmi_tuning().prefetch) p.pf.n = 0;
+  const int eb = is_fp8 ? 1 : 2;
   for (int i = 0; i < p.n_groups; ++i)
-    FLUXMI_REQUIRE((long long)p.g[i].M * p.g[i].lda < (1LL << 32) && (long long)p.N * p.K < (1LL << 32), "gemm_w1: operand larger than 4 GiB");
-  return launch_w1<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, 3>(p, s);
+    FLUXMI_REQUIRE((long long)p.g[i].M * p.g[i].lda * eb < (1LL << 32) && (long long)p.N * p.K * eb < (1LL << 32), "gemm_w1: operand larger than 4 GiB");
+  if (is_fp8) return launch_w1<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, 3>(p, s);
+  if (p.epi == FLUXMI_EPI_GATE_RESID) return launch_w1<false, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, 3>(p, s);
+  return launch_w1<false, FLUXMI_FMT_E5M2, FLUXMI_EPI_BF16, 3>(p, s);
 }
 
 // config 16 = 256x256, one wave per SIMD

@@ -448,6 +448,45 @@ def test_gemm_tile_config_17_matches_16(ops, dev, Ms):
         assert torch.isfinite(x.view(torch.bfloat16).float()).all()
 
 
+@pytest.mark.parametrize("epi_name", ["bf16", "gate_resid"])
+def test_gemm_tile_config_17_bf16(ops, dev, epi_name):
+    """Tile config 17 with bf16 operands (nn.Linear flows: Flux-schnell 256^2 linear1 at M = 512 -> 3 x 84 = 252 tiles of 192 rows instead of 168 of
+    256; the text encoders): every output byte equals config 16's, ragged last tile (512 = 2 x 192 + 128) and a second group included, and the
+    automatic dispatch agrees with both settings of fluxmi_tuning_t.gemm_tile192.                                   flux_model.py:471-473"""
+    from fluxmi import _lib
+
+    torch.manual_seed(37)
+    N, K, Ms = 21504, 1024, [512, 100]
+    epi = _lib.EPI_BF16 if epi_name == "bf16" else _lib.EPI_GATE_RESID
+    a = [torch.randn(M, K, device=dev).bfloat16() for M in Ms]
+    w = [(torch.randn(N, K, device=dev) * 0.05).bfloat16() for _ in Ms]
+    bias = torch.randn(N, device=dev).bfloat16()
+    gate = torch.randn(N, device=dev).bfloat16()
+    resid = [torch.randn(M, N, device=dev).bfloat16() for M in Ms]
+
+    def launch(cfg):
+        outs, groups = [], []
+        for gi, M in enumerate(Ms):
+            o = resid[gi].clone()
+            outs.append(o)
+            kw = dict(gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N) if epi == _lib.EPI_GATE_RESID else {}
+            groups.append(ops.make_group(a[gi].data_ptr(), w[gi].data_ptr(), bias.data_ptr(), None, None, o.data_ptr(), M, K, N, **kw))
+        ops.gemm_grouped(groups, N, K, False, E5M2, epi, cfg)
+        torch.cuda.synchronize()
+        return [o.view(torch.int16).clone() for o in outs]
+
+    ref = launch(16)
+    for cfg in (17, -1):
+        for x, y in zip(ref, launch(cfg)):
+            assert torch.equal(x, y), f"bf16 tile config {cfg} differs from config 16"
+    with _lib.tuning(gemm_tile192=0):
+        for x, y in zip(ref, launch(-1)):
+            assert torch.equal(x, y)
+    h = round_fp64_to_bf16(a[0].double().cpu() @ w[0].double().cpu().T + bias.double().cpu())
+    if epi == _lib.EPI_BF16:
+        assert_close_mag(ref[0].view(torch.bfloat16).cpu(), h, mag=accum_noise(a[0].cpu(), w[0].cpu(), 1.0), ulps=1.05, min_exact=0.98, what="bf16 cfg 16/17 vs fp64")
+
+
 def test_gemm_persistent_quantising_paths_exhaustive(ops, dev):
     """The persistent kernel's table epilogue (table DMA issued inside the last K-step into ring slots 2 / 3, gather, transposition through
     the per-wave scratch) over EVERY bf16 input: A = 0, so h = bf16(0 * s + bias) is the bias pattern itself; the bias runs through all
