@@ -694,7 +694,9 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
     if (on(2) && !fuse_k)
       FLUXMI_TRY(fluxmi_k_qkv_rope(qkv, 3 * H, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, fuse_v ? nullptr : VT, B, L, e->Lp, heads, L, attn_f16k(), s));
     if (on(3)) {
-      set_pf(e, {l2}, idle_cus((long long)B * heads * ((L + 255) / 256)));  // attention's idle CUs pull in linear2's weights
+      // attention's idle CUs pull in linear2's weights; fluxmi_tuning_t.prefetch = 3: the NEXT block's linear1 as well (113 MB in all)
+      if (fluxmi_tuning().prefetch >= 3 && i + 1 < e->d.depth_single) set_pf(e, {l2, SLi(e, i + 1, S_LIN1)}, idle_cus((long long)B * heads * ((L + 255) / 256)));
+      else set_pf(e, {l2}, idle_cus((long long)B * heads * ((L + 255) / 256)));
       FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s, qkv,
                                     3 * H, pe, ns[0], ns[0], attn_f16k()));
       fluxmi_set_prefetch(nullptr);

@@ -118,7 +118,9 @@ typedef struct fluxmi_tuning {
   int ln_variant;        /* FLUXMI_LN_V          2 = streaming LayerNorm kernel (default), 3 = the same at two workgroups per CU, 1 = one wave per row */
   int roctx;             /* FLUXMI_ROCTX         1: roctx ranges around the phases of a denoise call */
   int prefetch;          /* FLUXMI_PREFETCH      1: launches with idle CUs (attention, the 216-tile GEMMs) carry extra workgroups that read the
-                                                 weights of the following launches into the memory-side cache (engine, fused mode) */
+                                                 weights of the following launches into the memory-side cache (engine, fused mode); 2: a double
+                                                 block's attention also pulls in mlp.2, 3: a single block's attention also the next block's linear1
+                                                 (in-step -0.1 .. -0.7 % by lease for 2 and 3, +0.3 % once: inside the noise, default stays 1) */
   int w_pairs;           /* FLUXMI_W_PAIRS       1: the engine keeps a row-pair copy of the F8Linear weights its persistent GEMM launches read
                                                  (fluxmi_gemm_group_t.W_pairs: every L2 line of W fetched once per tile instead of twice) */
   int log;               /* FLUXMI_LOG           1: print the struct to stderr when it is resolved / set / an engine is created */
