@@ -278,3 +278,79 @@ def test_bench_preflight_and_batched_config():
     d = out[0]
     assert d["config"]["images_per_gpu"] == 4 and d["config"]["global_batch"] == 8 and d["n_gpus"] == 2
     assert abs(d["value"] - 8 * d["loop_its_per_gpu"]) / d["value"] < 1e-3 and d["image_steps_per_s"] == d["value"]
+
+
+def test_bench_step_trace_and_step_pmc_summaries(tmp_path, monkeypatch):
+    """bench.py's in-step roofline on synthetic rocprofv3 CSVs: the steady steps are the dispatches between the first and the last
+    euler_kernel of the LAST request (the first step carries the request's set-up and is dropped), kernels are binned into GEMM / attention / LayerNorm
+    / other, and the families + gaps sum to the wall time per step; the counter summary applies the gfx950 fetch correction (2 x FETCH_SIZE + WRITE_SIZE,
+    KiB) and the matrix-pipe formula per family."""
+    import csv
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    # ---- kernel trace: calibration, then a 2-step warm-up request, then a 4-step request (3 steady steps) ---------------------------------
+    rows, t = [], [1000]
+
+    def k(name, dur):
+        rows.append(dict(Kernel_Name=name, Start_Timestamp=t[0], End_Timestamp=t[0] + dur * 1000))
+        t[0] += dur * 1000 + 10000  # durations in us, 10 us between kernels
+
+    def step():
+        k("void gemm_ps_kernel<true, 1, 3, false>(FluxmiGemmParams)", 3000)
+        k("void (anonymous namespace)::attention2_kernel<1, true, false, true>(AttnArgs)", 2000)
+        k("ln_modulate_stream_kernel<6, true, 1, true>(LnModArgs, int, int)", 500)
+        k("gemm_w1_kernel<true, 1, 2, 4>(FluxmiGemmParams)", 1500)
+        k("select_step_kernel(int)", 50)
+        k("euler_kernel(unsigned short*)", 40)
+
+    for _ in range(3):
+        k("amax_kernel(float*)", 30); k("calib_update_kernel(float*)", 20); step()
+    for n_steps in (2, 4):
+        k("timestep_rows_kernel(unsigned short*)", 25); k("build_qlut_kernel<1>(float const*)", 25)
+        for _ in range(n_steps):
+            step()
+    d = tmp_path / "trace"
+    d.mkdir()
+    with open(d / "x_kernel_trace.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        w.writeheader(); w.writerows(rows)
+    s = bench.summarize_step_trace(str(d), header="hdr")
+    assert s["steps"] == 3 and s["launches"] == 6.0
+    assert (s["gemm_ms"], s["attention_ms"], s["ln_ms"], s["other_ms"]) == (4.5, 2.0, 0.5, 0.09)
+    assert abs(s["gemm_ms"] + s["attention_ms"] + s["ln_ms"] + s["other_ms"] + s["gaps_ms"] - s["wall_ms"]) < 2e-3 and abs(s["gaps_ms"] - 0.06) < 2e-3
+    assert s["text"].startswith("hdr") and "gemm_ps_kernel" in s["text"] and "3 graph-replayed denoise steps of the last request" in s["text"]
+    # one-step requests (config 1): every step carries its request's set-up, which then counts
+    rows.clear(); t[0] = 1000
+    for _ in range(6):
+        k("timestep_rows_kernel(unsigned short*)", 25); step()
+    with open(d / "x_kernel_trace.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        w.writeheader(); w.writerows(rows)
+    s1 = bench.summarize_step_trace(str(d))
+    assert s1["steps"] == 4 and s1["launches"] == 7.0 and "one-step requests" in s1["text"]
+
+    # ---- counters: three passes, 2 steady steps ---------------------------------------------------------------------------------------------
+    monkeypatch.setattr(bench, "step_pmc_file", lambda cfg: str(tmp_path / f"step_pmc_{cfg}.json"))
+    names = ["timestep_rows_kernel(x)", "gemm_ps_kernel<1>(P)", "attention2_kernel<1>(A)", "euler_kernel(x)"] + ["gemm_ps_kernel<1>(P)", "attention2_kernel<1>(A)", "euler_kernel(x)"] * 2
+    per = {"FETCH_SIZE": {"gemm": 1000.0, "attention": 100.0}, "WRITE_SIZE": {"gemm": 200.0, "attention": 50.0},
+           "GRBM_GUI_ACTIVE": {"gemm": 8000.0, "attention": 8000.0}, "SQ_VALU_MFMA_BUSY_CYCLES": {"gemm": 512000.0, "attention": 256000.0}}
+    for pi, counters in enumerate(bench.STEP_PMC_PASSES):
+        pd = tmp_path / "pmc" / f"p{pi}"
+        pd.mkdir(parents=True)
+        with open(pd / "pmc_counter_collection.csv", "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            w.writeheader()
+            for di, n in enumerate(names):
+                fam = "gemm" if "gemm" in n else "attention" if "attention" in n else None
+                for c in counters:
+                    w.writerow(dict(Dispatch_Id=di + 1, Kernel_Name=n, Counter_Name=c, Counter_Value=per[c].get(fam, 0.0) if fam else 0.0))
+    p = bench.summarize_step_pmc(str(tmp_path / "pmc"), 2, ms_per_step=1.0)
+    assert p["steps"] == 2
+    g, a = p["per_step"]["gemm"], p["per_step"]["attention"]
+    assert g["hbm_bytes"] == (2 * 1000 + 200) * 1024 and a["hbm_bytes"] == (2 * 100 + 50) * 1024
+    assert g["mfma_busy_frac"] == 0.5 and a["mfma_busy_frac"] == 0.25 and p["mfma_busy_frac_step"] == 0.375
+    assert abs(p["hbm_gbs_at_timed_ms_per_step"] - (g["hbm_bytes"] + a["hbm_bytes"]) / 1e-3 / 1e9) < 0.1

@@ -28,6 +28,19 @@ def main():
                     help="only the fused (frozen-scale) denoise steps: dispatches after the last calibration kernel up to the last "
                          "euler_kernel; prints per-step time and launch count per kernel")
     args = ap.parse_args()
+    if args.steady and (os.path.isdir(args.path) and glob.glob(os.path.join(args.path, "**", "*kernel_trace.csv"), recursive=True) or args.path.endswith(".csv")):
+        # CSV traces: the one implementation bench.py uses for roofline.step (steady steps of the LAST request, per-family totals)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+
+        s = bench.summarize_step_trace(args.path, header=args.header)
+        if s is None:
+            sys.exit("no steady denoise steps found in " + args.path)
+        if args.out:
+            os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+            open(args.out, "w").write(s["text"])
+        print(s["text"])
+        return
     dbs = glob.glob(os.path.join(args.path, "**", "*.db"), recursive=True) if os.path.isdir(args.path) else [args.path]
     if not dbs and os.path.isdir(args.path):
         dbs = glob.glob(os.path.join(args.path, "**", "*kernel_trace.csv"), recursive=True)
