@@ -27,6 +27,7 @@ int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, 
   a.B = B; a.L = L; a.Lp = Lp; a.H = H;
   a.scale_log2 = 0.08838834764831845f * 1.4426950408889634f;  // 128^-0.5 * log2(e)
   a.k_f16 = k_f16;
+  a.dbg = nullptr;
   const fluxmi_tuning_t tun = fluxmi_tuning();
   a.pf = fluxmi_take_prefetch();
   if (!tun.prefetch) a.pf.n = 0;

@@ -82,6 +82,10 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
     fluxmi_prefetch_ranges(a.pf, (int)blockIdx.x - main_wgs, a.pf.wgs, tid, NW2 * 64);
     return;
   }
+  const unsigned long long t_dbg0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;  // probes only (tools/attn_timeline.py)
+  auto stamp = [&](int i) {  // phase stamps 4..7 of this workgroup's record: Q fragments built, prologue tiles landed, step loop done, drain done
+    if (a.dbg && tid == 0) ((volatile unsigned long long*)a.dbg)[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+  };
   int lid, tb = 0, ntiles = ntiles_all;
   AttnPiece pc = {0, 0, 1, 0, 0, 0};
   if (split) {
@@ -112,6 +116,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   const float c = a.scale_log2;
   v8bf qf[8];  // FOLD: eight fp16 per fragment in the same registers
   load_q_frags<FOLD>(a, b, h, qld, hi, c, qf);
+  if (a.dbg) { asm volatile("" ::"v"(qf[0]), "v"(qf[7])); stamp(4); }
   // S^T tile += K fragment . Q fragment (f16 MFMA for the folded kernel)
   auto mfma_qk = [](v8bf kfr, v8bf qfr, v16f acc) -> v16f {
     if constexpr (FOLD) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, kfr), __builtin_bit_cast(v8h, qfr), acc, 0, 0, 0);
@@ -186,6 +191,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   if constexpr (MIDBAR) wait_vm<3 * LPW2>();  // K0 and K1 (step 0 reads K1 before its barrier)
   else wait_vm<5 * LPW2>();
   __builtin_amdgcn_s_barrier();
+  stamp(5);
   v16f sa[2], sb[2];
   v4i pfa[4], pfb[4];  // bf16 P fragments as packed words (two tiles: the one the PV MFMAs consume and the one being produced)
 #pragma unroll
@@ -429,6 +435,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
   if (j < ntiles) { step(I3{}, FF{}, sb, sa, pfb, pfa, j); ++j; }
 
   // ---- drain: O^T += V_{n-1}^T P_{n-1}^T (the tile the last step produced) ---------------------------------------------------------
+  stamp(6);
   wait_vm<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -442,6 +449,7 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       o[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, __builtin_bit_cast(v8bf, pf), o[s & 3], 0, 0, 0);
     }
   }
+  if (a.dbg) { asm volatile("" ::"v"(o[0][0]), "v"(o[3][15])); stamp(7); }
   const float l_part = (l4[0] + l4[1]) + (l4[2] + l4[3]);
   const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
   if (ntiles == ntiles_all) {  // the piece is the task
@@ -521,6 +529,14 @@ __global__ void __launch_bounds__(NW2 * 64, 2) attention2_kernel(const AttnArgs 
       if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero between launches
       store_o<FMT>(a, acc, 1.0f / lsum, b, h, qrow, hi);
     }
+  }
+  if (a.dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores of this workgroup's first wave are out
+    unsigned long long* d = a.dbg + (size_t)blockIdx.x * 8;
+    d[0] = blockIdx.x;
+    d[1] = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) << 8);
+    d[2] = t_dbg0;
+    d[3] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -621,6 +637,8 @@ void* attn_workspace(hipStream_t s) {
 }
 }  // namespace
 void fluxmi_set_attn_scratch(void* p) { t_attn_override = p; }
+static unsigned long long* g_attn_dbg = nullptr;  // fluxmi_attention_debug_buffer (probes)
+int fluxmi_attn_debug_buffer(void* p) { g_attn_dbg = (unsigned long long*)p; return 0; }
 
 // The merge of the balanced grid goes through ONE XCD's L2 (see the kernel): it needs workgroup b of a 1-D grid to run on XCD b % 8, the
 // same for every launch.  Checked once per device on the hardware itself (512 one-wave workgroups record HW_REG_XCC_ID): 1 = holds, 0 = not
@@ -684,6 +702,7 @@ template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArg
     attr = true;
   }
   memset(&a.sp, 0, sizeof(a.sp));
+  a.dbg = g_attn_dbg;
   const int tasks = ((a.L + 255) / 256) * a.H * a.B;
   const fluxmi_tuning_t tun = fluxmi_tuning();
   if (FOLD && tun.attn_split && fluxmi_xcd_mapping_ok(s) == 1) {

@@ -55,6 +55,7 @@ struct AttnArgs {
   int k_f16;  // K holds fp16: the folded kernel (scale * log2 e in Q, -max in the accumulator init), f16 MFMAs for QK^T
   FluxmiPrefetch pf;  // weights of the following GEMMs, read by pf.wgs extra workgroups behind the attention grid (fluxmi_internal.h)
   AttnSplit sp;       // balanced grid: the last, partial round of workgroups split along the keys (see AttnSplit)
+  unsigned long long* dbg;  // probes (fluxmi_attention_debug_buffer): [workgroup][8] = {blockIdx, XCC id | HW_ID << 8, start, end, Q built, prologue landed, loop done, drain done} in 100 MHz ticks; null = off
   int abl;  // A/B knobs (FLUXMI_ATTN_ABL, read per call): 2 = no barrier in the 8-wave kernel (timing only), 8 = fp8 output through 16 x 4 B
             // stores per lane (also taken when the output rows are not 16-byte aligned)
 };

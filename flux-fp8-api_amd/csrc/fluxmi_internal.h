@@ -109,6 +109,7 @@ constexpr size_t FLUXMI_ATTN_SPLIT_WS_BYTES = (size_t)8 * 64 * (8 * 17 * 64 * 4)
 void fluxmi_set_attn_scratch(void* p);
 int fluxmi_attn_split_on(int B, int L, int H);
 int fluxmi_attn_plan_any(int B, int L, int H);
+int fluxmi_attn_debug_buffer(void* dev_u64);  // fluxmi_attention_debug_buffer
 int fluxmi_attn_plan_export(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces);  // fluxmi_attention_plan  // the same for ANY tuning (what an engine sizes its workspace by: the knob may change later)
 // tile choice + (when it pays) the split of a grouped launch into a 256x256 and a 128x128 launch; any number of groups
 int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs, int n, int N, int K, int is_fp8, int act_fmt, int epi, hipStream_t s);

@@ -91,6 +91,7 @@ _SIGS = {
     "fluxmi_act_mul": ([vp, vp, i32, i32, i64, i64, i32, vp], i32),
     "fluxmi_text_attention": ([vp, vp, i64, vp, i64, vp, i64, vp, i32, vp, C.c_float, i32, i32, i32, i32, vp], i32),
     "fluxmi_attention": ([vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "fluxmi_attention_debug_buffer": ([vp], i32),
     "fluxmi_attention_plan": ([i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_ulonglong)], i32),
     "fluxmi_attention_rawq": ([vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_timestep_embedding": ([vp, vp, vp, i32, i32, f32, vp], i32),

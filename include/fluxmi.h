@@ -241,6 +241,10 @@ int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, lo
  * pieces[i] (i < npieces <= 64), in launch order: bits 0-7 index of the binned task, 8-15 piece index within the task, 16-23 pieces of
  * the task, 24-31 canonical index of the task's first piece (= its scratch slot), 32-47 first key tile, 48-63 key tiles. */
 int fluxmi_attention_plan(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces);
+/* Probes (tools/attn_timeline.py): a device buffer of [workgroups][8] uint64 that every attention workgroup fills with {blockIdx, XCC id | HW_ID << 8,
+ * start, end, Q fragments built, prologue tiles landed, step loop done, drain done} (100 MHz real-time counter): which CU ran which task / piece
+ * when, and where a workgroup's time outside its key tiles goes.  NULL switches it off. */
+int fluxmi_attention_debug_buffer(void* dev_u64);
 
 /* The same with Q taken RAW from the qkv GEMM output (q at column 0 of `qkv`, row stride ld_qkv): QKNorm (qn_scale0 for rows
  * < split, qn_scale1 otherwise) + RoPE (pe) are applied while the query fragments are loaded, so Q never round-trips through HBM.
