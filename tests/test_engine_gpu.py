@@ -793,3 +793,47 @@ def test_large_batches_in_one_pass_and_in_equal_passes(dev):
     fresh.MAX_ENGINE_BATCH = 12
     with pytest.raises(ValueError, match="frozen"):
         fresh.denoise(*sl(35), ts, guidance=3.5)
+
+
+def test_serving_sequence_at_real_width_is_reproducible_and_memory_flat(dev):
+    """What the reference's api.py does to one pipeline (api.py:54-122 -> flux_pipeline.py:526-651): requests of different resolutions and batch
+    sizes, back to back, through ONE engine.  Every change of shape re-sizes the engine workspace and re-captures the hipGraph, and the kernel
+    selection changes with it (1024^2: persistent GEMM + one workgroup per attention task; 768^2: 192-row tiles + the balanced attention grid;
+    512^2 B = 2: single partial rounds).  A request must give the same bits every time it comes back, whatever ran in between, and device
+    memory in use (library allocations + torch's pool, hipMemGetInfo) must not grow from cycle to cycle.  Hidden 3072, 24 heads, 1 + 2 blocks;
+    the full-depth version with more shapes is tools/soak.py (profiles/r05_soak.txt)."""
+    import util
+    from float8_quantize import quantize_flow_transformer_and_dispatch_float8
+    from fluxmi import synth
+
+    cfg = util.load_config(util.ModelVersion.flux_dev, flow_dtype="bfloat16", quantize_modulation=True, quantize_flow_embedder_layers=False)
+    p = cfg.params
+    p.depth, p.depth_single_blocks = 1, 2
+    requests = [(1024, 1024, 1, 4), (768, 768, 1, 4), (512, 512, 2, 3), (1024, 768, 1, 3)]
+    with torch.inference_mode():
+        model = util.load_flow_model(cfg, synth.make_state_dict(p, seed=0, device=dev))
+        quantize_flow_transformer_and_dispatch_float8(model, dev, flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
+                                                      quantize_modulation=True, quantize_flow_embedder_layers=False)
+        inputs = [to_dev(synth.make_inputs(p, h, w, 512, batch=b, seed=20 + i), dev) for i, (h, w, b, _) in enumerate(requests)]
+
+        def run(i, n):
+            d = inputs[i]
+            return model.denoise(d["img"], d["img_ids"], d["txt"], d["txt_ids"], d["y"], fo.get_schedule(n, d["img"].shape[1]), guidance=3.5)
+
+        run(0, 13)  # calibration: 12 trials + the freezing call
+        assert model.calibration_state()[0]
+        first, used = {}, []
+        for cycle in range(3):
+            for i, (h, w, b, n) in enumerate(requests):
+                out = run(i, n)
+                assert torch.isfinite(out.float()).all(), f"cycle {cycle}, {h}x{w} B={b}: non-finite latents"
+                bits = out.view(torch.int16)
+                if cycle == 0:
+                    first[i] = bits.clone()
+                else:
+                    assert torch.equal(bits, first[i]), f"cycle {cycle}, {h}x{w} B={b}: latents differ from the first time this request ran"
+            torch.cuda.synchronize()
+            free, total = torch.cuda.mem_get_info()
+            used.append(total - free)
+        assert used[2] - used[1] <= (16 << 20) and used[1] - used[0] <= (64 << 20), f"device memory in use grows from cycle to cycle: {[u >> 20 for u in used]} MiB"
+        del model
