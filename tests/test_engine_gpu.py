@@ -837,3 +837,58 @@ def test_serving_sequence_at_real_width_is_reproducible_and_memory_flat(dev):
             used.append(total - free)
         assert used[2] - used[1] <= (16 << 20) and used[1] - used[0] <= (64 << 20), f"device memory in use grows from cycle to cycle: {[u >> 20 for u in used]} MiB"
         del model
+
+
+def test_one_engine_called_from_a_thread_pool(dev):
+    """The reference's FastAPI handlers run in a thread pool (api.py:54: plain `def` endpoints) and share ONE pipeline without a lock; its eager torch ops
+    tolerate that.  A C engine handle with a workspace and a captured hipGraph does not, so Flux.denoise serialises on a per-engine lock and the
+    graph is captured in thread-local mode on a private stream (another thread's allocator calls must not poison the capture).  Three host
+    threads issue different requests (two resolutions + a batch of two: every hand-over re-sizes the workspace and re-captures) against one
+    frozen model, several times each; every result must equal the serial run's bits."""
+    import threading
+
+    import util
+    from float8_quantize import quantize_flow_transformer_and_dispatch_float8
+    from fluxmi import synth
+
+    cfg = util.load_config(util.ModelVersion.flux_dev, flow_dtype="bfloat16", quantize_modulation=True, quantize_flow_embedder_layers=False)
+    p = cfg.params
+    p.depth, p.depth_single_blocks = 1, 2
+    requests = [(1024, 1024, 1, 4), (768, 768, 1, 4), (512, 512, 2, 3)]
+    with torch.inference_mode():
+        model = util.load_flow_model(cfg, synth.make_state_dict(p, seed=1, device=dev))
+        quantize_flow_transformer_and_dispatch_float8(model, dev, flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
+                                                      quantize_modulation=True, quantize_flow_embedder_layers=False)
+        inputs = [to_dev(synth.make_inputs(p, h, w, 512, batch=b, seed=30 + i), dev) for i, (h, w, b, _) in enumerate(requests)]
+
+        def run(i):
+            d = inputs[i]
+            return model.denoise(d["img"], d["img_ids"], d["txt"], d["txt_ids"], d["y"], fo.get_schedule(requests[i][3], d["img"].shape[1]), guidance=3.5)
+
+        d0 = inputs[0]
+        model.denoise(d0["img"], d0["img_ids"], d0["txt"], d0["txt_ids"], d0["y"], fo.get_schedule(13, d0["img"].shape[1]), guidance=3.5)  # calibration
+        assert model.calibration_state()[0]
+        serial = [run(i).view(torch.int16).clone() for i in range(len(requests))]
+        torch.cuda.synchronize()
+        errors, bar = [], threading.Barrier(len(requests))
+
+        def work(i):
+            try:
+                with torch.inference_mode():
+                    bar.wait()
+                    for rep in range(6):
+                        out = run(i)
+                        torch.cuda.synchronize()
+                        if not torch.equal(out.view(torch.int16), serial[i]):
+                            errors.append(f"thread {i} repetition {rep}: latents differ from the serial run")
+            except Exception as e:  # noqa: BLE001 -- reported by the main thread
+                errors.append(f"thread {i}: {type(e).__name__}: {e}")
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(requests))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in th), "a worker thread hangs"
+        assert not errors, errors
+        del model
