@@ -14,6 +14,10 @@ Cases (one per BASELINE.json config, plus the full depth and the loop):
   c5_lora_2p2_L4608  c2_2p2_L4608's model with a rank-16 LoRA on every attention / MLP linear (fused-qkv layers in the reference's "uneven
                  rank" form) fused into the fp8 weights at scale 1.0 AFTER calibration (lora_loading.py:509-577,635-693)  configs[4]
   c2_loop4_2p2_L4608  c2_2p2_L4608's model: one calibrating call, then a 4-step frozen Euler loop (flux_pipeline.py:619-651)
+  c2_default_1p1_L3392  1 + 1 blocks at the resolution FluxPipeline.generate defaults to (width 720, height 1024, flux_pipeline.py:526-540):
+                 Li = 64 x 45 = 2880, L = 3392 = 13.25 row tiles of 256 (53 key tiles of 64)
+  c2_ragged_1p1_L3257  1 + 1 blocks at 720 x 976: Li = 61 x 45 = 2745, L = 3257 (ODD: ragged last GEMM row tile of 185 rows, ragged last query
+                 block and key tile in attention, padded V^T rows), 13 x 3 = 39 attention tasks per XCD = a thin last round (the balanced grid)
 Protocol per case: call 1 calibrates (every F8Linear takes its first amax trial, float8_quantize.py:220-238), the input scales are
 then frozen (`input_scale_initialized = True`, what the reference does after its 13th call, :239-246) and call 2 runs frozen with
 every intermediate recorded.  A full tensor at L = 4608 is tens of MB, so fixtures hold SAMPLES (first 256 + 768 evenly strided
@@ -43,6 +47,10 @@ CASES = {
                               w_seed=11, in_seed=21, trace="blocks", lora=dict(rank=16, seed=5)),
     "c2_loop4_2p2_L4608": dict(depth=2, single=2, height=1024, width=1024, txt_len=512, quant=dict(modulation=True, embedders=False),
                                w_seed=11, in_seed=21, trace="none", loop_steps=4),
+    "c2_default_1p1_L3392": dict(depth=1, single=1, height=1024, width=720, txt_len=512, quant=dict(modulation=True, embedders=False),
+                                 w_seed=16, in_seed=29, trace="all"),
+    "c2_ragged_1p1_L3257": dict(depth=1, single=1, height=976, width=720, txt_len=512, quant=dict(modulation=True, embedders=False),
+                                w_seed=16, in_seed=30, trace="all"),
     # harness checks only (no fixture): the same test code on models that run in a second
     "tiny_schnell_bf16_L48": dict(depth=2, single=2, height=64, width=64, txt_len=32, quant=None, w_seed=15, in_seed=27, trace="blocks", schnell=True,
                                   params=dict(hidden_size=256, num_heads=2, context_in_dim=128, vec_in_dim=64, guidance_embed=False)),

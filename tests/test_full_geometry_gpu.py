@@ -362,7 +362,7 @@ def teacher_forced_last_layer(ck, E, orc, tr, p, H, Lt, L, x_final, o1):
     ck.bf16("final_layer whole, teacher-forced input", E.get("pred_s", (L - Lt, o1.shape[-1]), torch.bfloat16), o1[0], 0.97, 0.995, 3e-3)
 
 
-@pytest.mark.parametrize("name", ["tiny_2p2_L96", "c2_2p2_L4608", "c3_2p2_L2816"])
+@pytest.mark.parametrize("name", ["tiny_2p2_L96", "c2_2p2_L4608", "c3_2p2_L2816", "c2_default_1p1_L3392", "c2_ragged_1p1_L3257"])
 def test_teacher_forced_blocks_at_real_geometry(dev, name):
     case, p, inp, model, orc, o1, tr = prepare_case(name, dev)
     ck = Checks(name)
