@@ -18,6 +18,10 @@ Cases (one per BASELINE.json config, plus the full depth and the loop):
                  Li = 64 x 45 = 2880, L = 3392 = 13.25 row tiles of 256 (53 key tiles of 64)
   c2_ragged_1p1_L3257  1 + 1 blocks at 720 x 976: Li = 61 x 45 = 2745, L = 3257 (ODD: ragged last GEMM row tile of 185 rows, ragged last query
                  block and key tile in attention, padded V^T rows), 13 x 3 = 39 attention tasks per XCD = a thin last round (the balanced grid)
+  c4_B2_ragged_1p1_L3257  the same odd L with a batch of TWO different samples (batch strides over ragged rows, 2 x (txt, img) GEMM groups each
+                 with its own ragged last tile, attention over B x heads with a ragged last block)
+  c1_schnell_bf16_1p1_L4352  Flux-schnell's bf16 flow (no fp8) at 1024x1024 + Lt 256: the bf16 MFMA GEMMs at LARGE M (17 row tiles), which the
+                 256x256 config-1 case (M = 512) never launches
 Protocol per case: call 1 calibrates (every F8Linear takes its first amax trial, float8_quantize.py:220-238), the input scales are
 then frozen (`input_scale_initialized = True`, what the reference does after its 13th call, :239-246) and call 2 runs frozen with
 every intermediate recorded.  A full tensor at L = 4608 is tens of MB, so fixtures hold SAMPLES (first 256 + 768 evenly strided
@@ -51,6 +55,10 @@ CASES = {
                                  w_seed=16, in_seed=29, trace="all"),
     "c2_ragged_1p1_L3257": dict(depth=1, single=1, height=976, width=720, txt_len=512, quant=dict(modulation=True, embedders=False),
                                 w_seed=16, in_seed=30, trace="all"),
+    "c4_B2_ragged_1p1_L3257": dict(depth=1, single=1, height=976, width=720, txt_len=512, quant=dict(modulation=True, embedders=False),
+                                   w_seed=16, in_seed=31, trace="blocks", batch=2),
+    "c1_schnell_bf16_1p1_L4352": dict(depth=1, single=1, height=1024, width=1024, txt_len=256, quant=None, w_seed=17, in_seed=32, trace="blocks",
+                                      params=dict(guidance_embed=False), schnell=True),
     # harness checks only (no fixture): the same test code on models that run in a second
     "tiny_schnell_bf16_L48": dict(depth=2, single=2, height=64, width=64, txt_len=32, quant=None, w_seed=15, in_seed=27, trace="blocks", schnell=True,
                                   params=dict(hidden_size=256, num_heads=2, context_in_dim=128, vec_in_dim=64, guidance_embed=False)),

@@ -513,7 +513,7 @@ def teacher_forced_all_blocks(ck, name, model, orc, tr, p, case, mode, single_to
     return E, prev
 
 
-@pytest.mark.parametrize("name", ["tiny_schnell_bf16_L48", "c1_schnell_bf16_19p38_L512"])
+@pytest.mark.parametrize("name", ["tiny_schnell_bf16_L48", "c1_schnell_bf16_1p1_L4352", "c1_schnell_bf16_19p38_L512"])
 def test_schnell_bf16_flow_at_full_depth(dev, name):
     """BASELINE.json configs[0] at its REAL geometry: Flux-schnell (no guidance embedder), hidden 3072, all 19 + 38 blocks, 256x256 + 256 text
     tokens, bf16 nn.Linear everywhere -- the engine's bf16 path (bf16 MFMA GEMMs at M = 256 / 512, unfused sequencing).  Gates: every block alone
@@ -546,7 +546,7 @@ def test_schnell_bf16_flow_at_full_depth(dev, name):
         fg.drop_sd_cache()  # 24 GB of synthetic checkpoint shared with test_full_depth_19_38
 
 
-@pytest.mark.parametrize("name", ["tiny_B2_L96", "c4_B2_1p1_L4608"])
+@pytest.mark.parametrize("name", ["tiny_B2_L96", "c4_B2_1p1_L4608", "c4_B2_ragged_1p1_L3257"])
 def test_batch_of_two_at_real_geometry(dev, name):
     """BASELINE.json configs[3] on one GPU: TWO different samples through one engine at L = 4608 (batch strides of every buffer, grouped GEMM
     launches with 2 x (txt, img) groups, attention over B x heads) against the oracle's / reference's batch-2 call; and each sample of the
