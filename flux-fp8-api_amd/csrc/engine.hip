@@ -218,6 +218,28 @@ int run_gemm(std::vector<FluxmiGemmGroup>& gs, int N, int K, int is_fp8, int act
   return fluxmi_gemm_dispatch(gs.data(), (int)gs.size(), N, K, is_fp8, act_fmt, epi, s);
 }
 
+// The bf16-operand linears around the blocks of an fp8 model (img_in, txt_in, final_layer.linear): ONE tile config whatever the batch size.  The
+// fp8 tile configs give the same bits (one MFMA shape, one K order), the bf16 ones do not: configs 2 / 15 and 13 / 16 associate the K sum
+// differently (~3e-4 of the outputs differ in their last bit, tools/probes/bf16_cfg_bits_probe.py), and the automatic choice follows the row
+// count -- through img_in a sample's latents depended on the batch it rode in from B = 4 on (B x 4096 rows: config 13 instead of 2;
+// tests/test_engine_gpu.py::test_maximum_batch_at_real_width).  Config 2 (128x128 tiles; 15 = its 128x64 form) is the choice at B = 1 for all
+// three and costs nothing at larger B (K = 64 / one launch per request / N = 64: output-bound launches of tens of microseconds).
+// The bf16 FLOW (no fp8 anywhere) keeps the per-shape choice incl. split-K: its results follow the batch size at rounding level, like the
+// reference's cuBLAS heuristics.
+int run_gemm_fixed_cfg(std::vector<FluxmiGemmGroup>& gs, int N, int K, int is_fp8, int act_fmt, int epi, hipStream_t s) {
+  const int cfg = fluxmi_gemm_tile_ok(N, K, 0, 2) ? 2 : (fluxmi_gemm_tile_ok(N, K, 0, 15) ? 15 : -1);
+  if (is_fp8 || cfg < 0 || fluxmi_tuning().gemm_cfg >= 0) return run_gemm(gs, N, K, is_fp8, act_fmt, epi, s);
+  for (size_t off = 0; off < gs.size(); off += FLUXMI_MAX_GROUPS) {
+    FluxmiGemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.n_groups = (int)std::min<size_t>(FLUXMI_MAX_GROUPS, gs.size() - off);
+    for (int i = 0; i < p.n_groups; ++i) p.g[i] = gs[off + i];
+    p.N = N; p.K = K; p.epi = epi;
+    FLUXMI_TRY(fluxmi_launch_gemm(p, 0, act_fmt, cfg, s));
+  }
+  return 0;
+}
+
 // ---- calibration helpers (unfused path) ------------------------------------------------------------
 int calib_begin(E* e, int li, hipStream_t s) { return hipMemsetAsync(e->d_amax + li, 0, sizeof(float), s) == hipSuccess ? 0 : 2; }
 int calib_amax(E* e, int li, const void* x, int rows, int cols, long long ld, hipStream_t s) {
@@ -392,7 +414,7 @@ int embed_txt(E* e, const u16* txt, bool calib, int trial, u16* dst, long long d
   for (int b = 0; b < B; ++b)
     gs.push_back(mk_group(l, l.kind ? (const void*)(in8 + (long long)b * Lt * C) : (const void*)(txt + (long long)b * Lt * C), C,
                           dst + b * dst_bstride, H, Lt));
-  return run_gemm(gs, H, C, l.kind, l.in_fmt, FLUXMI_EPI_BF16, s);
+  return run_gemm_fixed_cfg(gs, H, C, l.kind, l.in_fmt, FLUXMI_EPI_BF16, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -754,7 +776,7 @@ int final_layer(E* e, u16* pred, int s0, int s1, hipStream_t s) {
     const fluxmi_linear_t& l = e->lin[e->i_final_lin];
     std::vector<FluxmiGemmGroup> gs;
     gs.push_back(mk_group(l, fin, H, pred, l.N, B * Li));
-    FLUXMI_TRY(run_gemm(gs, l.N, H, 0, 0, FLUXMI_EPI_BF16, s));
+    FLUXMI_TRY(run_gemm_fixed_cfg(gs, l.N, H, 0, 0, FLUXMI_EPI_BF16, s));
   }
   return 0;
 }
@@ -794,7 +816,7 @@ int forward_impl(E* e, const u16* img, const u16* txt, const u16* y, const u16* 
     for (int b = 0; b < B; ++b)
       gs.push_back(mk_group(l, l.kind ? (const void*)(in8 + (long long)b * Li * C) : (const void*)(img + (long long)b * Li * C), C,
                             x + b * XB + (long long)Lt * H, H, Li));
-    FLUXMI_TRY(run_gemm(gs, H, C, l.kind, l.in_fmt, FLUXMI_EPI_BF16, s));
+    FLUXMI_TRY(run_gemm_fixed_cfg(gs, H, C, l.kind, l.in_fmt, FLUXMI_EPI_BF16, s));
   }
   if (txt_cached) {
     FLUXMI_CHECK_HIP(hipMemcpy2DAsync(x, XB * 2, buf<u16>(e, "txt_emb"), (size_t)Lt * H * 2, (size_t)Lt * H * 2, B, hipMemcpyDeviceToDevice, s));

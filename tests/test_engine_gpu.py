@@ -892,3 +892,37 @@ def test_one_engine_called_from_a_thread_pool(dev):
         assert not any(t.is_alive() for t in th), "a worker thread hangs"
         assert not errors, errors
         del model
+
+
+def test_maximum_batch_at_real_width(dev):
+    """The engine's limit, B = 32 samples in ONE pass, at Flux-dev's width and 1024x1024 + 512 text tokens (1 + 1 blocks): the buffers cross
+    2^31 bytes (linear1's output 4608 x 32 rows x 21504 bf16 = 6.3 GB, the linear2 input 2.3 G fp8 elements), every grouped launch carries 64
+    (sample, stream) groups, attention runs 13 824 tasks.  Samples never interact (flux_model.py has no cross-sample op), so each of a handful of
+    samples must come out of the batch exactly as it comes out alone -- any 32-bit offset, group-table or grid-size limit shows up as a mismatch."""
+    import util
+    from float8_quantize import quantize_flow_transformer_and_dispatch_float8
+    from fluxmi import synth
+
+    cfg = util.load_config(util.ModelVersion.flux_dev, flow_dtype="bfloat16", quantize_modulation=True, quantize_flow_embedder_layers=False)
+    p = cfg.params
+    p.depth, p.depth_single_blocks = 1, 1
+    B = 32
+    with torch.inference_mode():
+        model = util.load_flow_model(cfg, synth.make_state_dict(p, seed=2, device=dev))
+        quantize_flow_transformer_and_dispatch_float8(model, dev, flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
+                                                      quantize_modulation=True, quantize_flow_embedder_layers=False)
+        assert B == model.MAX_ENGINE_BATCH
+        inp = to_dev(synth.make_inputs(p, 1024, 1024, 512, batch=B, seed=40), dev)
+        keys = ("img", "img_ids", "txt", "txt_ids", "y")
+        Li = inp["img"].shape[1]
+        one = lambda i: tuple(inp[k][i:i + 1].contiguous() for k in keys)
+        model.denoise(*one(0), fo.get_schedule(13, Li), guidance=3.5)  # calibration on sample 0
+        assert model.calibration_state()[0]
+        ts = fo.get_schedule(2, Li)
+        whole = model.denoise(*(inp[k] for k in keys), ts, guidance=3.5)
+        torch.cuda.synchronize()
+        assert whole.shape[0] == B and torch.isfinite(whole.float()).all()
+        for i in (0, 1, 14, 15, 16, 30, 31):
+            alone = model.denoise(*one(i), ts, guidance=3.5)
+            assert torch.equal(alone[0].view(torch.int16), whole[i].view(torch.int16)), f"sample {i} of the 32-batch differs from the same sample alone"
+        del model
