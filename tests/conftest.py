@@ -44,11 +44,28 @@ def _full_geometry_case(item):
     return name if isinstance(name, str) and not name.startswith("tiny_") else None
 
 
+# process-spawning tests: real engines in child processes joined by a process group.  They depend on the most machinery outside the
+# kernels (spawn, rendezvous ports, a second HIP context on the device), so they run LAST: under `-x` nothing they do can hide a kernel result.
+SPAWNING_TESTS = ("test_two_process_sharded_calibration_over_a_process_group", "test_bench_two_ranks_share_one_device")
+_FILE_RANK = {"test_ops_gpu.py": 0, "test_text_gpu.py": 1, "test_engine_gpu.py": 2, "test_pixels_gpu.py": 3, "test_full_geometry_gpu.py": 4}
+
+
+def _gpu_rank(item):
+    if item.originalname in SPAWNING_TESTS or item.name in SPAWNING_TESTS:
+        return 9
+    if _full_geometry_case(item) in FULL_DEPTH_CASES:
+        return 8  # their checkpoint is synthesised by a background thread while everything else runs
+    return _FILE_RANK.get(os.path.basename(item.nodeid.split("::")[0]), 3)
+
+
 def pytest_collection_modifyitems(config, items):
-    """the two full-depth cases run LAST: their checkpoint is synthesised by a background thread while everything else runs"""
-    late = [it for it in items if _full_geometry_case(it) in FULL_DEPTH_CASES]
-    if late:
-        items[:] = [it for it in items if it not in late] + late
+    """GPU tests: op-level bit-exact tests FIRST (cheap, deterministic, most of the per-row parity evidence), then the text encoders, the
+    model-level tests, the full-geometry cases (full depth late: background checkpoint), process-spawning tests LAST.  CPU tests keep
+    their place.  The sort is stable, so the order inside a file is the file's."""
+    gpu = [it for it in items if it.get_closest_marker("gpu") is not None]
+    if gpu:
+        gpu_sorted = iter(sorted(gpu, key=_gpu_rank))
+        items[:] = [next(gpu_sorted) if it.get_closest_marker("gpu") is not None else it for it in items]
 
 
 def pytest_collection_finish(session):
@@ -66,3 +83,25 @@ def pytest_collection_finish(session):
         import oracle_prefetch
 
         oracle_prefetch.schedule([[c for c in cases if c in FULL_DEPTH_CASES], [c for c in cases if c not in FULL_DEPTH_CASES]])
+
+
+_exit_status = [None]
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_sessionfinish(session, exitstatus):
+    _exit_status[0] = int(exitstatus)
+    if "oracle_prefetch" in sys.modules:
+        sys.modules["oracle_prefetch"]._cancel.set()  # workers stop at their next log line while the summary is being written
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_unconfigure(config):
+    """no prefetch worker may still be inside torch when the interpreter finalises (oracle_prefetch.cancel_and_join): wait for them; if one
+    is in the middle of a minutes-long torch call, leave through os._exit with pytest's own exit status (everything has been reported)."""
+    op = sys.modules.get("oracle_prefetch")
+    if op is None or op.cancel_and_join(20.0):
+        return
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(_exit_status[0] if _exit_status[0] is not None else 1)

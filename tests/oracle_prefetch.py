@@ -15,6 +15,12 @@ import traceback
 
 _jobs = {}
 _lock = threading.Lock()
+_threads = []
+_cancel = threading.Event()
+
+
+class Cancelled(BaseException):
+    """raised inside a worker (from its log callback, the only cancellation points the oracle code offers) once the session is over"""
 
 
 class _Job:
@@ -41,9 +47,18 @@ def _worker(work):
     import torch
 
     torch.set_num_threads(torch.get_num_threads())  # a new thread starts from the OpenMP default: give it the session's team size
+    def log(line, _append=None):
+        if _cancel.is_set():
+            raise Cancelled()
+        _append(line)
+
     for name, job in work:  # the job objects themselves: take() may already have removed a name from the table
+        if _cancel.is_set():
+            job.error = "cancelled: the session ended before this case was computed"
+            job.done.set()
+            continue
         try:
-            job.result = compute(name, job.log.append)
+            job.result = compute(name, lambda line, a=job.log.append: log(line, a))
         except BaseException:  # noqa: the test that takes the case re-raises
             job.error = traceback.format_exc()
         job.done.set()
@@ -58,7 +73,21 @@ def schedule(groups):
                 continue
             for n in names:
                 _jobs[n] = _Job()
-            threading.Thread(target=_worker, args=([(n, _jobs[n]) for n in names],), daemon=True, name="oracle-prefetch:" + names[0]).start()
+            t = threading.Thread(target=_worker, args=([(n, _jobs[n]) for n in names],), daemon=True, name="oracle-prefetch:" + names[0])
+            _threads.append(t)
+            t.start()
+
+
+def cancel_and_join(timeout: float = 20.0) -> bool:
+    """End of session: ask the workers to stop at their next log line and wait for them.  -> True when no worker is left running.
+    A daemon thread still inside torch's C++ when the interpreter finalises is killed by pthread_exit while unwinding through noexcept
+    frames -> std::terminate -> the whole pytest process aborts with rc 134 whatever the tests did (GPUTEST_r05); the caller (conftest)
+    leaves through os._exit when this returns False."""
+    _cancel.set()
+    t_end = time.time() + timeout
+    for t in _threads:
+        t.join(max(0.0, t_end - time.time()))
+    return not any(t.is_alive() for t in _threads)
 
 
 def take(name):

@@ -18,6 +18,8 @@ order is bit-identical; residual differences come from attention (flash vs math 
 """
 import copy
 import os
+import queue
+import time
 
 import pytest
 import torch
@@ -329,7 +331,7 @@ def test_batch_sharded_calibration_matches_whole_batch(dev):
     assert differ > 0
 
 
-def _two_process_worker(rank, world, port, backend, q):
+def _two_process_worker(rank, world, port, backend, q, release):
     """One rank of test_two_process_sharded_calibration_over_a_process_group: the REAL engine on cuda:0, one sample of the batch, the
     in-step amax exchange through torch.distributed (RCCL if it takes two ranks on one device, else gloo with the 1.2 KB amax vector
     staged through the host)."""
@@ -393,13 +395,19 @@ def _two_process_worker(rank, world, port, backend, q):
         if backend != "gloo":
             rid = rid.to(dev)
         td.all_reduce(rid, op=td.ReduceOp.SUM)
-        q.put((rank, "ok", out.cpu(), scales, n_x[0], td.get_backend(), [float(v) for v in rid.cpu()]))
+        # plain Python objects only: a torch tensor crosses an mp.Queue by fd-passing from a thread INSIDE the sender, which races with
+        # the sender's exit (the parent's q.get then raises ConnectionRefusedError).  bf16 latents travel as their int16 bit patterns.
+        lat = out.detach().cpu().contiguous()
+        q.put((rank, "ok", (lat.view(torch.int16).numpy().tobytes(), tuple(lat.shape)), scales, n_x[0], td.get_backend(),
+               [float(v) for v in rid.cpu()]))
         td.barrier()
         td.destroy_process_group()
     except Exception as e:  # noqa
         import traceback
 
         q.put((rank, "error", traceback.format_exc(), None, 0, backend, None))
+    # stay alive until the parent holds BOTH results (or gives up): the queue's feeder thread has then certainly flushed
+    release.wait(timeout=600)
 
 
 def test_two_process_sharded_calibration_over_a_process_group(dev):
@@ -431,21 +439,33 @@ def test_two_process_sharded_calibration_over_a_process_group(dev):
             so.bind(("127.0.0.1", 0))
             port = so.getsockname()[1]
         q = ctx.Queue()
-        procs = [ctx.Process(target=_two_process_worker, args=(r, 2, port, backend, q)) for r in range(2)]
+        release = ctx.Event()
+        procs = [ctx.Process(target=_two_process_worker, args=(r, 2, port, backend, q, release)) for r in range(2)]
         for p in procs:
             p.start()
-        res = []
-        try:
-            for _ in procs:
-                res.append(q.get(timeout=150 if backend == "nccl" else 420))
-        except Exception:  # a rank died or hung (RCCL refuses two ranks on one device on some stacks): fall back to gloo
-            pass
+        res, why = [], None
+        deadline = time.time() + (240 if backend == "nccl" else 600)
+        while len(res) < len(procs) and time.time() < deadline:
+            try:
+                res.append(q.get(timeout=2.0))
+            except queue.Empty:
+                # a rank that died without reporting (RCCL refuses two ranks on one device on some stacks -> abort) will never report
+                if any(p.exitcode not in (None, 0) for p in procs) and q.empty():
+                    why = f"a rank exited with {[p.exitcode for p in procs]} before reporting"
+                    break
+            except Exception as e:  # noqa: recorded, never swallowed
+                why = f"q.get raised {type(e).__name__}: {e}"
+                break
+        if why is None and len(res) < len(procs):
+            why = f"timed out with {len(res)} of {len(procs)} results"
+        release.set()
         for p in procs:
-            p.join(timeout=30)
+            p.join(timeout=60)
             if p.is_alive():
                 p.terminate()
+                p.join(timeout=10)
         ok = len(res) == 2 and all(r[1] == "ok" for r in res)
-        tried.append((backend, ok, [r[2][-400:] if r[1] != "ok" else "ok" for r in res]))
+        tried.append((backend, ok, why, [r[2][-400:] if r[1] != "ok" else "ok" for r in res]))
         if ok:
             break
     assert ok, f"no backend completed the two-process run: {tried}"
@@ -457,7 +477,7 @@ def test_two_process_sharded_calibration_over_a_process_group(dev):
     for r in res:
         bad = [n for n in names if r[3][n] != want[n]]
         assert not bad, f"rank {r[0]}: {len(bad)} input scales differ from the whole-batch run (e.g. {bad[:3]})"
-    lat = torch.cat((res[0][2], res[1][2]), 0)
+    lat = torch.cat([torch.frombuffer(bytearray(b), dtype=torch.int16).view(torch.bfloat16).reshape(shp) for b, shp in (res[0][2], res[1][2])], 0)
     assert torch.equal(lat, ref), f"two-process latents differ from the whole-batch run: rel-L2 {rel_l2(lat, ref):.3e}"
 
 
