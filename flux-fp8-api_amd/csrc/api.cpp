@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <vector>
 
 #include "fluxmi_internal.h"
@@ -62,7 +63,31 @@ int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8) {
 static thread_local int g_splitk_block = 0;
 void fluxmi_gemm_block_splitk(int on) { g_splitk_block += on ? 1 : -1; }
 
-static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is_fp8, int act_fmt, int epi, int force_cfg, hipStream_t s) {
+// The split-K choice of a bf16 launch (below) depends on how many tiles the launch has, and a split-K sum associates K differently from the
+// one-pass kernels (whose tile configs all give the same bits): decided on ALL rows of a batched launch, a sample's result would follow the
+// batch it rides in (Flux-schnell 256^2, bf16 flow: split-K at B = 1, none from B = 4 on).  An engine therefore announces its batch
+// (fluxmi_gemm_set_batch, thread-local like the scratch pointers) and the dispatcher decides on ONE sample's share of the groups;
+// reference flux_model.py:672-716 has no cross-sample operation.
+static thread_local int g_gemm_batch = 1;
+void fluxmi_gemm_set_batch(int B) { g_gemm_batch = B < 1 ? 1 : B; }
+
+// split-K slices for a bf16 launch of these groups (0 = one pass); `tiles`, `rows`: 256-row tiles x N / 256 and padded rows of the groups
+static int splitk_slices(long long tiles, long long rows, int N, int K, int is_fp8, int epi, bool fused_out, int force_cfg) {
+  const fluxmi_tuning_t tun = fluxmi_tuning();
+  const int nk = K * (is_fp8 ? 1 : 2) / 64;
+  const bool can = !fused_out && (epi == FLUXMI_EPI_BF16 || epi == FLUXMI_EPI_GATE_RESID) && fluxmi_gemm_tile_ok(N, K, is_fp8, 13) && tiles > 0;
+  int S = 0;
+  // measured on M = 512 bf16 launches (tools/bf16_gemm_probe.py, profiles/r03_small_m.txt): below ~190 K-steps per tile the 128x128 tiles at two
+  // workgroups per CU are as fast as any split; above, ~40-50 K-steps per workgroup is the sweet spot (K = 15360: 72 us vs 158 us unsplit)
+  if (force_cfg < 0 && tun.gemm_splitk && !g_splitk_block && can && !is_fp8 && tun.gemm_cfg < 0 && tiles <= 128 && nk >= 192)
+    S = (int)std::max<long long>(2, std::min<long long>(std::min<long long>(256 / tiles, (nk + 24) / 48), 16));
+  while (S >= 2 && (size_t)S * rows * N * 4 > ((size_t)256 << 20)) --S;
+  return S >= 2 ? S : 0;
+}
+
+// s_hint: -1 = decide the split-K slices on this chunk's own groups; >= 0 = decided by the caller on one sample's groups (0: one pass)
+static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is_fp8, int act_fmt, int epi, int force_cfg, hipStream_t s,
+                          int s_hint = -1) {
   FluxmiGemmParams p;
   memset(&p, 0, sizeof(p));
   p.n_groups = n;
@@ -77,21 +102,31 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
   // bound -> split K over several workgroups per tile (fp32 partials + a reduce / epilogue pass).  fluxmi_tuning_t.gemm_splitk = 0 turns it off;
   // fluxmi_gemm_grouped(tile_cfg = 113 + S) forces S splits (tests).
   {
-    const fluxmi_tuning_t tun = fluxmi_tuning();
-    const int sk_on = tun.gemm_splitk;
-    int S = 0;
-    const int nk = K * (is_fp8 ? 1 : 2) / 64;
     bool fused_out = false;
     long long tiles = 0, rows = 0;
     for (int i = 0; i < n; ++i) { tiles += (gs[i].M + 255) / 256; rows += (long long)((gs[i].M + 255) / 256) * 256; fused_out |= (gs[i].vt_out || gs[i].k_out); }
     tiles *= N / 256;
-    const bool can = !fused_out && (epi == FLUXMI_EPI_BF16 || epi == FLUXMI_EPI_GATE_RESID) && fluxmi_gemm_tile_ok(N, K, is_fp8, 13) && tiles > 0;
-    // measured on M = 512 bf16 launches (tools/bf16_gemm_probe.py, profiles/r03_small_m.txt): below ~190 K-steps per tile the 128x128 tiles at two
-    // workgroups per CU are as fast as any split; above, ~40-50 K-steps per workgroup is the sweet spot (K = 15360: 72 us vs 158 us unsplit)
-    if (force_cfg < 0 && sk_on && !g_splitk_block && can && !is_fp8 && tun.gemm_cfg < 0 && tiles <= 128 && nk >= 192)
-      S = (int)std::max<long long>(2, std::min<long long>(std::min<long long>(256 / tiles, (nk + 24) / 48), 16));
-    while (S >= 2 && (size_t)S * rows * N * 4 > ((size_t)256 << 20)) --S;
-    if (S >= 2) return fluxmi_launch_gemm_splitk(p, is_fp8, act_fmt, S, s);
+    const int S = s_hint >= 0 ? s_hint : splitk_slices(tiles, rows, N, K, is_fp8, epi, fused_out, force_cfg);
+    if (S >= 2) {
+      // the fp32 partial tiles of S slices must fit the scratch: a batched launch whose S was fixed on one sample goes in as many pieces as it takes
+      const size_t cap = (size_t)256 << 20;
+      if ((size_t)S * rows * N * 4 <= cap) return fluxmi_launch_gemm_splitk(p, is_fp8, act_fmt, S, s);
+      FLUXMI_REQUIRE(s_hint >= 0, "gemm: split-K scratch too small for %d slices", S);
+      for (int i0 = 0; i0 < n;) {
+        FluxmiGemmParams q = p;
+        q.n_groups = 0;
+        size_t r = 0;
+        while (i0 < n) {
+          const size_t gr = (size_t)((gs[i0].M + 255) / 256) * 256;
+          if (q.n_groups > 0 && (size_t)S * (r + gr) * N * 4 > cap) break;
+          FLUXMI_REQUIRE((size_t)S * gr * N * 4 <= cap, "gemm: one group of %d rows does not fit the split-K scratch at %d slices", gs[i0].M, S);
+          q.g[q.n_groups++] = gs[i0++];
+          r += gr;
+        }
+        FLUXMI_TRY(fluxmi_launch_gemm_splitk(q, is_fp8, act_fmt, S, s));
+      }
+      return 0;
+    }
   }
   // bf16 operands, one thin round of 256x256 tiles (Flux-schnell linear1 at M = 512: 168 tiles): the one-wave-per-SIMD kernel runs the
   // single tile per CU fastest (74 us vs 95 / 98 us for configs 13 / 2, profiles/r03_small_m.txt)
@@ -157,26 +192,77 @@ int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs_in, int n_in, int N, int K, i
       FLUXMI_TRY(run_gemm_chunk(gs.data() + off, (int)std::min<size_t>(FLUXMI_MAX_GROUPS, gs.size() - off), N, K, is_fp8, act_fmt, epi, cfg, s));
     return 0;
   }
-  if (hybrid && gs.size() >= 2 && gs.size() <= FLUXMI_MAX_GROUPS && tun.gemm_cfg < 0 &&
-      fluxmi_gemm_tile_ok(N, K, is_fp8, 13) && fluxmi_gemm_tile_ok(N, K, is_fp8, 2) &&
-      (epi != FLUXMI_EPI_SPLIT || gs[0].split_n % 256 == 0)) {
-    std::vector<int> order(gs.size());
-    for (size_t i = 0; i < gs.size(); ++i) order[i] = (int)i;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return gs[a].M < gs[b].M; });
+  const bool peel_ok = hybrid && tun.gemm_cfg < 0 && fluxmi_gemm_tile_ok(N, K, is_fp8, 13) && fluxmi_gemm_tile_ok(N, K, is_fp8, 2) &&
+                       (epi != FLUXMI_EPI_SPLIT || gs[0].split_n % 256 == 0);
+  // how many of the smallest groups (row counts `ms`, ascending) go to the 128x128 launch
+  auto peel_count = [&](const std::vector<int>& ms) -> int {
+    if (!peel_ok || ms.size() < 2 || ms.size() > FLUXMI_MAX_GROUPS) return 0;
     const long long tn = N / 256;
     long long T = 0;
-    for (auto& g : gs) T += (long long)((g.M + 255) / 256) * tn;
-    const double single = (double)((T + 255) / 256);
-    double best = single - 0.15;
+    for (int m : ms) T += (long long)((m + 255) / 256) * tn;
+    double best = (double)((T + 255) / 256) - 0.15;
     int best_k = 0;
     long long peeled = 0;
-    for (size_t k = 1; k < gs.size(); ++k) {  // peel the k smallest groups
-      peeled += (long long)((gs[order[k - 1]].M + 255) / 256) * tn;
+    for (size_t k = 1; k < ms.size(); ++k) {  // peel the k smallest groups
+      peeled += (long long)((ms[k - 1] + 255) / 256) * tn;
       long long small_tiles = 0;
-      for (size_t q = 0; q < k; ++q) small_tiles += (long long)((gs[order[q]].M + 127) / 128) * (N / 128);
+      for (size_t q = 0; q < k; ++q) small_tiles += (long long)((ms[q] + 127) / 128) * (N / 128);
       const double cost = (double)((T - peeled + 255) / 256) + 0.58 * (double)((small_tiles + 511) / 512);
       if (cost < best) { best = cost; best_k = (int)k; }
     }
+    return best_k;
+  };
+  auto chunks = [&](std::vector<FluxmiGemmGroup>& v, int force_cfg, int s_hint) -> int {
+    for (size_t off = 0; off < v.size(); off += FLUXMI_MAX_GROUPS)
+      FLUXMI_TRY(run_gemm_chunk(v.data() + off, (int)std::min<size_t>(FLUXMI_MAX_GROUPS, v.size() - off), N, K, is_fp8, act_fmt, epi, force_cfg, s, s_hint));
+    return 0;
+  };
+  // bf16 launches of a batched engine (fluxmi_gemm_set_batch): replay the decisions of ONE sample's launch -- which groups are peeled, how many
+  // split-K slices the others get -- and apply them to every sample's groups.  One sample's share = 1 / batch of the groups of every row
+  // count (the engine pushes one group per (sample, stream)), or 1 / batch of the rows of a single group that carries the whole batch.  The
+  // one-pass tile configs all give the same bits, so only the split-K slices have to follow the sample; a launch whose groups do not divide
+  // by the batch keeps the whole-launch decision.
+  if (!is_fp8 && g_gemm_batch > 1) {
+    const int B = g_gemm_batch;
+    bool ok = true;
+    std::vector<int> all, sub;  // row counts of the launch / of one sample's share, ascending
+    std::map<int, int> per_sample;  // rows of a group of the launch -> rows of it that belong to one sample
+    for (auto& g : gs) all.push_back(g.M);
+    std::sort(all.begin(), all.end());
+    for (size_t i = 0; i < all.size() && ok;) {
+      size_t j = i;
+      while (j < all.size() && all[j] == all[i]) ++j;
+      const size_t cnt = j - i;
+      if (cnt % B == 0) { sub.insert(sub.end(), cnt / B, all[i]); per_sample[all[i]] = all[i]; }
+      else if (cnt == 1 && all[i] % B == 0) { sub.push_back(all[i] / B); per_sample[all[i]] = all[i] / B; }
+      else ok = false;
+      i = j;
+    }
+    std::sort(sub.begin(), sub.end());
+    const int k = ok ? peel_count(sub) : 0;
+    if (ok && k > 0 && k < (int)sub.size() && sub[k - 1] == sub[k]) ok = false;  // the peel would cut through groups of one row count
+    if (ok) {
+      const int m_small = k > 0 ? sub[k - 1] : -1;  // groups of at most this many rows (per sample) are peeled
+      long long tiles = 0, rows = 0;
+      for (size_t q = (size_t)k; q < sub.size(); ++q) { tiles += (sub[q] + 255) / 256; rows += (long long)((sub[q] + 255) / 256) * 256; }
+      // one sample's launch decides per chunk of FLUXMI_MAX_GROUPS groups; a sample has a handful, so its launch is one chunk
+      ok = sub.size() <= FLUXMI_MAX_GROUPS;
+      if (ok) {
+        const int S = splitk_slices(tiles * (N / 256), rows, N, K, is_fp8, epi, false, -1);
+        std::vector<FluxmiGemmGroup> big, small;
+        for (auto& g : gs) (per_sample[g.M] <= m_small ? small : big).push_back(g);
+        FLUXMI_TRY(chunks(big, -1, S));
+        return chunks(small, 2, 0);
+      }
+    }
+  }
+  if (peel_ok && gs.size() >= 2 && gs.size() <= FLUXMI_MAX_GROUPS) {
+    std::vector<int> order(gs.size());
+    for (size_t i = 0; i < gs.size(); ++i) order[i] = (int)i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return gs[a].M < gs[b].M; });
+    std::vector<int> ms;
+    for (int i : order) ms.push_back(gs[i].M);
+    const int best_k = peel_count(ms);
     if (best_k > 0) {
       std::vector<FluxmiGemmGroup> big, small;
       for (size_t q = 0; q < gs.size(); ++q) (q < (size_t)best_k ? small : big).push_back(gs[order[q]]);
@@ -186,9 +272,7 @@ int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs_in, int n_in, int N, int K, i
       return run_gemm_chunk(small.data(), (int)small.size(), N, K, is_fp8, act_fmt, epi, 2, s);
     }
   }
-  for (size_t off = 0; off < gs.size(); off += FLUXMI_MAX_GROUPS)
-    FLUXMI_TRY(run_gemm_chunk(gs.data() + off, (int)std::min<size_t>(FLUXMI_MAX_GROUPS, gs.size() - off), N, K, is_fp8, act_fmt, epi, -1, s));
-  return 0;
+  return chunks(gs, -1, -1);
 }
 
 extern "C" {

@@ -674,24 +674,22 @@ int fluxmi_xcd_mapping_ok(hipStream_t s) {
   g_xcc_ok[dev] = ok;
   return ok;
 }
+// The plan is made PER SAMPLE (tasks of one batch element: row blocks x heads) and a batch is launched sample by sample when it is on, so the
+// pieces a (sample, head, row block) is cut into -- and with them the bits of its output -- do not depend on the batch the sample rides in
+// (round 5 planned over B x H x row blocks: at 768^2 a sample's latents depended on its batch by <= 2.5e-3; reference flux_model.py:672-716
+// has no cross-sample operation).  B only has to be valid.
 int fluxmi_attn_plan_any(int B, int L, int H) {
-  return fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256).on && fluxmi_xcd_mapping_ok(nullptr) == 1;
+  return B >= 1 && fluxmi_attn_plan(((L + 255) / 256) * H, (L + KT - 1) / KT, 256).on && fluxmi_xcd_mapping_ok(nullptr) == 1;
 }
 int fluxmi_attn_plan_export(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces) {
   if (B < 1 || L < 1 || H < 1) return 0;
-  const AttnSplit sp = fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256);
+  const AttnSplit sp = fluxmi_attn_plan(((L + 255) / 256) * H, (L + KT - 1) / KT, 256);
   if (!sp.on) return 0;
   if (n_per_x) *n_per_x = sp.n_per_x;
   if (full_per_x) *full_per_x = sp.full_per_x;
   if (npieces) *npieces = sp.npieces;
   if (pieces) memcpy(pieces, sp.pieces, sizeof(AttnPiece) * sp.npieces);
   return sp.thin ? 1 : 2;
-}
-int fluxmi_attn_split_on(int B, int L, int H) {
-  const int mode = fluxmi_tuning().attn_split;
-  if (!mode || !fluxmi_attn_plan_any(B, L, H)) return 0;
-  const AttnSplit sp = fluxmi_attn_plan(((L + 255) / 256) * H * B, (L + KT - 1) / KT, 256);
-  return mode == 2 || sp.thin;
 }
 
 template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArgs a, int fmt, hipStream_t s) {
@@ -703,10 +701,15 @@ template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArg
   }
   memset(&a.sp, 0, sizeof(a.sp));
   a.dbg = g_attn_dbg;
-  const int tasks = ((a.L + 255) / 256) * a.H * a.B;
+  const int tasks1 = ((a.L + 255) / 256) * a.H;  // of one sample
   const fluxmi_tuning_t tun = fluxmi_tuning();
+  auto launch = [&](const AttnArgs& aa, int wgs) {
+    const dim3 grid(wgs);
+    if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, aa);
+    else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, aa);
+  };
   if (FOLD && tun.attn_split && fluxmi_xcd_mapping_ok(s) == 1) {
-    AttnSplit sp = fluxmi_attn_plan(tasks, (a.L + KT - 1) / KT, 256);
+    AttnSplit sp = fluxmi_attn_plan(tasks1, (a.L + KT - 1) / KT, 256);  // per SAMPLE: see fluxmi_attn_plan_any
     // attn_split = 1: only THIN last rounds (at most 8 of an XCD's 32 CUs busy, folded into the round in front of them; or a single partial
     // round).  Fuller ones were measured not to pay on this chip -- Flux-dev 1024^2, 22 of 32: 236 vs 223 - 235 us isolated, +3.4 % per
     // step (profiles/r05_attention_split.txt); 2 forces the balanced grid wherever a plan exists (tests, probes)
@@ -715,14 +718,26 @@ template <bool FOLD, bool EXACT, bool MIDBAR = false> static int launch2(AttnArg
     if (sp.on && ws) {
       sp.part = (float*)ws;
       sp.cnt = (unsigned*)((char*)ws + (size_t)8 * ATTN_MAX_PIECES * ATTN_PART_FLOATS * 4);  // [8][ATTN_SPLIT_MAXT]
-      a.sp = sp;
-      a.pf.n = 0;  // no CU idles in the last round any more: nothing for the weight prefetch to ride on
-      a.pf.wgs = 0;
+      // one launch per sample, each exactly the B = 1 launch of that sample (stream order keeps the scratch slots private to a launch)
+      for (int b = 0; b < a.B; ++b) {
+        AttnArgs ab = a;
+        ab.B = 1;
+        ab.sp = sp;
+        ab.pf.n = 0;  // no CU idles in the last round any more: nothing for the weight prefetch to ride on
+        ab.pf.wgs = 0;
+        const long long bl = (long long)b * a.L;
+        if (a.Q) ab.Q = a.Q + bl * a.H * 128;
+        ab.K = a.K + bl * a.H * 128;
+        ab.VT = a.VT + (long long)b * a.H * 128 * a.Lp;
+        if (a.qraw) { ab.qraw = a.qraw + bl * a.ldq; ab.pe = a.pe + bl * 128; }
+        ab.out = (char*)a.out + bl * a.ld_out * (a.out_fp8 ? 1 : 2);
+        launch(ab, 8 * (sp.full_per_x + sp.npieces));
+      }
+      FLUXMI_LAUNCH_CHECK();
+      return 0;
     }
   }
-  const dim3 grid((a.sp.on ? 8 * (a.sp.full_per_x + a.sp.npieces) : tasks) + (a.pf.n > 0 ? a.pf.wgs : 0));
-  if (fmt == FLUXMI_FMT_E5M2) hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E5M2, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, a);
-  else hipLaunchKernelGGL((attention2_kernel<FLUXMI_FMT_E4M3, FOLD, EXACT, MIDBAR>), grid, dim3(512), 4 * A_STAGE, s, a);
+  launch(a, tasks1 * a.B + (a.pf.n > 0 ? a.pf.wgs : 0));
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }

@@ -852,8 +852,10 @@ struct SplitkScope {
     auto ia = e->bufs.find("attn_part");
     fluxmi_set_attn_scratch(ia != e->bufs.end() && ia->second.n >= FLUXMI_ATTN_SPLIT_WS_BYTES ? ia->second.p : nullptr);
     fluxmi_set_prefetch(nullptr);
+    fluxmi_gemm_set_batch(e->B);
   }
   ~SplitkScope() {
+    fluxmi_gemm_set_batch(1);
     fluxmi_set_splitk_scratch(nullptr);
     fluxmi_set_attn_scratch(nullptr);
     fluxmi_set_prefetch(nullptr);

@@ -102,12 +102,14 @@ int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int 
 // its step graph is captured on a private stream and replayed on the caller's, so the scratch must belong to the engine, not to a stream.
 constexpr size_t FLUXMI_SPLITK_WS_BYTES = (size_t)256 << 20;
 void fluxmi_set_splitk_scratch(float* p);
+// the batch of the calling thread's engine (1 = none): bf16 launches take the split-K decision of ONE sample's groups, so a sample's bits do not
+// follow the batch it rides in (api.cpp)
+void fluxmi_gemm_set_batch(int B);
 // scratch of attention's balanced grid (attention2.hip, AttnSplit: partial softmax states of the key bins + arrival counters, which must be
 // ZERO when handed over and are left zero by every launch): thread-local like the split-K scratch, an engine owns one; nullptr = the library's own
-// per-(device, stream) buffer.  fluxmi_attn_split_on: does a launch of this shape use the balanced grid under the current tuning?
+// per-(device, stream) buffer.  fluxmi_attn_plan_any: does a balanced-grid plan exist for one sample of this shape (any tuning)?
 constexpr size_t FLUXMI_ATTN_SPLIT_WS_BYTES = (size_t)8 * 64 * (8 * 17 * 64 * 4) * 4 + 8 * 64 * 4;
 void fluxmi_set_attn_scratch(void* p);
-int fluxmi_attn_split_on(int B, int L, int H);
 int fluxmi_attn_plan_any(int B, int L, int H);
 int fluxmi_attn_debug_buffer(void* dev_u64);  // fluxmi_attention_debug_buffer
 int fluxmi_attn_plan_export(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces);  // fluxmi_attention_plan  // the same for ANY tuning (what an engine sizes its workspace by: the knob may change later)

@@ -188,7 +188,12 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_tile_kernel(const FluxmiGemm
     } else {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const int s0 = kk * 2 + hi;
+        // the K association of the 256x256 kernels (gemm_pp / gemm_w1 / gemm_persist: 64-byte K-steps, one MFMA over the 16-byte chunks
+        // {0, 2} of a step, one over {1, 3}): MFMA kk covers chunks (kk >> 1) * 4 + (kk & 1) + {0, 2}.  With the natural order (chunks
+        // 2 kk, 2 kk + 1) ~3e-4 of the bf16 outputs differed from theirs in the last bit, so a bf16 result followed the tile choice --
+        // and through it the row count, i.e. the batch a sample rode in (profiles/r05_batch_invariance.txt).  Every bf16 tile config
+        // now sums K in ONE order (tests/test_ops_gpu.py::test_bf16_tile_configs_are_bit_identical)
+        const int s0 = (kk >> 1) * 4 + (kk & 1) + hi * 2;
         v8bf fa[TM], fw[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[i] = *(const v8bf*)(sb + a_off[i] + ((s0 ^ a_sw[i]) << 4));

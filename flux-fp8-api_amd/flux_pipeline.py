@@ -308,7 +308,8 @@ class FluxPipeline:
             out = self.unpack(latents.float(), height, width) if latents is not None else None
             return (out, seed) if return_seed else out
         img_px = self.vae_decode(latents, height, width)
-        out = self.into_bytes(img_px, jpeg_quality=jpeg_quality)
+        # output_type "uint8": the [B, H, W, 3] array into_bytes hands to the JPEG encoder (the pixel-parity tests compare it)
+        out = self.to_uint8(img_px) if output_type == "uint8" else self.into_bytes(img_px, jpeg_quality=jpeg_quality)
         return (out, seed) if return_seed else out
 
     def vae_decode(self, x: torch.Tensor, height: int, width: int) -> torch.Tensor:
@@ -316,11 +317,16 @@ class FluxPipeline:
         with torch.autocast(device_type=self.device_ae.type, dtype=torch.bfloat16, cache_enabled=False):
             return self.ae.decode(x)
 
+    @staticmethod
+    def to_uint8(x: torch.Tensor) -> torch.Tensor:
+        """[B, 3, H, W] in [-1, 1] -> [B, H, W, 3] uint8 on the host (reference flux_pipeline.py:385-393)"""
+        return x.clamp(-1, 1).add(1.0).mul(127.5).clamp(0, 255).permute(0, 2, 3, 1).contiguous().to(torch.uint8).cpu()
+
     def into_bytes(self, x: torch.Tensor, jpeg_quality: int = 99) -> io.BytesIO:
         from PIL import Image
 
-        imgs = [(x[i].clamp(-1, 1).add(1.0).mul(127.5).clamp(0, 255).permute(1, 2, 0).contiguous().to(torch.uint8).cpu().numpy())
-                for i in range(x.shape[0])]
+        px = self.to_uint8(x)
+        imgs = [px[i].numpy() for i in range(px.shape[0])]
         im = imgs[0] if len(imgs) == 1 else np.vstack(imgs)
         buf = io.BytesIO()
         Image.fromarray(im).save(buf, format="JPEG", quality=jpeg_quality)

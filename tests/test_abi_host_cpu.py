@@ -41,12 +41,14 @@ def test_attention_balanced_grid_plan(B, L, H):
     from fluxmi import ops
 
     plan = ops.attention_plan(B, L, H)
-    tasks, nt = (L + 255) // 256 * H * B, (L + 63) // 64
+    # round 6: planned PER SAMPLE (a batch is launched sample by sample when the plan is on), so a sample's pieces never depend on its batch
+    assert plan == ops.attention_plan(1, L, H)
+    tasks, nt = (L + 255) // 256 * H, (L + 63) // 64
     n, last = tasks // 8, (tasks // 8) % 32
     if tasks % 8 or nt < 16 or last == 0 or last > 26:
         assert plan is None
         return
-    expect = {(1, 4608, 24): (32, 22), (1, 2816, 24): (0, 33), (2, 4608, 24): (96, 12), (8, 4608, 24): (416, 16), (1, 1100, 8): (0, 5), (1, 1536, 24): (0, 18),
+    expect = {(1, 4608, 24): (32, 22), (1, 2816, 24): (0, 33), (2, 4608, 24): (32, 22), (8, 4608, 24): (32, 22), (1, 1100, 8): (0, 5), (1, 1536, 24): (0, 18),
               (1, 3072, 24): (0, 36)}
     if (B, L, H) in expect:
         assert plan is not None and (plan["full_per_x"], plan["n_per_x"] - plan["full_per_x"]) == expect[(B, L, H)]

@@ -946,3 +946,52 @@ def test_maximum_batch_at_real_width(dev):
             alone = model.denoise(*one(i), ts, guidance=3.5)
             assert torch.equal(alone[0].view(torch.int16), whole[i].view(torch.int16)), f"sample {i} of the 32-batch differs from the same sample alone"
         del model
+
+
+@pytest.mark.parametrize("flow", ["fp8_768", "bf16_schnell_256"])
+def test_a_sample_does_not_depend_on_its_batch(flow, dev):
+    """Round 6 (VERDICT r05 weak #5 / ADVICE): samples never interact in the reference (flux_model.py:672-716), so sample i of a batch of 2 or 4
+    must come out with exactly the bits it has alone, at the two shapes where round 5 could not promise it:
+      fp8_768          Flux-dev width, 768x768 + 512 text tokens (L = 2816): the balanced attention grid of the thin last round was planned
+                       over the whole launch, so the key pieces of a (head, row block) followed B (<= 2.5e-3); now planned per sample
+      bf16_schnell_256 the bf16 FLOW (no F8Linear; BASELINE configs[0]: schnell 256x256 + 256 text tokens, M = 512 rows per sample): the
+                       dispatcher's tile / split-K choice followed the row count; now every bf16 tile config gives the same bits and the
+                       split-K slices are decided on one sample's groups (csrc/api.cpp, fluxmi_gemm_set_batch)
+    1 + 1 blocks at hidden 3072, frozen scales, a 2-step hipGraph loop."""
+    import util
+    from float8_quantize import quantize_flow_transformer_and_dispatch_float8
+    from fluxmi import synth
+
+    fp8 = flow == "fp8_768"
+    cfg = util.load_config(util.ModelVersion.flux_dev if fp8 else util.ModelVersion.flux_schnell, flow_dtype="bfloat16", quantize_modulation=True,
+                           quantize_flow_embedder_layers=False)
+    p = cfg.params
+    p.depth, p.depth_single_blocks = 1, 1
+    side, lt = (768, 512) if fp8 else (256, 256)
+    with torch.inference_mode():
+        model = util.load_flow_model(cfg, synth.make_state_dict(p, seed=4, device=dev)).to(dev)
+        if fp8:
+            quantize_flow_transformer_and_dispatch_float8(model, dev, flow_dtype=torch.bfloat16, swap_linears_with_cublaslinear=False,
+                                                          quantize_modulation=True, quantize_flow_embedder_layers=False)
+        else:
+            model.eval().requires_grad_(False)
+            assert len(model.f8_modules()) == 0
+        inp = to_dev(synth.make_inputs(p, side, side, lt, batch=4, seed=41), dev)
+        keys = ("img", "img_ids", "txt", "txt_ids", "y")
+        Li = inp["img"].shape[1]
+        sl = lambda a, b: tuple(inp[k][a:b].contiguous() for k in keys)
+        g = 3.5  # schnell has no guidance embedder: ignored there
+        shift = fp8  # schnell: no time shift
+        if fp8:
+            model.denoise(*sl(0, 1), fo.get_schedule(13, Li), guidance=g)  # calibration on sample 0
+            assert model.calibration_state()[0]
+        ts = fo.get_schedule(2, Li, shift=shift)
+        alone = [model.denoise(*sl(i, i + 1), ts, guidance=g)[0].clone() for i in range(4)]
+        for B in (2, 4):
+            whole = model.denoise(*sl(0, B), ts, guidance=g)
+            torch.cuda.synchronize()
+            assert whole.shape[0] == B and torch.isfinite(whole.float()).all()
+            for i in range(B):
+                same = torch.equal(alone[i].view(torch.int16), whole[i].view(torch.int16))
+                assert same, f"{flow}: sample {i} of a batch of {B} differs from the same sample alone (rel-L2 {rel_l2(whole[i], alone[i]):.3e})"
+        del model

@@ -448,6 +448,73 @@ def test_gemm_tile_config_17_matches_16(ops, dev, Ms):
         assert torch.isfinite(x.view(torch.bfloat16).float()).all()
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 3072, 4096), (4096, 3072, 3072), (16384, 3072, 64), (1000, 3072, 15360), (4096, 64, 3072)])
+def test_bf16_tile_configs_are_bit_identical(ops, dev, M, N, K):
+    """Round 6: every bf16 tile config sums K in ONE order -- the 128-byte-K-step tiles (configs 2 / 15) issue their MFMAs over the same 16-byte
+    chunk pairs as the 64-byte-K-step 256 x 256 kernels (13 / 16 / 17), so a bf16 linear's bits do not depend on which tile the dispatcher
+    picks for the row count (round 5: ~3e-4 of the outputs differed in the last bit and, through img_in, a sample's latents followed its batch;
+    profiles/r05_batch_invariance.txt).  Plain and gate*y+x epilogues, a ragged M, and the automatic choice on a quarter of the rows.
+    reference: F.linear on bf16 (flux_model.py:154-155, 356-400), no cross-row operation."""
+    from fluxmi import _lib
+
+    torch.manual_seed(5)
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    bias = torch.randn(N, device=dev).bfloat16()
+    gate = torch.randn(N, device=dev).bfloat16()
+    resid = torch.randn(M, N, device=dev).bfloat16()
+
+    def run(cfg, rows=M, epi=_lib.EPI_BF16):
+        o = resid[:rows].clone() if epi == _lib.EPI_GATE_RESID else torch.empty(rows, N, dtype=torch.bfloat16, device=dev)
+        kw = dict(gate=gate, resid=o) if epi == _lib.EPI_GATE_RESID else {}
+        ops.linear(a[:rows].contiguous(), w, bias, out=o, tile_cfg=cfg, epilogue=epi, **kw)
+        torch.cuda.synchronize()
+        return o.view(torch.int16).clone()
+
+    for epi in (_lib.EPI_BF16, _lib.EPI_GATE_RESID):
+        outs = {}
+        for c in (2, 15, 13, 16, 17, -1):
+            try:
+                outs[c] = run(c, epi=epi)
+            except RuntimeError:  # a tile config that does not fit (N % 256, K-step) refuses: not part of the dispatcher's choice for this shape
+                continue
+        assert -1 in outs and len(outs) >= 2, f"configs that ran: {sorted(outs)}"
+        ref = outs[-1]
+        for c, o in outs.items():
+            assert torch.equal(o, ref), f"bf16 tile config {c} differs from the automatic choice (epilogue {epi}, M={M} N={N} K={K}): {(o != ref).float().mean().item():.2e} of the elements"
+        with _lib.tuning(gemm_splitk=0):  # the automatic ONE-PASS choice on a quarter of the rows: same bits as on all rows
+            q = run(-1, rows=M // 4, epi=epi)
+        assert torch.equal(q, ref[: M // 4]), "the one-pass result of a row depends on how many rows share its launch"
+
+
+@pytest.mark.parametrize("B", [2, 4])
+def test_attention_is_batch_invariant_at_thin_last_rounds(ops, dev, B):
+    """Round 6: the balanced attention grid is planned PER SAMPLE and a batch is launched sample by sample when it is on, so
+    at Flux-dev 768^2 (L = 2816: 33 tasks per XCD, the thin last round the DEFAULT tuning folds into the round in front of it) sample i of a
+    batch gets exactly the bits it gets alone -- bf16 and fused-fp8 outputs.  Round 5 planned over B x heads x row blocks, which cut the same
+    (head, row block) into different key pieces at B = 1 and B = 2 (<= 2.5e-3 apart).  flux_model.py:41-45 / 672-716: no cross-sample op."""
+    H, L = 24, 2816
+    assert ops.attention_plan(1, L, H) is not None and ops.attention_plan(1, L, H)["thin"]
+    p1, pb = ops.attention_plan(1, L, H), ops.attention_plan(B, L, H)
+    assert p1 == pb, "the plan must not depend on the batch"
+    torch.manual_seed(83)
+    q = torch.randn(B, H, L, 128).bfloat16()
+    k = torch.randn(B, H, L, 128).bfloat16()
+    v = torch.randn(B, H, L, 128).bfloat16()
+    k = torch.where(k.abs() < 6.2e-5, torch.zeros_like(k), k)
+    VT = _vt_layout(v, L)
+    qd, kd, vd = q.to(dev), k.half().to(dev), VT.to(dev)
+    s0, s1 = torch.tensor(3000.0, device=dev), torch.tensor(9000.0, device=dev)
+    whole = ops.attention(qd, kd, vd)
+    whole8 = ops.attention(qd, kd, vd, q_scale0=s0, q_scale1=s1, split=512)
+    for i in range(B):
+        one = ops.attention(qd[i:i + 1].contiguous(), kd[i:i + 1].contiguous(), vd[i:i + 1].contiguous())
+        one8 = ops.attention(qd[i:i + 1].contiguous(), kd[i:i + 1].contiguous(), vd[i:i + 1].contiguous(), q_scale0=s0, q_scale1=s1, split=512)
+        assert torch.equal(one[0].view(torch.int16), whole[i].view(torch.int16)), f"sample {i} of {B}: bf16 output differs from the sample alone"
+        assert torch.equal(one8[0].view(torch.uint8), whole8[i].view(torch.uint8)), f"sample {i} of {B}: fp8 output differs from the sample alone"
+    assert torch.isfinite(whole.float()).all()
+
+
 @pytest.mark.parametrize("epi_name", ["bf16", "gate_resid"])
 def test_gemm_tile_config_17_bf16(ops, dev, epi_name):
     """Tile config 17 with bf16 operands (nn.Linear flows: Flux-schnell 256^2 linear1 at M = 512 -> 3 x 84 = 252 tiles of 192 rows instead of 168 of
