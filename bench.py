@@ -850,8 +850,14 @@ def main():
     ap.add_argument("--single-rank-group", action="store_true",
                     help="N = 1 only: create a one-rank process group anyway and run every collective of the N > 1 path through it (broadcast, "
                          "in-step amax all-reduce from the engine's hook, barriers): exercises the RCCL plumbing on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true",
+                    help="N > 1 on a ONE-GPU box (with --backend gloo): every rank builds its real engine on cuda:0 and the whole N-rank timed path runs -- "
+                         "request broadcast, in-step amax exchange from the engine's hook, barriers, max-over-ranks timing, one JSON line.  The ranks share "
+                         "the chip, so the line is flagged `share_device` and is NOT a scaling measurement")
     args = ap.parse_args()
     C = CONFIGS[args.config]
+    if args.share_device and (args.backend != "gloo" or args.gpus < 2):
+        raise SystemExit("--share-device needs --gpus N >= 2 and --backend gloo (RCCL refuses two ranks on one device)")
 
     if args.pmc_summarize:
         Li, Lt = (C["height"] // 16) * (C["width"] // 16), C["txt_len"]
@@ -893,6 +899,8 @@ def main():
         dev = torch.device("cpu")
         sync = lambda: None
     else:
+        if args.share_device:
+            local = 0
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         sync = torch.cuda.synchronize
@@ -1086,6 +1094,9 @@ def main():
                 "data": "synthetic seeded request + random-init Flux weights (no checkpoint available offline)",
                 "config": cfg_block,
             }
+            if args.share_device:
+                result.update({"share_device": True, "data": result["data"] + f"; {world} ranks with real engines SHARING cuda:0 (plumbing run of the "
+                               "N-rank timed path on a one-GPU box: the value is not a scaling measurement)"})
             if dry:
                 result.update({"dry_run": True, "data": "DRY RUN on a stub engine (CPU tensors): control flow only, not a measurement",
                                "amax_exchanges": model.exchanges})

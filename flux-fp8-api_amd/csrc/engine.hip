@@ -74,6 +74,7 @@ struct fluxmi_engine {
   size_t pairs_bytes = 0;
   std::vector<long long> pairs_off;
   bool pairs_dirty = true;
+  bool pairs_skipped = false;      // the copies were wanted and did not fit (ensure_pairs): retried at the next prepare
   unsigned pairs_gen = 0;          // fluxmi_tuning_generation() the copies were built under (fluxmi_tuning_t.w_pairs may have changed)
   int* d_step0 = nullptr;          // first step of the modulation table (device scalar: the captured graph reads it)
   int mods_rows_cap = 0;           // rows (steps x B) the table holds; sized in engine_prepare, never inside denoise
@@ -189,12 +190,19 @@ int ensure_pairs(E* e, hipStream_t s) {
     size_t free_b = 0, total_b = 0;
     const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= 2 * total + ((size_t)4 << 30);
     if (!room || hipMalloc((void**)&e->pairs, total) != hipSuccess) {
-      // no room for the copies: run without them
+      // no room for the copies: run without them (same results, ~3 % slower steps) -- said once per engine, and tried again at the next
+      // fluxmi_engine_prepare (the caller's allocator may have given memory back by then); hipMemGetInfo does not see what the torch
+      // allocator holds cached, so this depends on the allocator's state at the first launch
       (void)hipGetLastError();
+      if (!e->pairs_skipped)
+        fprintf(stderr, "fluxmi: row-pair weight copies skipped (%.1f GB wanted, %.1f GB free of %.1f): the GEMMs read the plain weights\n",
+                total / 1e9, free_b / 1e9, total_b / 1e9);
+      e->pairs_skipped = true;
       e->pairs_off.assign(n, -1);
       e->pairs_dirty = false;
       return 0;
     }
+    e->pairs_skipped = false;
     e->pairs_bytes = total;
   }
   for (int li = 0; li < n; ++li)
@@ -224,8 +232,9 @@ int run_gemm(std::vector<FluxmiGemmGroup>& gs, int N, int K, int is_fp8, int act
 // count -- through img_in a sample's latents depended on the batch it rode in from B = 4 on (B x 4096 rows: config 13 instead of 2;
 // tests/test_engine_gpu.py::test_maximum_batch_at_real_width).  Config 2 (128x128 tiles; 15 = its 128x64 form) is the choice at B = 1 for all
 // three and costs nothing at larger B (K = 64 / one launch per request / N = 64: output-bound launches of tens of microseconds).
-// The bf16 FLOW (no fp8 anywhere) keeps the per-shape choice incl. split-K: its results follow the batch size at rounding level, like the
-// reference's cuBLAS heuristics.
+// Round 6: every bf16 tile config sums K in one order now (gemm.hip) and the split-K slices follow ONE sample's groups (api.cpp,
+// fluxmi_gemm_set_batch), so the bf16 FLOW is batch-invariant as well; the pin stays (it is the B = 1 choice and keeps these three launches
+// off the split-K path whatever the tuning says).
 int run_gemm_fixed_cfg(std::vector<FluxmiGemmGroup>& gs, int N, int K, int is_fp8, int act_fmt, int epi, hipStream_t s) {
   const int cfg = fluxmi_gemm_tile_ok(N, K, 0, 2) ? 2 : (fluxmi_gemm_tile_ok(N, K, 0, 15) ? 15 : -1);
   if (is_fp8 || cfg < 0 || fluxmi_tuning().gemm_cfg >= 0) return run_gemm(gs, N, K, is_fp8, act_fmt, epi, s);
@@ -1004,6 +1013,7 @@ int fluxmi_engine_prepare(fluxmi_engine_t* e, int B, int Li, int Lt, const void*
                  Lt, FLUXMI_ENGINE_MAX_BATCH);
   FLUXMI_REQUIRE(img_ids && (Lt == 0 || txt_ids), "engine_prepare: NULL ids");
   const int H = e->d.hidden, Hm = e->d.mlp_hidden, L = Li + Lt, Lp = ((L + 63) / 64) * 64;
+  if (e->pairs_skipped) e->pairs_dirty = true;  // the row-pair copies did not fit last time: try again with this request
   if (B != e->B || Li != e->Li || Lt != e->Lt || !e->ws) {
     FLUXMI_CHECK_HIP(hipStreamSynchronize(s));
     free_ws(e);

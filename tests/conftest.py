@@ -46,7 +46,7 @@ def _full_geometry_case(item):
 
 # process-spawning tests: real engines in child processes joined by a process group.  They depend on the most machinery outside the
 # kernels (spawn, rendezvous ports, a second HIP context on the device), so they run LAST: under `-x` nothing they do can hide a kernel result.
-SPAWNING_TESTS = ("test_two_process_sharded_calibration_over_a_process_group", "test_bench_two_ranks_share_one_device")
+SPAWNING_TESTS = ("test_two_process_sharded_calibration_over_a_process_group",)
 _FILE_RANK = {"test_ops_gpu.py": 0, "test_text_gpu.py": 1, "test_engine_gpu.py": 2, "test_pixels_gpu.py": 3, "test_full_geometry_gpu.py": 4}
 
 
