@@ -563,8 +563,10 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
   const void* const* ns = &e->norm[i * 4];  // img q, img k, txt q, txt k
   // V^T leaves the qkv GEMM's epilogue directly in the attention kernel's layout when the 256x256 kernels apply
   // (short sequences -- Flux-schnell 256x256: 72 tiles -- leave V^T to the relayout kernel: the fused output exists only in the 256x256
-  // kernels, and a launch that small runs 1.7x faster on 128x128 tiles at two workgroups per CU, profiles/r03_small_m.txt)
-  const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H, H, e->lin[li_q[0]].kind, 13) && Lt % 16 == 0 && (long long)B * L >= 2048;
+  // kernels, and a launch that small runs 1.7x faster on 128x128 tiles at two workgroups per CU, profiles/r03_small_m.txt).  The threshold
+  // is on ONE sample's rows, not on B x L: the fused K of tile config 13 and the relayout kernel's K agree on 99.9 % of the elements, not on
+  // all, so a choice that followed the batch made a sample's bits follow it (round 6: schnell 256^2 at B = 4 crossed 2048 rows)
+  const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H, H, e->lin[li_q[0]].kind, 13) && Lt % 16 == 0 && L >= 2048;
   const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;  // a 256-column tile must not straddle the q|k|v boundaries
 
   for (int half = 0; half < 2; ++half) {
@@ -701,7 +703,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
   const void* const* ns = &e->norm[e->d.depth * 4 + i * 2];
   if (fused) {
     const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H + Hm, H, 1, 13);
-    const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0 && (long long)B * L >= 2048;  // short sequences: one launch of the relayout kernel is cheaper
+    const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0 && L >= 2048;  // short sequences: one launch of the relayout kernel is cheaper
     if (on(0))
       FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, ms, ms + H, ms, ms + H, MC, L1.in_scale, L1.in_scale, B, L, L, H, 1, L1.in_fmt, s));
     if (on(1)) {

@@ -82,8 +82,12 @@ typedef struct fluxmi_gemm_group {
   /* Optional 64 KiB table for the quantising epilogues (FLUXMI_EPI_GELU_QUANT and the mlp columns of FLUXMI_EPI_SPLIT, tile config
    * 13): q_lut[b] = the fp8 byte the epilogue would compute for the bf16 GEMM output with bit pattern b -- bf16 -> GELU -> bf16 ->
    * x input_scale -> bf16 -> clamp -> fp8 is a pure function of those 16 bits once the scale is frozen.  Built by
-   * fluxmi_build_quant_lut with the same device code, so results are bit-identical; it replaces ~25 VALU instructions per element
-   * by one LDS gather while the matrix pipe is idle.  NULL = compute.        flux_model.py:301,480 + float8_quantize.py:217-218,274-276 */
+   * fluxmi_build_quant_lut from the same helpers; measured over all 65536 inputs (profiles/r06_qlut_vs_computed.txt) the table equals the
+   * oracle's torch chain on every finite input outside a 4-pattern fp32-tanh cliff, and the epilogue the kernels COMPUTE when no table is
+   * given differs from the table on ONE pattern (hipcc contracts the GELU polynomial differently per kernel) -- the table is the default
+   * and the more faithful of the two; latents of a qlut = 0 run drift from the default's like two fp8 runs do.  It replaces ~25 VALU
+   * instructions per element by one LDS gather while the matrix pipe is idle.  NULL = compute (tile configs 2, 13, 16; the persistent
+   * config 18 has no computed quantising epilogue).                       flux_model.py:301,480 + float8_quantize.py:217-218,274-276 */
   const void* q_lut;
   /* Optional copy of W in the ROW-PAIR layout [N/2][K_bytes/64][2][64] (fluxmi_pair_rows): the 64-byte K-steps of rows 2r and 2r+1 share one
    * 128-byte line.  The tiled kernels fetch an operand one 64-byte K-step at a time, i.e. HALF an L2 line per row and step -- each line crosses the
@@ -148,8 +152,9 @@ int fluxmi_clock_sample(void* out24_dev_u64, void* stream);
 /* Grouped linear.  is_fp8=1: A is `act_fmt` fp8, W is e4m3fn (torch._scaled_mm, float8_quantize.py:284-292);
  * is_fp8=0: A, W bf16 (F.linear).  tile_cfg: -1 auto (cost model + split of a thin last round, what the engine uses);
  * 13 = 256x256 ping-pong LDS ring (K*bytes % 64 == 0); 16 = 256x256 with one wave per SIMD (K*bytes % 256 == 0), 17 = the same kernel on 192x256 tiles
- * (fp8 x e5m2, gate*y+x epilogue only: launches with a thin single round of 256-row tiles); 2 = 128x128 and 15 = 128x64
- * double-buffered tiles (K*bytes % 128 == 0); 100 = generic any-shape kernel.  Every one of these computes the same bits.  (Other numbers
+ * (fp8 x e5m2 or bf16 operands, plain bf16 or gate*y+x epilogue: launches with a thin single round of 256-row tiles); 2 = 128x128 and 15 = 128x64
+ * double-buffered tiles (K*bytes % 128 == 0); 100 = generic any-shape kernel (scalar fma: <= 1 bf16 ulp of the others on bf16 operands).  The
+ * tiled configs compute the same bits for fp8 AND, since round 6, for bf16 operands (one K association: test_bf16_tile_configs_are_bit_identical).  (Other numbers
  * named kernel generations that were removed: they are rejected.)  18 = config 13 as a PERSISTENT kernel (one workgroup per CU walks the tiles;
  * fp8 x e5m2, N % 256 == 0, K % 256 == 0, K >= 512; the auto dispatch takes it for launches of more than 256 tiles), 19 = its timing build.
  * 113 + S (S = 2..32, S <= K-steps): config 13 with SPLIT-K -- S workgroups per tile, each over its own K range, fp32 partial tiles in a 256 MiB
@@ -158,9 +163,11 @@ int fluxmi_clock_sample(void* out24_dev_u64, void* stream);
  * under stream capture is refused -- so launches on different streams never share partial tiles; a fluxmi_engine owns one of its own (its step
  * graph is captured on a private stream).  The auto dispatch uses split-K for bf16 launches of <= 128 tiles with >= 192 K-steps (M <= 512:
  * Flux-schnell at 256x256, the text encoders): deterministic, <= 1 bf16 ulp of fp64 like the others, but not bit-identical to the unsplit
- * kernels (the fp32 sum is associated differently) -- i.e. the bits of a bf16 auto-dispatched GEMM depend on how many rows share the launch.
- * Callers that need batch-invariant bits launch a fixed number of rows (the native text encoders run one prompt per launch; the engine's
- * modulation-table GEMM blocks the choice) or set fluxmi_tuning_t.gemm_splitk = 0. */
+ * kernels (the fp32 sum is associated differently) -- i.e. the bits of a bf16 auto-dispatched GEMM called through THIS entry depend on how many
+ * rows share the launch.  A fluxmi_engine announces its batch to the dispatcher, which then takes the slice count of ONE sample's groups, so a
+ * sample's bits do not follow the batch it rides in (round 6; test_a_sample_does_not_depend_on_its_batch).  Other callers that need
+ * batch-invariant bits launch a fixed number of rows (the native text encoders run one prompt per launch; the engine's modulation-table GEMM
+ * blocks the choice) or set fluxmi_tuning_t.gemm_splitk = 0. */
 int fluxmi_gemm_grouped(const fluxmi_gemm_group_t* groups, int n_groups, int N, int K, int is_fp8, int act_fmt,
                         int epilogue, int tile_cfg, void* stream);
 /* single-problem convenience form of the above (F8Linear.forward after quantisation) */
@@ -228,7 +235,9 @@ int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, lo
                      const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, int k_f16,
                      void* stream);
 
-/* The launch plan of the kernel above for B x H heads of L keys on a 256-CU part (host arithmetic only, no GPU needed; tests + bench notes).
+/* The launch plan of the kernel above for ONE SAMPLE's H heads of L keys on a 256-CU part (host arithmetic only, no GPU needed; tests + bench
+ * notes).  Since round 6 the plan is per sample and a batch is launched sample by sample when it is on: B only has to be >= 1 and the pieces a
+ * (head, row block) is cut into -- hence its bits -- do not depend on the batch (test_attention_is_batch_invariant_at_thin_last_rounds).
  * The kernel runs one workgroup of 256 query rows per (head, row block) -- a TASK -- and one workgroup per CU at a time, so 264 tasks take two
  * rounds for 1.03 rounds of work.  Under fluxmi_tuning_t.attn_split (fp16-K calls only) every XCD runs full_per_x of its n_per_x tasks whole
  * and the remaining ones as `npieces` PIECES of their key range, launched longest first, so that every CU ends up with the same number of key

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 import flux_oracle as fo
-from parity_util import assert_bf16_close, assert_close_mag, assert_f8_close, round_fp64_to_bf16, ulp_diff
+from parity_util import assert_bf16_close, assert_close_mag, assert_f8_close, f8_ulp_diff, round_fp64_to_bf16, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -475,7 +475,8 @@ def test_bf16_tile_configs_are_bit_identical(ops, dev, M, N, K):
         outs = {}
         for c in (2, 15, 13, 16, 17, -1):
             try:
-                outs[c] = run(c, epi=epi)
+                with _lib.tuning(gemm_splitk=0):  # -1: the automatic ONE-PASS choice (split-K associates K differently by design; its slices
+                    outs[c] = run(c, epi=epi)     # follow one sample's groups: tests/test_engine_gpu.py::test_a_sample_does_not_depend_on_its_batch)
             except RuntimeError:  # a tile config that does not fit (N % 256, K-step) refuses: not part of the dispatcher's choice for this shape
                 continue
         assert -1 in outs and len(outs) >= 2, f"configs that ran: {sorted(outs)}"
@@ -586,11 +587,15 @@ def test_gemm_persistent_quantising_paths_exhaustive(ops, dev):
 def test_quantising_epilogue_computed_vs_table_exhaustive(ops, dev):
     """is the 64 KiB table (fluxmi_gemm_group_t.q_lut, built by build_qlut_kernel) bit-identical to the epilogue the
     kernels COMPUTE when no table is given?  Exhaustive over all 65536 bf16 inputs (A = 0, bias = every pattern) for every kernel that has a
-    computed GELU + quantise epilogue (tile configs 2, 13, 16, 18), at three scales; both are also compared with the oracle's torch chain
-    (F.gelu(tanh) -> bf16 -> x scale -> bf16 -> clamp -> e5m2: flux_model.py:301, float8_quantize.py:217-218,274-276).  The numbers are
-    printed; the gates: every computed epilogue and the table agree with the oracle on >= 99.9 % of the non-NaN patterns within 1 fp8 ulp,
-    and the table agrees with the oracle at least as often as any computed epilogue does (so the default, table-driven path is never the
-    less faithful one)."""
+    computed GELU + quantise epilogue (tile configs 2, 13, 16; the persistent kernel takes the table or refuses), at three scales; both are
+    compared with the oracle's torch chain (F.gelu(tanh) -> bf16 -> x scale -> bf16 -> clamp -> e5m2: flux_model.py:301,
+    float8_quantize.py:217-218,274-276).  MEASURED (profiles/r06_qlut_vs_computed.txt): the table equals the oracle on every finite pattern
+    but the cliff below; the computed epilogues equal the table on all but ONE of 65536 patterns (hipcc contracts the GELU polynomial into
+    different fma's inside the GEMM kernels than inside build_qlut_kernel) -- "same helpers, so bit-identical" was off by that one pattern;
+    the table is the more faithful path and it is the default.  The cliff: for -5.16 <= h <= -5.06, 1 + tanh(u) is 0 or 2^-24 in fp32
+    depending on the tanh implementation (torch CPU: 0 -> gelu = -0; the device: 2^-24 -> -1.5e-7); at scale 9000 that is fp8 byte 0x96
+    against 0x80.  Gates: >= 99.9 % of the finite patterns exact and nothing beyond 1 fp8 ulp outside the cliff, for the table and for every
+    computed epilogue; computed == table on >= 99.99 %; the table agrees with the oracle at least as often as any computed epilogue."""
     from fluxmi import _lib
 
     M, N, K = 512, 65536, 512
@@ -599,28 +604,40 @@ def test_quantising_epilogue_computed_vs_table_exhaustive(ops, dev):
     bias = torch.arange(N, dtype=torch.int32, device=dev).to(torch.int16).view(torch.bfloat16)
     one = torch.tensor(1.0, device=dev)
     bits = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
-    ok_in = ~torch.isnan(bits.float())
+    ok_in = torch.isfinite(bits.float())  # +-inf / NaN inputs: F.gelu(-inf) is NaN in torch and -0 here; no finite model produces them
+    cliff = (bits.float() >= -5.2) & (bits.float() <= -5.0)
+
+    def check(x, what):
+        dd = f8_ulp_diff(x.view(torch.float8_e5m2), ref.view(torch.float8_e5m2))
+        far = torch.nonzero((dd > 1) & ok_in & ~cliff).flatten()
+        assert len(far) == 0, f"{what}: beyond 1 fp8 ulp outside the tanh cliff: " + ", ".join(
+            f"h={bits[i].item():.6g} got 0x{int(x[i]):02x} oracle 0x{int(ref[i]):02x}" for i in far[:8])
+        exact = (x[ok_in] == ref[ok_in]).float().mean().item()
+        assert exact >= 0.999, f"{what}: exact on {exact:.6f} of the finite patterns"
+        return exact, int(((dd > 1) & ok_in & cliff).sum())
+
     for scale in (1.0, 37.5, 9000.0):
         qs = torch.tensor(scale, device=dev)
         lut = ops.build_quant_lut(qs, E5M2, act=1).cpu()
         ref = fo.to_fp8_saturated(F.gelu(bits, approximate="tanh"), torch.tensor(scale), 57344.0).to(torch.float8_e5m2).view(torch.uint8)
-        agree = lambda x: (x[ok_in] == ref[ok_in]).float().mean().item()
-        line = [f"scale {scale}: table == oracle on {agree(lut):.6f}"]
-        worst_computed = 1.0
-        for cfg in (2, 13, 16, 18):
+        e_t, c_t = check(lut, "table")
+        line = [f"scale {scale}: table == oracle on {e_t:.6f} of the finite patterns ({c_t} cliff patterns beyond 1 ulp)"]
+        worst = 1.0
+        for cfg in (2, 13, 16):
             out = torch.full((M, N), 0x55, dtype=torch.uint8, device=dev)
             g8 = ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), one.data_ptr(), one.data_ptr(), out.data_ptr(), M, K, N, q_scale=qs.data_ptr())
             ops.gemm_grouped([g8], N, K, True, E5M2, _lib.EPI_GELU_QUANT, cfg)
             rows = out.cpu()
             assert (rows == rows[0:1]).all(), f"cfg {cfg}: rows of one column differ"
             got = rows[0]
+            e_c, c_c = check(got, f"computed epilogue of tile config {cfg}")
             same_t = (got[ok_in] == lut[ok_in]).float().mean().item()
-            line.append(f"cfg {cfg}: computed == table {same_t:.6f}, == oracle {agree(got):.6f}")
-            worst_computed = min(worst_computed, agree(got))
-            assert_f8_close(got[ok_in].view(torch.float8_e5m2), ref[ok_in].view(torch.float8_e5m2), max_ulp=1, min_exact=0.999, what=f"computed epilogue cfg {cfg}")
+            n_diff = int((got[ok_in] != lut[ok_in]).sum())
+            line.append(f"cfg {cfg}: computed == table on all but {n_diff}, == oracle {e_c:.6f}")
+            assert same_t >= 0.9999
+            worst = min(worst, e_c)
         print("; ".join(line))
-        assert_f8_close(lut[ok_in].view(torch.float8_e5m2), ref[ok_in].view(torch.float8_e5m2), max_ulp=1, min_exact=0.999, what="table")
-        assert agree(lut) >= worst_computed - 1e-9
+        assert e_t >= worst - 1e-9
 
 
 @pytest.mark.parametrize("cfg", [2, 13, 16, 100])
