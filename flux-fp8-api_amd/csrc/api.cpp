@@ -413,6 +413,9 @@ int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void
 int fluxmi_pair_rows(const void* in, void* out, int rows, long long row_bytes, void* stream) {
   return fluxmi_k_pair_rows(in, out, rows, row_bytes, (hipStream_t)stream);
 }
+int fluxmi_unpair_rows(const void* in, void* out, int rows, long long row_bytes, void* stream) {
+  return fluxmi_k_unpair_rows(in, out, rows, row_bytes, (hipStream_t)stream);
+}
 int fluxmi_attention_debug_buffer(void* dev_u64) { return fluxmi_attn_debug_buffer(dev_u64); }
 
 int fluxmi_attention_plan(int B, int L, int H, int* n_per_x, int* full_per_x, int* npieces, unsigned long long* pieces) {

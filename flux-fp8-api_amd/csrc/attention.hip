@@ -14,12 +14,15 @@
 
 int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
                        const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt,
-                       hipStream_t s, const void* qraw, long long ldq, const void* pe, const void* qn0, const void* qn1, int k_f16) {
+                       hipStream_t s, const void* qraw, long long ldq, const void* pe, const void* qn0, const void* qn1, int k_f16, int out_pairs) {
   FLUXMI_REQUIRE(Q || (qraw && pe && qn0 && qn1 && ldq % 8 == 0), "attention: need Q, or raw q + pe + both q-norm scales (ld %% 8 == 0)");
   FLUXMI_REQUIRE(Lp % 64 == 0 && Lp >= L, "attention: Lp=%d must be a multiple of 64 and >= L=%d", Lp, L);
   FLUXMI_REQUIRE(!out_fp8 || (q_scale0 && q_scale1), "attention: fp8 output needs q_scale pointers");
+  FLUXMI_REQUIRE(!out_pairs || (out_fp8 && ld_out % 64 == 0 && col_off % 64 == 0 && ((long long)B * L) % 2 == 0 && L % 2 == 0),
+                 "attention: the row-pair output layout needs fp8 output, 64-byte aligned rows and an even L");
   if (B * L * H == 0) return 0;
   AttnArgs a;
+  a.out_pairs = out_pairs;
   a.Q = (const u16*)Q; a.K = (const u16*)K; a.VT = (const u16*)VT;
   a.qraw = (const u16*)qraw; a.ldq = ldq; a.pe = (const u16*)pe; a.qn[0] = (const u16*)qn0; a.qn[1] = (const u16*)qn1;
   a.out = out; a.ld_out = ld_out; a.col_off = col_off; a.out_fp8 = out_fp8;

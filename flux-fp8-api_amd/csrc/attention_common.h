@@ -56,6 +56,7 @@ struct AttnArgs {
   FluxmiPrefetch pf;  // weights of the following GEMMs, read by pf.wgs extra workgroups behind the attention grid (fluxmi_internal.h)
   AttnSplit sp;       // balanced grid: the last, partial round of workgroups split along the keys (see AttnSplit)
   unsigned long long* dbg;  // probes (fluxmi_attention_debug_buffer): [workgroup][8] = {blockIdx, XCC id | HW_ID << 8, start, end, Q built, prologue landed, loop done, drain done} in 100 MHz ticks; null = off
+  int out_pairs;  // fp8 output rows in the row-pair layout (fluxmi_gemm_group_t.a_pairs: the next F8Linear's A operand; dense rows, even B * L)
   int abl;  // A/B knobs (FLUXMI_ATTN_ABL, read per call): 2 = no barrier in the 8-wave kernel (timing only), 8 = fp8 output through 16 x 4 B
             // stores per lane (also taken when the output rows are not 16-byte aligned)
 };
@@ -164,7 +165,10 @@ __device__ __forceinline__ void store_o(const AttnArgs& a, const v16f (&o)[4], f
   const long long orow = ((long long)b * a.L + qrow) * a.ld_out + a.col_off + h * 128;
   if (a.out_fp8) {
     const float qs = *a.q_scale[qrow < a.split ? 0 : 1];
-    unsigned char* op = (unsigned char*)a.out + orow;
+    // out_pairs: rows 2r, 2r + 1 interleaved in 64-byte chunks (common.h f8_act_off); a head's 128 columns are two chunks, 128 bytes apart
+    const long long grow = (long long)b * a.L + qrow;
+    const int pr = a.out_pairs;
+    unsigned char* op = (unsigned char*)a.out + (pr ? f8_act_off(grow, a.ld_out, a.col_off + h * 128, 1) : orow);
     unsigned w[4][4];
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -176,7 +180,7 @@ __device__ __forceinline__ void store_o(const AttnArgs& a, const v16f (&o)[4], f
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) *(unsigned*)(op + db * 32 + g * 8 + hi * 4) = w[db][g];
+        for (int g = 0; g < 4; ++g) *(unsigned*)(op + (pr ? (db >> 1) * 128 + (db & 1) * 32 : db * 32) + g * 8 + hi * 4) = w[db][g];
       return;
     }
     // word (db, g) of lane half `hi` covers d = db*32 + g*8 + hi*4 + [0,4).  One v_permlane32_swap of words g and g+2 leaves the
@@ -188,7 +192,7 @@ __device__ __forceinline__ void store_o(const AttnArgs& a, const v16f (&o)[4], f
       const auto s1 = __builtin_amdgcn_permlane32_swap(w[db][1], w[db][3], false, false);
       uint4 v;
       v.x = s0[0]; v.y = s0[1]; v.z = s1[0]; v.w = s1[1];
-      *(uint4*)(op + db * 32 + hi * 16) = v;
+      *(uint4*)(op + (pr ? (db >> 1) * 128 + (db & 1) * 32 : db * 32) + hi * 16) = v;
     }
   } else {
     u16* op = (u16*)a.out + orow;

@@ -30,6 +30,13 @@ __device__ __forceinline__ u16 f2bf(float f) {
 }
 // round an fp32 value through bf16 (the reference materialised a bf16 tensor here)
 __device__ __forceinline__ float rbf(float f) { return (float)((bf16)f); }
+
+// Byte offset of (row m, byte column col) in an fp8 activation buffer with rows of `ld` bytes (ld % 64 == 0): plain row-major, or the ROW-PAIR
+// layout [M/2][ld/64][2][64] of fluxmi_gemm_group_t.a_pairs / c8_pairs (the 64-byte K-steps of rows 2r and 2r + 1 share one 128-byte line).
+// A store / load of <= 16 bytes that is aligned to its own size never crosses a 64-byte chunk, so every access site just swaps its offset.
+__device__ __forceinline__ long long f8_act_off(long long m, long long ld, long long col, int pairs) {
+  return pairs ? (m >> 1) * 2 * ld + (m & 1) * 64 + (col >> 6) * 128 + (col & 63) : m * ld + col;
+}
 // two floats -> packed bf16 pair (RNE).  Written as ONE vector fptrunc so that hipcc selects a single v_cvt_pk_bf16_f32 for the pair;
 // two scalar casts + shift + or compile to two half-used v_cvt_pk_bf16_f32 plus two integer ops (4 instructions, same bits).
 typedef float v2f_pk_t __attribute__((ext_vector_type(2)));

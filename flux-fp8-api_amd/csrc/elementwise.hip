@@ -148,6 +148,7 @@ struct LnModArgs {
   const u16* shift[2]; const u16* scale[2]; long long mod_bstride;  // [B][H] each, batch stride in elements
   const float* q_scale[2];
   int B, L, split, H;
+  int out_pairs;  // fp8 output in the row-pair layout over the B * L rows (fluxmi_gemm_group_t.a_pairs: dense rows, ldo == H, out_bstride == L * ldo)
 };
 // One wave per row, four rows per workgroup.  Round 1 kept x, scale and shift of the row in registers (72 packed + ~40 unpacked =
 // 124 VGPRs -> 4 waves per SIMD -> the 4608 rows of a 1024x1024 step need 1.125 rounds of the chip, i.e. the kernel took two wave
@@ -307,7 +308,8 @@ __global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch on top (hipcc sinks it below the first reduction otherwise)
     const int l = row, st = (l < a.split) ? 0 : 1;
     const float qs = st ? qs2[1] : qs2[0];
-    const long long orow = (long long)b0 * a.out_bstride + (long long)l * a.ldo;
+    const long long grow = (long long)b0 * a.L + l;  // row-pair layout: rows 2r, 2r + 1 interleaved in 64-byte chunks (common.h f8_act_off)
+    const long long orow = (OUT_FP8 && a.out_pairs) ? (grow >> 1) * 2 * a.ldo + (grow & 1) * 64 : (long long)b0 * a.out_bstride + (long long)l * a.ldo;
     // pairs of elements in packed f32 VALU ops (v_pk_add / v_pk_mul / v_pk_fma: two elements per instruction) -- the kernel is VALU-bound
     v2f_t sum2 = {0.f, 0.f};
     float xv[NCH][8];  // the row in fp32, unpacked once for the three passes
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__(512) ln_modulate_stream_kernel(const LnModArgs
           uint2 o;
           o.x = cvt4_fp8<FMT>(q[0], q[1], q[2], q[3]);
           o.y = cvt4_fp8<FMT>(q[4], q[5], q[6], q[7]);
-          *(uint2*)((unsigned char*)a.out + orow + c) = o;
+          *(uint2*)((unsigned char*)a.out + orow + (a.out_pairs ? ((c >> 6) * 128 + (c & 63)) : c)) = o;
         } else {
           *(uint4*)((u16*)a.out + orow + c) = pack8(y);
         }
@@ -652,8 +654,11 @@ int fluxmi_k_axpy_f32(float* w, const float* d, float alpha, long long n, hipStr
 
 int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void* out, long long ldo, long long out_bstride,
                          const void* shift0, const void* scale0, const void* shift1, const void* scale1, long long mod_bstride,
-                         const float* q0, const float* q1, int B, int L, int split, int H, int out_fp8, int fmt, hipStream_t s) {
+                         const float* q0, const float* q1, int B, int L, int split, int H, int out_fp8, int fmt, hipStream_t s, int out_pairs) {
   FLUXMI_REQUIRE(H % 8 == 0 && H <= 4096, "ln_modulate: hidden size %d unsupported (need %%8==0, <=4096)", H);
+  FLUXMI_REQUIRE(!out_pairs || (out_fp8 && ldo == H && out_bstride == (long long)L * ldo && H % 64 == 0 && ((long long)B * L) % 2 == 0 &&
+                                fluxmi_tuning().ln_variant >= 2 && (size_t)H * 16 <= 49152),
+                 "ln_modulate: the row-pair output layout needs fp8 output, dense rows, an even row count and the streaming kernel");
   FLUXMI_REQUIRE(!out_fp8 || (q0 && q1), "ln_modulate: fp8 output needs q_scale pointers");
   if (B * L == 0) return 0;
   LnModArgs a;
@@ -661,7 +666,7 @@ int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void
   a.shift[0] = (const u16*)shift0; a.scale[0] = (const u16*)scale0;
   a.shift[1] = (const u16*)shift1; a.scale[1] = (const u16*)scale1;
   a.mod_bstride = mod_bstride; a.q_scale[0] = q0; a.q_scale[1] = q1;
-  a.B = B; a.L = L; a.split = split; a.H = H;
+  a.B = B; a.L = L; a.split = split; a.H = H; a.out_pairs = out_pairs;
   const int nch = (H + 511) / 512;
   // fluxmi_tuning_t.ln_variant: 2 = streaming kernel (one 8-wave workgroup per CU, next row's loads under this row's arithmetic),
   // 1 = one wave per row, every row resident at once
@@ -710,20 +715,32 @@ int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void
 
 // rows x row_bytes -> [rows/2][row_bytes/64][2][64]: the 64-byte K-steps of a row pair share one 128-byte line (fluxmi_gemm_group_t.W_pairs).
 // One 16-byte chunk per thread; reads and writes are both 64-byte runs.
+// INVERSE: the same mapping read the other way (row-pair layout -> plain rows; the engine's test hook fluxmi_engine_copy_buffer).
+template <bool INVERSE>
 __global__ void __launch_bounds__(256) pair_rows_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, long long chunks, int cpr) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / cpr;
     const int c = (int)(i - r * cpr);                   // 16-byte chunk inside the row
     const long long line = (r >> 1) * (cpr >> 2) + (c >> 2);  // 128-byte line of (row pair, K-step)
-    out[line * 8 + (r & 1) * 4 + (c & 3)] = in[i];
+    if (INVERSE) out[i] = in[line * 8 + (r & 1) * 4 + (c & 3)];
+    else out[line * 8 + (r & 1) * 4 + (c & 3)] = in[i];
   }
+}
+int fluxmi_k_unpair_rows(const void* in, void* out, int rows, long long row_bytes, hipStream_t s) {
+  FLUXMI_REQUIRE(in && out && in != out, "unpair_rows: NULL or aliased buffers");
+  FLUXMI_REQUIRE(rows >= 0 && rows % 2 == 0 && row_bytes > 0 && row_bytes % 64 == 0, "unpair_rows: rows %d (even), row_bytes %lld (multiple of 64)", rows, row_bytes);
+  if (rows == 0) return 0;
+  const long long chunks = (long long)rows * (row_bytes / 16);
+  hipLaunchKernelGGL(pair_rows_kernel<true>, dim3(grid_for(chunks)), dim3(256), 0, s, (const uint4*)in, (uint4*)out, chunks, (int)(row_bytes / 16));
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
 }
 int fluxmi_k_pair_rows(const void* in, void* out, int rows, long long row_bytes, hipStream_t s) {
   FLUXMI_REQUIRE(in && out && in != out, "pair_rows: NULL or aliased buffers");
   FLUXMI_REQUIRE(rows >= 0 && rows % 2 == 0 && row_bytes > 0 && row_bytes % 64 == 0, "pair_rows: rows %d (even), row_bytes %lld (multiple of 64)", rows, row_bytes);
   if (rows == 0) return 0;
   const long long chunks = (long long)rows * (row_bytes / 16);
-  hipLaunchKernelGGL(pair_rows_kernel, dim3(grid_for(chunks)), dim3(256), 0, s, (const uint4*)in, (uint4*)out, chunks, (int)(row_bytes / 16));
+  hipLaunchKernelGGL(pair_rows_kernel<false>, dim3(grid_for(chunks)), dim3(256), 0, s, (const uint4*)in, (uint4*)out, chunks, (int)(row_bytes / 16));
   FLUXMI_LAUNCH_CHECK();
   return 0;
 }

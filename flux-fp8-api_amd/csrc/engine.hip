@@ -157,6 +157,14 @@ const void* pairs_of(E* e, int li) {
   if (!e->pairs || e->pairs_dirty || !fluxmi_tuning().w_pairs || li < 0 || li >= (int)e->pairs_off.size() || e->pairs_off[li] < 0) return nullptr;
   return e->pairs + e->pairs_off[li];
 }
+// ACTIVATIONS in the row-pair layout (round 6; fluxmi_gemm_group_t.a_pairs / c8_pairs, fluxmi_tuning_t.a_pairs): in FUSED mode the fp8
+// activation buffers a8 / attn8 / h8 / cat8 -- written by LayerNorm, attention and the quantising GEMM epilogues, read as the A operand of
+// the block linears -- keep the 64-byte K-steps of rows 2r and 2r + 1 in one 128-byte line, so an A panel's lines cross L2 -> CU once per
+// tile instead of twice (what W_pairs does for the weights).  Needs every row offset of a group to be even: L and Lt even, hidden % 64 == 0.
+// The unfused / calibrating modes keep plain rows (their producers are the standalone quantise kernels).
+bool act_pairs(const E* e, bool fused) {
+  return fused && fluxmi_tuning().a_pairs && e->L % 2 == 0 && e->Lt % 2 == 0 && e->d.hidden % 64 == 0 && e->d.mlp_hidden % 64 == 0;
+}
 // Linears whose launches go through the kernels that honour W_pairs at Flux geometry: the persistent kernel (double blocks' qkv and mlp.0,
 // single blocks' linear1) and the one-wave-per-SIMD kernel (mlp.2, linear2).  +8 GB at Flux-dev.  Built lazily on the caller's stream:
 // create / rebind have none, and a rebind follows weight surgery.
@@ -568,6 +576,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
   // all, so a choice that followed the batch made a sample's bits follow it (round 6: schnell 256^2 at B = 4 crossed 2048 rows)
   const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H, H, e->lin[li_q[0]].kind, 13) && Lt % 16 == 0 && L >= 2048;
   const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0;  // a 256-column tile must not straddle the q|k|v boundaries
+  const int ap = act_pairs(e, fused) ? 1 : 0;  // fp8 activation buffers in the row-pair layout (see act_pairs)
 
   for (int half = 0; half < 2; ++half) {
     const int so = half * 3;  // offset of (shift, scale, gate) triple inside the 6H chunk
@@ -575,7 +584,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
     if (on(half == 0 ? 0 : 5)) {
       if (fused) {
         FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, mt + so * H, mt + (so + 1) * H, mi + so * H, mi + (so + 1) * H, MC,
-                                        e->lin[li_in[0]].in_scale, e->lin[li_in[1]].in_scale, B, L, Lt, H, 1, e->lin[li_in[0]].in_fmt, s));
+                                        e->lin[li_in[0]].in_scale, e->lin[li_in[1]].in_scale, B, L, Lt, H, 1, e->lin[li_in[0]].in_fmt, s, ap));
       } else {
         FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, abf, H, XB, mt + so * H, mt + (so + 1) * H, mi + so * H, mi + (so + 1) * H, MC, nullptr,
                                         nullptr, B, L, Lt, H, 0, 0, s));
@@ -593,6 +602,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
             const long long r0 = (long long)b * L + roff[st];
             FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(a8 + r0 * H) : (const void*)(abf + r0 * H), H, qkv + r0 * 3 * H, 3 * H, rows[st]);
             g.W_pairs = pairs_of(e, li_q[st]);
+            g.a_pairs = ap;
             if (fuse_v) {
               g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = roff[st];
               g.vt_rows = st == 0 ? Lt : e->Lp - Lt; g.kv_col0 = H; g.heads = heads;
@@ -616,7 +626,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
             set_pf(e, {li_p[0], li_p[1], li_m0[0], li_m0[1], li_m2[0], li_m2[1]}, idle_cus((long long)B * heads * ((L + 255) / 256)));
           else set_pf(e, {li_p[0], li_p[1], li_m0[0], li_m0[1]}, idle_cus((long long)B * heads * ((L + 255) / 256)));
           FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attn8, H, 0, 1, e->lin[li_p[0]].in_scale, e->lin[li_p[1]].in_scale, Lt, B, L, e->Lp,
-                                        heads, e->lin[li_p[0]].in_fmt, s, qkv, 3 * H, pe, ns[2], ns[0], attn_f16k()));
+                                        heads, e->lin[li_p[0]].in_fmt, s, qkv, 3 * H, pe, ns[2], ns[0], attn_f16k(), ap));
           fluxmi_set_prefetch(nullptr);
         } else {
           FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, attnbf, H, 0, 0, nullptr, nullptr, Lt, B, L, e->Lp, heads, 0, s, qkv, 3 * H, pe,
@@ -634,6 +644,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
             const long long r0 = (long long)b * L + roff[st];
             FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(attn8 + r0 * H) : (const void*)(attnbf + r0 * H), H, x + r0 * H, H, rows[st]);
             g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 2 * H;
+            g.a_pairs = ap;
             gs.push_back(g);
           }
         FLUXMI_TRY(run_gemm(gs, H, H, e->lin[li_p[0]].kind, e->lin[li_p[0]].in_fmt, FLUXMI_EPI_GATE_RESID, s));
@@ -649,6 +660,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
                                          fused ? (void*)(h8 + r0 * Hm) : (void*)(hbf + r0 * Hm), Hm, rows[st]);
             g.q_scale = e->lin[li_m2[st]].in_scale;
             g.W_pairs = pairs_of(e, li_m0[st]);
+            g.a_pairs = ap; g.c8_pairs = ap;  // reads a8 and writes h8 in the row-pair layout
             if (fused && qlut_enabled()) g.q_lut = c.qlut + (size_t)(i * 2 + st) * 65536;
             gs.push_back(g);
           }
@@ -669,6 +681,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
             FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(h8 + r0 * Hm) : (const void*)(hbf + r0 * Hm), Hm, x + r0 * H, H, rows[st]);
             g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 5 * H;
             g.W_pairs = pairs_of(e, li_m2[st]);
+            g.a_pairs = ap;
             gs.push_back(g);
           }
         if (fused) {  // the 216-tile launch leaves 40 CUs idle: they pull in the first weights of the NEXT block
@@ -698,6 +711,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
   auto on = [&](int st) { return st >= s0 && st <= s1; };
   const int HC = H + Hm;
   const u16* ms = c.mod + (long long)e->d.depth * 12 * H + (long long)i * 3 * H;  // shift scale gate
+  const int ap = act_pairs(e, fused) ? 1 : 0;  // fp8 activation buffers in the row-pair layout (see act_pairs)
   const int l1 = SLi(e, i, S_LIN1), l2 = SLi(e, i, S_LIN2);
   const fluxmi_linear_t &L1 = e->lin[l1], &L2 = e->lin[l2];
   const void* const* ns = &e->norm[e->d.depth * 4 + i * 2];
@@ -705,7 +719,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
     const bool fuse_v = fuse_kv_level() >= 1 && fluxmi_gemm_tile_ok(3 * H + Hm, H, 1, 13);
     const bool fuse_k = fuse_kv_level() >= 2 && fuse_v && H % 256 == 0 && L >= 2048;  // short sequences: one launch of the relayout kernel is cheaper
     if (on(0))
-      FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, ms, ms + H, ms, ms + H, MC, L1.in_scale, L1.in_scale, B, L, L, H, 1, L1.in_fmt, s));
+      FLUXMI_TRY(fluxmi_k_ln_modulate(x, H, XB, a8, H, XB, ms, ms + H, ms, ms + H, MC, L1.in_scale, L1.in_scale, B, L, L, H, 1, L1.in_fmt, s, ap));
     if (on(1)) {
       std::vector<FluxmiGemmGroup> gs;
       for (int b = 0; b < B; ++b) {  // one group per batch element: the fused V^T output is per sequence
@@ -713,6 +727,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
         FluxmiGemmGroup g = mk_group(L1, a8 + r0 * H, H, qkv + r0 * 3 * H, 3 * H, L);
         g.C2 = cat8 + r0 * HC; g.ldc2 = HC; g.split_n = 3 * H; g.c2_col0 = H; g.q_scale = L2.in_scale;
         g.W_pairs = pairs_of(e, l1);
+        g.a_pairs = ap; g.c8_pairs = ap;  // reads a8, writes gelu(mlp) into cat8[:, H:], both in the row-pair layout
         if (qlut_enabled()) g.q_lut = c.qlut + (size_t)(e->d.depth * 2 + i) * 65536;
         if (fuse_v) {
           g.vt_out = VT + (long long)b * H * e->Lp; g.vt_ld = e->Lp; g.tok0 = 0; g.vt_rows = e->Lp; g.kv_col0 = H; g.heads = heads;
@@ -731,7 +746,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
       if (fluxmi_tuning().prefetch >= 3 && i + 1 < e->d.depth_single) set_pf(e, {l2, SLi(e, i + 1, S_LIN1)}, idle_cus((long long)B * heads * ((L + 255) / 256)));
       else set_pf(e, {l2}, idle_cus((long long)B * heads * ((L + 255) / 256)));
       FLUXMI_TRY(fluxmi_k_attention(nullptr, K, VT, cat8, HC, 0, 1, L2.in_scale, L2.in_scale, L, B, L, e->Lp, heads, L2.in_fmt, s, qkv,
-                                    3 * H, pe, ns[0], ns[0], attn_f16k()));
+                                    3 * H, pe, ns[0], ns[0], attn_f16k(), ap));
       fluxmi_set_prefetch(nullptr);
     }
   } else {
@@ -759,6 +774,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
       FluxmiGemmGroup g = mk_group(L2, L2.kind ? (const void*)(cat8 + r0 * HC) : (const void*)(catbf + r0 * HC), HC, x + r0 * H, H, L);
       g.resid = x + r0 * H; g.ldr = H; g.gate = ms + (long long)b * MC + 2 * H;
       g.W_pairs = pairs_of(e, l2);
+      g.a_pairs = ap;
       gs.push_back(g);
     }
     if (fused) {  // linear2's 216 tiles leave 40 CUs idle: they pull in the next block's linear1 (after the last block: the next step's first qkv)
@@ -1291,6 +1307,19 @@ int fluxmi_engine_copy_buffer(fluxmi_engine_t* e, const char* name, long long of
   FLUXMI_REQUIRE(offset >= 0 && bytes >= 0 && (size_t)(offset + bytes) <= it->second.n, "engine_copy_buffer: [%lld, +%lld) outside '%s' (%zu bytes)",
                  offset, bytes, name, it->second.n);
   char* p = (char*)it->second.p + offset;
+  // the fp8 activation buffers are exchanged as PLAIN rows; the FUSED path keeps them in the row-pair layout (act_pairs): convert on the way
+  // (whole row pairs only).  The unfused / calibrating modes use plain rows -- this hook serves the fused teacher-forced tests.
+  long long ld = 0;
+  const std::string nm(name);
+  if (nm == "a8" || nm == "attn8") ld = e->d.hidden;
+  else if (nm == "h8") ld = e->d.mlp_hidden;
+  else if (nm == "cat8") ld = (long long)e->d.hidden + e->d.mlp_hidden;
+  if (ld > 0 && act_pairs(e, true)) {
+    FLUXMI_REQUIRE(offset % (2 * ld) == 0 && bytes % (2 * ld) == 0, "engine_copy_buffer: '%s' is kept in row pairs: offset / size must cover whole pairs of %lld-byte rows",
+                   name, ld);
+    return to_engine ? fluxmi_k_pair_rows(dev_ptr, p, (int)(bytes / ld), ld, (hipStream_t)stream)
+                     : fluxmi_k_unpair_rows(p, dev_ptr, (int)(bytes / ld), ld, (hipStream_t)stream);
+  }
   FLUXMI_CHECK_HIP(hipMemcpyAsync(to_engine ? (void*)p : dev_ptr, to_engine ? (const void*)dev_ptr : (const void*)p, (size_t)bytes,
                                   hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;

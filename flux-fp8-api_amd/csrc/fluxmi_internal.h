@@ -130,13 +130,14 @@ int fluxmi_k_lora_delta(const float* Bm, const float* A, float* delta, int N, in
 int fluxmi_k_axpy_f32(float* w, const float* d, float alpha, long long n, hipStream_t s);
 int fluxmi_k_ln_modulate(const void* x, long long ldx, long long x_bstride, void* out, long long ldo, long long out_bstride,
                          const void* shift0, const void* scale0, const void* shift1, const void* scale1, long long mod_bstride,
-                         const float* q0, const float* q1, int B, int L, int split, int H, int out_fp8, int fmt, hipStream_t s);
+                         const float* q0, const float* q1, int B, int L, int split, int H, int out_fp8, int fmt, hipStream_t s, int out_pairs = 0);
 int fluxmi_k_act(const void* x, void* y, int rows, int cols, long long ld_in, long long ld_out, int mode, hipStream_t s);
 int fluxmi_k_gate_residual(const void* x, const void* y, const void* gate, void* out, int B, int L, int H, long long ldx,
                            long long ldy, long long ldo, long long gate_bstride, hipStream_t s);
 int fluxmi_k_add(const void* a, const void* b, void* z, long long n, hipStream_t s);
 int fluxmi_k_build_qlut(const float* scale, int fmt, int act, void* lut, hipStream_t s);
 int fluxmi_k_pair_rows(const void* in, void* out, int rows, long long row_bytes, hipStream_t s);
+int fluxmi_k_unpair_rows(const void* in, void* out, int rows, long long row_bytes, hipStream_t s);  // the inverse
 int fluxmi_k_add_bcast(const void* a, const void* b, void* z, long long rows, int nb, int cols, hipStream_t s);
 int fluxmi_k_select_step(const void* table, const int* step, const int* step0_dev, void* dst, long long bytes, hipStream_t s);
 int fluxmi_k_timestep_rows(void* t_rows, const float* ts, int step0, int B, int R, hipStream_t s);
@@ -162,4 +163,4 @@ int fluxmi_k_qkv_rope(const void* qkv, long long ld, const void* pe, const void*
 int fluxmi_k_attention(const void* Q, const void* K, const void* VT, void* out, long long ld_out, int col_off, int out_fp8,
                        const float* q_scale0, const float* q_scale1, int split, int B, int L, int Lp, int H, int fmt, hipStream_t s,
                        const void* qraw = nullptr, long long ldq = 0, const void* pe = nullptr, const void* qn0 = nullptr,
-                       const void* qn1 = nullptr, int k_f16 = 0);
+                       const void* qn1 = nullptr, int k_f16 = 0, int out_pairs = 0);

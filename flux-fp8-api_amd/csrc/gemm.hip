@@ -116,8 +116,12 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_tile_kernel(const FluxmiGemm
   for (int i = 0; i < IA; ++i) {
     const int p = tid + NT * i, row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
     const int gr = min(m0 + row, M - 1);
-    srcA[i] = (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16;
+    // a_pairs (fp8 activations in the row-pair layout, fluxmi_gemm_group_t): the two 64-byte halves of this kernel's 128-byte K-step sit 128
+    // bytes apart, consecutive K-steps 256
+    srcA[i] = (FP8 && G.a_pairs) ? (const unsigned char*)G.A + f8_act_off(gr, G.lda, (slot >> 2) * 64 + (slot & 3) * 16, 1)
+                                 : (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16;
   }
+  const long long a_kstep = (FP8 && G.a_pairs) ? 256 : 128;
 #pragma unroll
   for (int i = 0; i < IW; ++i) {
     const int p = tid + NT * i, row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
@@ -128,7 +132,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_tile_kernel(const FluxmiGemm
     unsigned char* dW = dA + A_BYTES;
     const long long koff = (long long)kt * 128;
 #pragma unroll
-    for (int i = 0; i < IA; ++i) glds16(srcA[i] + koff, dA + NT * 16 * i);
+    for (int i = 0; i < IA; ++i) glds16(srcA[i] + kt * a_kstep, dA + NT * 16 * i);
 #pragma unroll
     for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, dW + NT * 16 * i);
   };
@@ -337,6 +341,22 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
   for (int i = 0; i < p.n_groups; ++i)
     if (p.g[i].vt_out || p.g[i].k_out)
       FLUXMI_REQUIRE(cfg == 13 || cfg == 16 || cfg == 18 || cfg == 19, "gemm: fused K / V^T outputs exist only in the 256x256 tile configs (got %d)", cfg);
+  // activations in the row-pair layout (fluxmi_gemm_group_t.a_pairs / c8_pairs): every group of a launch or none; fp8, dense even rows
+  for (int i = 0; i < p.n_groups; ++i) {
+    const FluxmiGemmGroup& g = p.g[i];
+    FLUXMI_REQUIRE((g.a_pairs != 0) == (p.g[0].a_pairs != 0) && (g.c8_pairs != 0) == (p.g[0].c8_pairs != 0),
+                   "gemm: a_pairs / c8_pairs must be the same for every group of a launch");
+    if (g.a_pairs)
+      FLUXMI_REQUIRE(is_fp8 && g.lda == p.K && g.M % 2 == 0 && p.K % 64 == 0,
+                     "gemm: a_pairs needs fp8 operands, dense rows (lda == K, K %% 64 == 0) and an even M (group %d: M=%d lda=%lld K=%d cfg=%d)", i, g.M, g.lda, p.K, cfg);
+    if (g.c8_pairs) {
+      const bool split = p.epi == FLUXMI_EPI_SPLIT;
+      FLUXMI_REQUIRE(p.epi == FLUXMI_EPI_GELU_QUANT || p.epi == FLUXMI_EPI_QUANT || p.epi == FLUXMI_EPI_SILU_QUANT || split,
+                     "gemm: c8_pairs applies to the quantising epilogues only (epilogue %d)", p.epi);
+      FLUXMI_REQUIRE(g.M % 2 == 0 && (split ? (g.ldc2 % 64 == 0 && g.c2_col0 % 64 == 0 && g.split_n % 64 == 0) : g.ldc % 64 == 0),
+                     "gemm: c8_pairs needs an even M and 64-byte aligned rows / column offsets (group %d)", i);
+    }
+  }
   if (cfg == 18 || cfg == 19) return fluxmi_launch_gemm_persist(p, is_fp8, act_fmt, cfg == 19, s);
   if (cfg == 16) return fluxmi_launch_gemm_w1(p, is_fp8, act_fmt, s);
   if (cfg == 17) return fluxmi_launch_gemm_w1_192(p, is_fp8, act_fmt, s);
@@ -353,6 +373,8 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
 int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {
   FLUXMI_REQUIRE(p.n_groups >= 1 && p.n_groups <= FLUXMI_MAX_GROUPS, "gemm: n_groups=%d out of range", p.n_groups);
   FLUXMI_REQUIRE(p.K % (is_fp8 ? 16 : 8) == 0, "gemm: K=%d must be a multiple of %d", p.K, is_fp8 ? 16 : 8);
+  for (int i = 0; i < p.n_groups; ++i)
+    FLUXMI_REQUIRE(!p.g[i].a_pairs && !p.g[i].c8_pairs, "gemm: the generic kernel does not read or write the row-pair activation layout (a_pairs / c8_pairs)");
   int maxM = 0;
   for (int i = 0; i < p.n_groups; ++i) maxM = p.g[i].M > maxM ? p.g[i].M : maxM;
   if (maxM == 0 || p.N == 0) return 0;

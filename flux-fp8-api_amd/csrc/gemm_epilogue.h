@@ -45,7 +45,7 @@ __device__ __forceinline__ void epilogue(const FluxmiGemmGroup& G, float qs, int
       float g[CNT];
 #pragma unroll
       for (int j = 0; j < CNT; ++j) g[j] = rbf(gelu_tanh_f(h[j]));
-      store_q<FMT, CNT>(G.C2, (long long)m * G.ldc2 + G.c2_col0 + (n - G.split_n), g, qs);
+      store_q<FMT, CNT>(G.C2, f8_act_off(m, G.ldc2, G.c2_col0 + (n - G.split_n), G.c8_pairs), g, qs);
     }
   } else if constexpr (EPI == FLUXMI_EPI_BF16) {
     store_bf<CNT>(G.C, (long long)m * G.ldc + n, h);
@@ -53,14 +53,14 @@ __device__ __forceinline__ void epilogue(const FluxmiGemmGroup& G, float qs, int
     float g[CNT];
 #pragma unroll
     for (int j = 0; j < CNT; ++j) g[j] = rbf(gelu_tanh_f(h[j]));
-    store_q<FMT, CNT>(G.C, (long long)m * G.ldc + n, g, qs);
+    store_q<FMT, CNT>(G.C, f8_act_off(m, G.ldc, n, G.c8_pairs), g, qs);
   } else if constexpr (EPI == FLUXMI_EPI_SILU_QUANT) {
     float g[CNT];
 #pragma unroll
     for (int j = 0; j < CNT; ++j) g[j] = rbf(silu_f(h[j]));
-    store_q<FMT, CNT>(G.C, (long long)m * G.ldc + n, g, qs);
+    store_q<FMT, CNT>(G.C, f8_act_off(m, G.ldc, n, G.c8_pairs), g, qs);
   } else if constexpr (EPI == FLUXMI_EPI_QUANT) {
-    store_q<FMT, CNT>(G.C, (long long)m * G.ldc + n, h, qs);
+    store_q<FMT, CNT>(G.C, f8_act_off(m, G.ldc, n, G.c8_pairs), h, qs);
   } else if constexpr (EPI == FLUXMI_EPI_GATE_RESID) {
     float r[CNT], o[CNT];
     load_bf<CNT>(G.resid, (long long)m * G.ldr + n, r);
@@ -135,10 +135,10 @@ __device__ __forceinline__ void row_epilogue(const FluxmiGemmGroup& G, float qs,
         plain = true;
         dst = nullptr;
       } else {
-        dst = (unsigned char*)G.C2 + (long long)m * G.ldc2 + G.c2_col0 + (n - G.split_n);
+        dst = (unsigned char*)G.C2 + f8_act_off(m, G.ldc2, G.c2_col0 + (n - G.split_n), G.c8_pairs);
       }
     } else {
-      dst = (unsigned char*)G.C + (long long)m * G.ldc + n;
+      dst = (unsigned char*)G.C + f8_act_off(m, G.ldc, n, G.c8_pairs);
     }
     if (plain) {
       *(uint4*)((u16*)G.C + (long long)m * G.ldc + n) = pack8(h);
@@ -289,8 +289,8 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
         const uint4 raw = *(const uint4*)(tile + ml * 64 + ((c ^ ((ml >> 1) & 3)) * 16));
         if (m < M) {
           unsigned char* dst;
-          if constexpr (EPI == FLUXMI_EPI_SPLIT) dst = (unsigned char*)G.C2 + (long long)m * G.ldc2 + G.c2_col0 + (n - G.split_n);
-          else dst = (unsigned char*)G.C + (long long)m * G.ldc + n;
+          if constexpr (EPI == FLUXMI_EPI_SPLIT) dst = (unsigned char*)G.C2 + f8_act_off(m, G.ldc2, G.c2_col0 + (n - G.split_n), G.c8_pairs);
+          else dst = (unsigned char*)G.C + f8_act_off(m, G.ldc, n, G.c8_pairs);
           *(uint4*)dst = raw;
         }
       }

@@ -209,13 +209,17 @@ __device__ __forceinline__ void ps_epilogue(const FluxmiGemmGroup& G, v16f (&acc
       after_table();
       const unsigned ld8 = EPI == FLUXMI_EPI_SPLIT ? uni_u32((unsigned)G.ldc2) : uni_u32((unsigned)G.ldc);
       const int col0 = EPI == FLUXMI_EPI_SPLIT ? (int)uni_u32((unsigned)(G.c2_col0 - G.split_n)) : 0;
-      const __amdgpu_buffer_rsrc_t c8 = ps_out_rsrc(EPI == FLUXMI_EPI_SPLIT ? G.C2 : G.C, (long long)M * ld8, (long long)m_wave0 * ld8 + (col0 + n_wave0));
+      // c8_pairs: the fp8 rows leave in the row-pair layout the next F8Linear reads with a_pairs (fluxmi_gemm_group_t; the wave's 64 columns
+      // are ONE 64-byte chunk of every row, m_wave0 is even): chunk (row r, col) -> (r / 2) * 2 * ld + (r % 2) * 64 + (col / 64) * 128
+      const bool c8p = uni_u32((unsigned)G.c8_pairs) != 0;
+      const long long org = c8p ? (long long)m_wave0 * ld8 + (long long)((col0 + n_wave0) >> 6) * 128 : (long long)m_wave0 * ld8 + (col0 + n_wave0);
+      const __amdgpu_buffer_rsrc_t c8 = ps_out_rsrc(EPI == FLUXMI_EPI_SPLIT ? G.C2 : G.C, (long long)M * ld8, org);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          const int ml = it * 16 + (lane >> 2), c = lane & 3;
-          ps_store16(c8, __builtin_bit_cast(v4i, raw[i][it]), (unsigned)(i * 32 + ml) * ld8 + c * 16);
+          const int ml = it * 16 + (lane >> 2), c = lane & 3, r = i * 32 + ml;
+          ps_store16(c8, __builtin_bit_cast(v4i, raw[i][it]), c8p ? (unsigned)(r >> 1) * 2 * ld8 + (r & 1) * 64 + c * 16 : (unsigned)r * ld8 + c * 16);
         }
       return;
     }
@@ -518,6 +522,9 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
   const unsigned a_row_b = (unsigned)(P.g[0].lda * EB), w_row_b = (unsigned)(P.K * EB);  // one lda for every group (host check)
   const bool w_pairs = (PS_ABL & 16) != 0 || uni_ptr((const u16*)P.g[0].W_pairs) != nullptr;  // every group or none (host check)
   const unsigned w_kstep = w_pairs ? 128u : 64u;                                               // bytes between consecutive K-steps of a W row
+  // A in the row-pair layout (fluxmi_gemm_group_t.a_pairs: the engine's fp8 activation buffers in fused mode; every group or none, host check)
+  const bool a_pairs = (PS_ABL & 8) != 0 || uni_u32((unsigned)P.g[0].a_pairs) != 0;
+  const unsigned a_kstep = a_pairs ? 128u : 64u;
 
   // ring slot arithmetic (slots 0 .. NS-1; d <= NS)
   auto nslot = [](int sl, int d) { const int t = sl + d; return t >= NS ? t - NS : t; };
@@ -526,7 +533,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-      a_voff[i] = (PS_ABL & 8) ? (unsigned)(row >> 1) * 2 * a_row_b + (row & 1) * 64 + slot * 16 : (unsigned)row * a_row_b + slot * 16;
+      a_voff[i] = a_pairs ? (unsigned)(row >> 1) * 2 * a_row_b + (row & 1) * 64 + slot * 16 : (unsigned)row * a_row_b + slot * 16;
       // W in the row-pair layout (W_pairs: the K-steps of rows 2r, 2r + 1 share a 128-byte line, consecutive K-steps of a pair are 128 bytes apart)
       w_voff[i] = w_pairs ? (unsigned)(row >> 1) * 2 * w_row_b + (row & 1) * 64 + slot * 16 : (unsigned)row * w_row_b + slot * 16;
     }
@@ -547,7 +554,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
     for (int st = 0; st < D; ++st) {
       unsigned char* dA = smem + st * STAGE + wave * 1024;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) dma16_buf(c_ars, dA + NT * 16 * i, a_voff[i], c_asoff + st * ((PS_ABL & 8) ? 128 : 64));
+      for (int i = 0; i < 2; ++i) dma16_buf(c_ars, dA + NT * 16 * i, a_voff[i], c_asoff + st * a_kstep);
 #pragma unroll
       for (int i = 0; i < 2; ++i) dma16_buf(c_wrs, dA + A_BYTES + NT * 16 * i, w_voff[i], c_wsoff + st * w_kstep);
     }
@@ -600,7 +607,7 @@ __global__ void __launch_bounds__(512, 2) gemm_ps_kernel(const FluxmiGemmParams 
     // piece q of a K-step's refill into ring slot sl: 0, 1 = the lane's two A pieces, 2, 3 = its two W pieces
     auto dma_piece = [&](__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t wrs, unsigned asoff, unsigned wsoff, int kt, int sl, int q) {
       unsigned char* dA = smem + sl * STAGE + wave * 1024;
-      if (q < 2) dma16_buf(ars, dA + NT * 16 * q, a_voff[q], asoff + kt * ((PS_ABL & 8) ? 128 : 64));
+      if (q < 2) dma16_buf(ars, dA + NT * 16 * q, a_voff[q], asoff + kt * a_kstep);
       else dma16_buf(wrs, dA + A_BYTES + NT * 16 * (q - 2), w_voff[q - 2], wsoff + kt * w_kstep);
     };
     auto dma_stage = [&](__amdgpu_buffer_rsrc_t ars, __amdgpu_buffer_rsrc_t wrs, unsigned asoff, unsigned wsoff, int kt, int sl) {
@@ -847,7 +854,7 @@ int fluxmi_gemm_persist_ok(const FluxmiGemmParams& p, int is_fp8, int act_fmt) {
   if (p.epi != FLUXMI_EPI_BF16 && p.epi != FLUXMI_EPI_GATE_RESID && p.epi != FLUXMI_EPI_SPLIT && p.epi != FLUXMI_EPI_GELU_QUANT) return 0;
   for (int i = 0; i < p.n_groups; ++i) {
     const FluxmiGemmGroup& g = p.g[i];
-    if (g.lda != p.g[0].lda || (g.W_pairs != nullptr) != (p.g[0].W_pairs != nullptr)) return 0;
+    if (g.lda != p.g[0].lda || (g.W_pairs != nullptr) != (p.g[0].W_pairs != nullptr) || (g.a_pairs != 0) != (p.g[0].a_pairs != 0)) return 0;
     // fused K: whole 256-column tiles inside the K columns, head pairs (the dispatcher requires the same of configs 13 / 16)
     if (g.k_out && (g.kv_col0 % 256 != 0 || (g.heads * 128) % 256 != 0 || !g.pe || !g.k_norm || g.k_rows <= 0 ||
                     (long long)g.heads * g.k_rows * 256 >= (1LL << 32) || (p.epi != FLUXMI_EPI_BF16 && p.epi != FLUXMI_EPI_SPLIT)))

@@ -82,12 +82,16 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
   const unsigned char* srcW[IW];
   unsigned a_voff[IA], w_voff[IW];
   const long long a_row_b = (long long)G.lda * EB, w_row_b = (long long)P.K * EB;
+  const bool a_pairs = FP8 && !SPLITK && G.a_pairs != 0;
+  const int a_kstep = a_pairs ? 128 : 64;
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
     const int gr = min(m0 + row, M - 1);
-    srcA[i] = (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16 + (long long)k_begin * 64;
-    a_voff[i] = (unsigned)(row * a_row_b + slot * 16);
+    // a_pairs: fp8 activations in the row-pair layout (fluxmi_gemm_group_t; never with split-K): K-steps of a row are 128 bytes apart
+    srcA[i] = a_pairs ? (const unsigned char*)G.A + f8_act_off(gr, G.lda, slot * 16, 1)
+                      : (const unsigned char*)G.A + ((long long)gr * G.lda) * EB + slot * 16 + (long long)k_begin * 64;
+    a_voff[i] = a_pairs ? (unsigned)((row >> 1) * 2 * a_row_b + (row & 1) * 64 + slot * 16) : (unsigned)(row * a_row_b + slot * 16);
   }
 #pragma unroll
   for (int i = 0; i < IW; ++i) {
@@ -103,13 +107,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
     unsigned char* dW = dA + A_BYTES;
     if constexpr (BUF) {
 #pragma unroll
-      for (int i = 0; i < IA; ++i) dma16_buf(ars, dA + NT * 16 * i, a_voff[i], a_soff0 + kt * 64);
+      for (int i = 0; i < IA; ++i) dma16_buf(ars, dA + NT * 16 * i, a_voff[i], a_soff0 + kt * a_kstep);
 #pragma unroll
       for (int i = 0; i < IW; ++i) dma16_buf(wrs, dW + NT * 16 * i, w_voff[i], w_soff0 + kt * 64);
     } else {
       const long long koff = (long long)kt * 64;
 #pragma unroll
-      for (int i = 0; i < IA; ++i) glds16(srcA[i] + koff, dA + NT * 16 * i);
+      for (int i = 0; i < IA; ++i) glds16(srcA[i] + (long long)kt * a_kstep, dA + NT * 16 * i);
 #pragma unroll
       for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, dW + NT * 16 * i);
     }
@@ -416,7 +420,8 @@ void fluxmi_set_splitk_scratch(float* p) { t_splitk_override = p; }
 
 int fluxmi_launch_gemm_splitk(FluxmiGemmParams& p, int is_fp8, int act_fmt, int split_k, hipStream_t s) {
   FLUXMI_REQUIRE(fluxmi_gemm_tile_ok(p.N, p.K, is_fp8, 13), "gemm split-K: shape N=%d K=%d not tileable", p.N, p.K);
-  for (int i = 0; i < p.n_groups; ++i) FLUXMI_REQUIRE(!p.g[i].vt_out && !p.g[i].k_out, "gemm split-K: no fused K / V^T outputs");
+  for (int i = 0; i < p.n_groups; ++i)
+    FLUXMI_REQUIRE(!p.g[i].vt_out && !p.g[i].k_out && !p.g[i].a_pairs && !p.g[i].c8_pairs, "gemm split-K: no fused K / V^T outputs, no row-pair activation layout");
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) return launch_pp_splitk<true, FLUXMI_FMT_E5M2>(p, split_k, s);
     return launch_pp_splitk<true, FLUXMI_FMT_E4M3>(p, split_k, s);

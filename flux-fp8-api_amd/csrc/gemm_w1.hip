@@ -76,18 +76,21 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   const bool w_pairs = uni_ptr((const u16*)G.W_pairs) != nullptr;
   const unsigned w_kstep = w_pairs ? 128u : 64u;
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(w_pairs ? G.W_pairs : G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
+  // A in the row-pair layout as well (fluxmi_gemm_group_t.a_pairs: the engine's fp8 activation buffers in fused mode; fp8 only, lda == K, M even)
+  const bool a_pairs = FP8 && uni_u32((unsigned)G.a_pairs) != 0;
+  const unsigned a_kstep = a_pairs ? 128u : 64u;
   unsigned a_voff[4], w_voff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-    a_voff[i] = (unsigned)(row * a_row_b + slot * 16);  // (i < NA is used)
+    a_voff[i] = a_pairs ? (unsigned)((row >> 1) * 2 * a_row_b + (row & 1) * 64 + slot * 16) : (unsigned)(row * a_row_b + slot * 16);  // (i < NA is used)
     w_voff[i] = w_pairs ? (unsigned)((row >> 1) * 2 * w_row_b + (row & 1) * 64 + slot * 16) : (unsigned)(row * w_row_b + slot * 16);
   }
   const unsigned a_soff0 = uni_u32((unsigned)(m0 * a_row_b)), w_soff0 = uni_u32((unsigned)(n0 * w_row_b));
   // piece q (0..LPT-1: NA of A, then 4 of W) of K-step kt into ring slot `slot`
   auto dma_piece = [&](int q, int slot, int kt) {
     unsigned char* d = smem + slot * STAGE + wave * 1024;
-    if (q < NA) dma16_buf(ars, d + NT * 16 * q, a_voff[q], a_soff0 + kt * 64);
+    if (q < NA) dma16_buf(ars, d + NT * 16 * q, a_voff[q], a_soff0 + kt * a_kstep);
     else dma16_buf(wrs, d + A_BYTES + NT * 16 * (q - NA), w_voff[q - NA], w_soff0 + kt * w_kstep);
   };
 

@@ -40,7 +40,7 @@ int validate(const fluxmi_tuning_t& t) {
       {"gemm_splitk", t.gemm_splitk, 0, 1}, {"gemm_hybrid", t.gemm_hybrid, 0, 1}, {"gemm_esel", t.gemm_esel, 0, 1}, {"gemm_persist", t.gemm_persist, 0, 2},
       {"attn_var", t.attn_var, 0, 3},       {"attn_abl", t.attn_abl, 0, 15},      {"attn_f16k", t.attn_f16k, 0, 1}, {"qlut", t.qlut, 0, 1},
       {"roctx", t.roctx, 0, 1},             {"prefetch", t.prefetch, 0, 3},       {"w_pairs", t.w_pairs, 0, 1},     {"log", t.log, 0, 1},
-      {"attn_split", t.attn_split, 0, 2}, {"gemm_tile192", t.gemm_tile192, 0, 1}};
+      {"attn_split", t.attn_split, 0, 2}, {"gemm_tile192", t.gemm_tile192, 0, 1}, {"a_pairs", t.a_pairs, 0, 1}};
   for (const auto& k : sw) FLUXMI_REQUIRE(k.v >= k.lo && k.v <= k.hi, "tuning: %s %d outside [%d, %d]", k.name, k.v, k.lo, k.hi);
   return 0;
 }
@@ -48,9 +48,9 @@ int validate(const fluxmi_tuning_t& t) {
 void log_tuning(const fluxmi_tuning_t& t, const char* why) {
   fprintf(stderr,
           "fluxmi tuning (%s): gemm_cfg=%d splitk=%d hybrid=%d esel=%d persist=%d | attn var=%d abl=%d defer_log2=%g f16k=%d | "
-          "fuse_kv=%d qlut=%d ln=%d roctx=%d prefetch=%d w_pairs=%d attn_split=%d tile192=%d\n",
+          "fuse_kv=%d qlut=%d ln=%d roctx=%d prefetch=%d w_pairs=%d attn_split=%d tile192=%d a_pairs=%d\n",
           why, t.gemm_cfg, t.gemm_splitk, t.gemm_hybrid, t.gemm_esel, t.gemm_persist, t.attn_var, t.attn_abl,
-          (double)t.attn_defer_log2, t.attn_f16k, t.fuse_kv, t.qlut, t.ln_variant, t.roctx, t.prefetch, t.w_pairs, t.attn_split, t.gemm_tile192);
+          (double)t.attn_defer_log2, t.attn_f16k, t.fuse_kv, t.qlut, t.ln_variant, t.roctx, t.prefetch, t.w_pairs, t.attn_split, t.gemm_tile192, t.a_pairs);
 }
 
 void init_from_env() {
@@ -78,6 +78,7 @@ void init_from_env() {
   t.log = env_int("FLUXMI_LOG", 0);
   t.attn_split = env_int("FLUXMI_ATTN_SPLIT", 1);
   t.gemm_tile192 = env_int("FLUXMI_GEMM_TILE192", 1);
+  t.a_pairs = env_int("FLUXMI_A_PAIRS", 1);
   if (validate(t) != 0) {  // a bad environment must not silently change the arithmetic: say so and keep the compiled defaults for that knob
     fprintf(stderr, "fluxmi: ignoring invalid FLUXMI_* environment (%s)\n", fluxmi_last_error());
     if (!(isfinite(t.attn_defer_log2) && t.attn_defer_log2 >= 0.f && t.attn_defer_log2 <= 16.f)) t.attn_defer_log2 = 8.0f;
@@ -87,7 +88,7 @@ void init_from_env() {
     auto fix = [](int& v, int lo, int hi, int dflt) { if (v < lo || v > hi) v = dflt; };
     fix(t.gemm_splitk, 0, 1, 1); fix(t.gemm_hybrid, 0, 1, 1); fix(t.gemm_esel, 0, 1, 1); fix(t.gemm_persist, 0, 2, 1);
     fix(t.attn_var, 0, 3, 0); fix(t.attn_abl, 0, 15, 0); fix(t.attn_f16k, 0, 1, 1); fix(t.qlut, 0, 1, 1); fix(t.roctx, 0, 1, 0);
-    fix(t.prefetch, 0, 3, 1); fix(t.w_pairs, 0, 1, 1); fix(t.log, 0, 1, 0); fix(t.attn_split, 0, 2, 1); fix(t.gemm_tile192, 0, 1, 1);
+    fix(t.prefetch, 0, 3, 1); fix(t.w_pairs, 0, 1, 1); fix(t.log, 0, 1, 0); fix(t.attn_split, 0, 2, 1); fix(t.gemm_tile192, 0, 1, 1); fix(t.a_pairs, 0, 1, 1);
   }
   g_tuning = t;
   if (t.log) log_tuning(t, "environment");

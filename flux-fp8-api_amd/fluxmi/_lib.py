@@ -33,7 +33,7 @@ class GemmGroup(C.Structure):
         ("M", i32), ("m_tile_start", i32), ("split_n", i32), ("c2_col0", i32),
         ("vt_out", vp), ("k_out", vp), ("pe", vp), ("k_norm", vp), ("vt_ld", i64),
         ("k_rows", i32), ("tok0", i32), ("vt_rows", i32), ("kv_col0", i32), ("heads", i32), ("k_f16", i32),
-        ("q_lut", vp), ("W_pairs", vp),
+        ("q_lut", vp), ("W_pairs", vp), ("a_pairs", i32), ("c8_pairs", i32),
     ]
 
 
@@ -42,7 +42,7 @@ class Tuning(C.Structure):
     _fields_ = [
         ("struct_size", i32), ("gemm_cfg", i32), ("gemm_splitk", i32), ("gemm_hybrid", i32), ("gemm_esel", i32), ("gemm_persist", i32),
         ("attn_var", i32), ("attn_abl", i32), ("attn_defer_log2", f32), ("attn_f16k", i32), ("fuse_kv", i32), ("qlut", i32),
-        ("ln_variant", i32), ("roctx", i32), ("prefetch", i32), ("w_pairs", i32), ("log", i32), ("gemm_tile192", i32), ("attn_split", i32),
+        ("ln_variant", i32), ("roctx", i32), ("prefetch", i32), ("w_pairs", i32), ("log", i32), ("gemm_tile192", i32), ("attn_split", i32), ("a_pairs", i32),
     ]
 
 
@@ -84,6 +84,7 @@ _SIGS = {
     "fluxmi_qkv_rope": ([vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_build_quant_lut": ([vp, i32, i32, vp, vp], i32),
     "fluxmi_pair_rows": ([vp, vp, i32, i64, vp], i32),
+    "fluxmi_unpair_rows": ([vp, vp, i32, i64, vp], i32),
     "fluxmi_im2col3x3": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_groupnorm": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp], i32),
     "fluxmi_softmax_rows": ([vp, vp, i32, i32, i64, C.c_float, vp], i32),
@@ -121,7 +122,7 @@ for _name, (_args, _res) in _SIGS.items():
     _fn.argtypes = _args
     _fn.restype = _res
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 if lib.fluxmi_abi_version() != ABI_VERSION:
     raise ImportError(f"fluxmi: ABI version mismatch ({lib.fluxmi_abi_version()} != {ABI_VERSION})")
 

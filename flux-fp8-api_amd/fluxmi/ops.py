@@ -101,10 +101,11 @@ def lora_fuse_f8(w8: torch.Tensor, w_scale: torch.Tensor, w_scale_recip: torch.T
 # ---- linear ----------------------------------------------------------------------------------------
 def make_group(A, W, bias, sa_recip, sb_recip, Cout, M, lda, ldc, *, C2=None, ldc2=0, gate=None, resid=None, ldr=0,
                q_scale=None, split_n=0, c2_col0=0, vt_out=None, vt_ld=0, tok0=0, vt_rows=0, kv_col0=0, heads=0, k_out=None, pe=None,
-               k_norm=None, k_rows=0, q_lut=None, k_f16=False, W_pairs=None) -> GemmGroup:
+               k_norm=None, k_rows=0, q_lut=None, k_f16=False, W_pairs=None, a_pairs=False, c8_pairs=False) -> GemmGroup:
     g = GemmGroup()
     g.q_lut = q_lut
     g.W_pairs = W_pairs
+    g.a_pairs, g.c8_pairs = int(a_pairs), int(c8_pairs)
     g.k_f16 = int(k_f16)
     g.vt_out, g.k_out, g.pe, g.k_norm = vt_out, k_out, pe, k_norm
     g.vt_ld, g.k_rows, g.tok0, g.vt_rows, g.kv_col0, g.heads = vt_ld, k_rows, tok0, vt_rows, kv_col0, heads
@@ -252,6 +253,14 @@ def attention(Q, K, VT, q_scale0=None, q_scale1=None, split=None, fmt=E5M2, out=
         out = torch.empty((B, L, H * 128), dtype=dtype_of(fmt) if out_fp8 else torch.bfloat16, device=Q.device)
     call("fluxmi_attention", _p(Q), _p(K), _p(VT), _p(out), out.stride(1), col_off, int(out_fp8), _p(q_scale0), _p(q_scale1), split,
          B, L, Lp, H, fmt, int(K.dtype == torch.float16), _stream())
+    return out
+
+
+def unpair_rows(w: torch.Tensor) -> torch.Tensor:
+    """inverse of pair_rows: the row-pair layout [R/2][row_bytes/64][2][64] back to plain rows [R, C]"""
+    assert w.dim() == 2 and w.is_contiguous()
+    out = torch.empty_like(w)
+    call("fluxmi_unpair_rows", _p(w), _p(out), w.shape[0], w.shape[1] * w.element_size(), _stream())
     return out
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FLUXMI_ABI_VERSION 4
+#define FLUXMI_ABI_VERSION 5
 
 /* fp8 format codes (torch.float8_e4m3fn / torch.float8_e5m2, float8_quantize.py:39,43) */
 #define FLUXMI_E4M3 0
@@ -95,12 +95,23 @@ typedef struct fluxmi_gemm_group {
    * K loop of the persistent kernel 62.4 K -> 56.5 K cycles per tile).  Same values, same results; NULL = read W.  Honoured by tile configs 18
    * (all groups of a launch with or all without) and 16; the engine keeps such a copy of the weights those launches read (+8 GB at Flux-dev). */
   const void* W_pairs;
+  /* ACTIVATIONS in the row-pair layout (ABI 5, round 6).  a_pairs != 0: A (fp8, dense rows: lda == K, M % 2 == 0) is stored as
+   * [M/2][K/64][2][64] like W_pairs -- the 64-byte K-steps of rows 2r and 2r + 1 share one 128-byte line, so every L2 line of the A panel
+   * crosses to the CU once per tile instead of twice (in-step, timing-only ablation of the persistent kernel alone: -1.3 % per step,
+   * profiles/r06_act_pairs.txt).  c8_pairs != 0: the fp8 output of the QUANTISING epilogues (C for FLUXMI_EPI_GELU_QUANT / _QUANT /
+   * _SILU_QUANT, C2 for FLUXMI_EPI_SPLIT) is written in that layout over rows of ldc (ldc2) bytes: byte (m, col) of the row-major buffer
+   * lives at (m / 2) * 2 * ld + (m % 2) * 64 + (col / 64) * 128 + col % 64 (ld % 64 == 0; col = the column inside the FULL row, i.e.
+   * c2_col0 + n - split_n for SPLIT) -- the next F8Linear reads it with a_pairs.  Same values, same results; honoured by tile configs 2,
+   * 13, 16, 17, 18 (every group of a launch with the same flags); the generic and split-K kernels refuse a flagged group.  The engine
+   * keeps its fp8 activation buffers this way in fused mode (fluxmi_tuning_t.a_pairs). */
+  int a_pairs;
+  int c8_pairs;
 } fluxmi_gemm_group_t;
 
 const char* fluxmi_last_error(void);
 int fluxmi_abi_version(void);
 
-/* ---- kernel-selection knobs (ABI 3; attn_split: ABI 4) --------------------------------------------------------------------------------------------
+/* ---- kernel-selection knobs (ABI 3; attn_split: ABI 4; a_pairs: ABI 5) --------------------------------------------------------------------------------------------
  * The reference has no counterpart (its only switches are the ModelSpec flags of util.py:40-77); these choose between kernels /
  * fusion levels that compute the same results.  They are resolved ONCE: the first call that needs a knob parses the FLUXMI_*
  * environment variables named below into this struct (csrc/tuning.cpp -- the only getenv site of the library);
@@ -136,6 +147,9 @@ typedef struct fluxmi_tuning {
                                                  their key range and merge the partial softmax states (fp32 log-sum-exp in a fixed order:
                                                  deterministic); see fluxmi_attention_plan.  2 = wherever such a plan exists (fuller last
                                                  rounds: measured not to pay, Flux-dev 1024^2 +3.4 % per step), 0 = one workgroup per task */
+  int a_pairs;           /* FLUXMI_A_PAIRS       1 (default): in fused mode the engine keeps its fp8 ACTIVATION buffers (LayerNorm / attention /
+                                                 GELU outputs = the A operands of the block linears) in the row-pair layout
+                                                 (fluxmi_gemm_group_t.a_pairs / c8_pairs; even L and Lt only) -- same bits, fewer L2 lines */
 } fluxmi_tuning_t;
 int fluxmi_get_tuning(fluxmi_tuning_t* out);
 int fluxmi_set_tuning(const fluxmi_tuning_t* in); /* validates every field (non-zero + fluxmi_last_error on a bad value) */
@@ -214,6 +228,8 @@ int fluxmi_add(const void* a, const void* b, void* z, long long n, void* stream)
 int fluxmi_build_quant_lut(const float* scale, int fmt, int act, void* lut, void* stream);
 /* rows x row_bytes (row-major, rows % 2 == 0, row_bytes % 64 == 0) -> the row-pair layout of fluxmi_gemm_group_t.W_pairs; out != in */
 int fluxmi_pair_rows(const void* in, void* out, int rows, long long row_bytes, void* stream);
+/* the inverse: the row-pair layout back to plain rows (ABI 5; tests, fluxmi_engine_copy_buffer) */
+int fluxmi_unpair_rows(const void* in, void* out, int rows, long long row_bytes, void* stream);
 
 /* ---- attention path --------------------------------------------------------------------------------- */
 /* pe[rows, pairs, (cos,sin)] from position ids                                    flux_model.py:49-57,82-92 */

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(_lib.lib, s), f"libfluxmi.so does not export {s}"
     assert set(_lib.EXPORTS) == set(syms), f"ctypes table out of sync with the header: {set(_lib.EXPORTS) ^ set(syms)}"
-    assert _lib.lib.fluxmi_abi_version() == 4
+    assert _lib.lib.fluxmi_abi_version() == 5
 
 
 @pytest.mark.parametrize("B,L,H", [(1, 4608, 24), (1, 2816, 24), (2, 4608, 24), (8, 4608, 24), (1, 1100, 8), (3, 4608, 24), (1, 8192, 24), (1, 512, 24),
@@ -149,7 +149,7 @@ def test_tuning_struct_round_trip_and_validation(monkeypatch):
 def test_struct_layouts_match_the_header():
     from fluxmi import _lib
 
-    assert C.sizeof(_lib.GemmGroup) == 10 * 8 + 4 * 8 + 4 * 4 + 4 * 8 + 8 + 6 * 4 + 8 + 8  # ... q_lut, W_pairs
+    assert C.sizeof(_lib.GemmGroup) == 10 * 8 + 4 * 8 + 4 * 4 + 4 * 8 + 8 + 6 * 4 + 8 + 8 + 2 * 4  # ... q_lut, W_pairs, a_pairs, c8_pairs
     assert C.sizeof(_lib.Linear) == 6 * 8 + 4 * 4
     assert C.sizeof(_lib.ModelDesc) == 14 * 4
 

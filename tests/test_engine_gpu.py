@@ -189,7 +189,7 @@ def test_fused_equals_unfused_and_graph_equals_eager(dev):
     # the weight prefetch riding on attention / the 216-tile GEMMs (extra workgroups that only read), the persistent GEMM, the table epilogues
     from fluxmi import _lib
 
-    for knobs in (dict(prefetch=0), dict(prefetch=2), dict(gemm_persist=0), dict(qlut=0), dict(fuse_kv=1), dict(fuse_kv=0), dict(w_pairs=0)):
+    for knobs in (dict(prefetch=0), dict(prefetch=2), dict(gemm_persist=0), dict(qlut=0), dict(fuse_kv=1), dict(fuse_kv=0), dict(w_pairs=0), dict(a_pairs=0)):
         with _lib.tuning(**knobs):
             a3 = model.denoise(lat, inp["img_ids"], inp["txt"], inp["txt_ids"], inp["y"], ts2, guidance=3.5, use_graph=True)
         assert torch.equal(a, a3), f"latents change under tuning {knobs}: rel-L2 {rel_l2(a3, a):.3e}"

@@ -584,6 +584,69 @@ def test_gemm_persistent_quantising_paths_exhaustive(ops, dev):
                                f"{[hex(int(v)) for v in hbits[bad][:8].tolist()]} rows {torch.nonzero(bad)[:4, 0].tolist()}")
 
 
+@pytest.mark.parametrize("cfg", [2, 13, 16, 17, 18, -1])
+def test_gemm_row_pair_activations(ops, dev, cfg):
+    """ABI 5 (round 6): fluxmi_gemm_group_t.a_pairs -- the fp8 A operand stored as [M/2][K/64][2][64] (ops.pair_rows), what the engine's
+    LayerNorm / attention / GELU epilogues write in fused mode -- and c8_pairs -- the fp8 output of the quantising epilogues written in that
+    layout for the next linear.  Same values at other addresses: every tile config that honours the flags must give the bits of the plain
+    launch (bf16 / gate*y+x outputs identical; unpaired fp8 outputs identical), two groups with ragged-free even M, table and computed
+    GELU; the generic and split-K kernels refuse a flagged group.             float8_quantize.py:272-296 (layout-only: no arithmetic changes)"""
+    from fluxmi import _lib
+
+    torch.manual_seed(41)
+    N, K = 3072, (8192 if cfg in (16, 17) else 3072)
+    Ms = (640, 1022) if cfg != 18 else (4096, 1024)  # the persistent kernel takes launches of more than 256 tiles
+    one = torch.tensor(1.0, device=dev)
+    sar = torch.tensor(0.02, device=dev)
+    qs = torch.tensor(37.5, device=dev)
+    lut = ops.build_quant_lut(qs, E5M2, act=1)
+    a = [(torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2) for M in Ms]
+    ap = [ops.pair_rows(x.view(torch.uint8)).view(torch.float8_e5m2) for x in a]
+    w = [(torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn) for _ in Ms]
+    bias = torch.randn(N, device=dev).bfloat16()
+    gate = torch.randn(N, device=dev).bfloat16()
+    resid = [torch.randn(M, N, device=dev).bfloat16() for M in Ms]
+
+    def launch(epi, pairs_in, pairs_out, table):
+        outs, groups = [], []
+        for gi, M in enumerate(Ms):
+            src = ap[gi] if pairs_in else a[gi]
+            if epi == _lib.EPI_GATE_RESID:
+                o = resid[gi].clone()
+                kw = dict(gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N)
+            elif epi == _lib.EPI_GELU_QUANT:
+                o = torch.zeros(M, N, dtype=torch.uint8, device=dev)
+                kw = dict(q_scale=qs.data_ptr(), q_lut=lut.data_ptr() if table else None)
+            else:
+                o = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+                kw = {}
+            outs.append(o)
+            groups.append(ops.make_group(src.data_ptr(), w[gi].data_ptr(), bias.data_ptr(), sar.data_ptr(), one.data_ptr(), o.data_ptr(), M, K, N,
+                                         a_pairs=pairs_in, c8_pairs=pairs_out, **kw))
+        ops.gemm_grouped(groups, N, K, True, E5M2, epi, cfg)
+        torch.cuda.synchronize()
+        if pairs_out:  # back to plain rows for the comparison
+            outs = [ops.unpair_rows(o) for o in outs]
+        return [o.view(torch.int16 if o.dtype == torch.bfloat16 else torch.uint8).clone() for o in outs]
+
+    epis = [_lib.EPI_GATE_RESID] if cfg in (16, 17) else [_lib.EPI_BF16, _lib.EPI_GATE_RESID, _lib.EPI_GELU_QUANT]
+    for epi in epis:
+        for table in ((True,) if cfg == 18 else (False, True)) if epi == _lib.EPI_GELU_QUANT else (False,):
+            if table and cfg not in (13, 18, -1):
+                continue  # the table epilogue exists in the 256 x 256 LDS-epilogue kernels only
+            ref = launch(epi, False, False, table)
+            got = launch(epi, True, epi == _lib.EPI_GELU_QUANT, table)
+            for x, y in zip(ref, got):
+                assert torch.equal(x, y), f"tile config {cfg}, epilogue {epi}, table {table}: row-pair activations change the result ({(x != y).float().mean().item():.2e} of the elements)"
+            if epi == _lib.EPI_GELU_QUANT:  # mixed: plain A, paired output
+                for x, y in zip(ref, launch(epi, False, True, table)):
+                    assert torch.equal(x, y)
+    if cfg == -1:
+        g = ops.make_group(ap[0].data_ptr(), w[0].data_ptr(), bias.data_ptr(), sar.data_ptr(), one.data_ptr(), resid[0].data_ptr(), Ms[0], K, N, a_pairs=True)
+        with pytest.raises(RuntimeError, match="row-pair"):
+            ops.gemm_grouped([g], N, K, True, E5M2, _lib.EPI_BF16, 100)
+
+
 def test_quantising_epilogue_computed_vs_table_exhaustive(ops, dev):
     """is the 64 KiB table (fluxmi_gemm_group_t.q_lut, built by build_qlut_kernel) bit-identical to the epilogue the
     kernels COMPUTE when no table is given?  Exhaustive over all 65536 bf16 inputs (A = 0, bias = every pattern) for every kernel that has a
