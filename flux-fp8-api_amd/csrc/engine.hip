@@ -181,6 +181,8 @@ int ensure_pairs(E* e, hipStream_t s) {
       off[li] = (long long)total;
       total += ((size_t)l.N * l.K + 255) & ~(size_t)255;
     };
+    // (proj: the ping-pong kernel, tile config 13, honours W_pairs since round 6, but copies of the proj weights measured nothing in the step --
+    // 38.71 / 38.74 / 38.76 ms with, 38.71 / 38.75 / 38.71 without, profiles/r06_act_pairs.txt -- so they are not made)
     for (int i = 0; i < e->d.depth; ++i)
       for (int sl : {D_IMG_QKV, D_TXT_QKV, D_IMG_MLP0, D_TXT_MLP0, D_IMG_MLP2, D_TXT_MLP2}) want(DLi(e, i, sl));
     for (int i = 0; i < e->d.depth_single; ++i) { want(SLi(e, i, S_LIN1)); want(SLi(e, i, S_LIN2)); }
@@ -645,6 +647,7 @@ int double_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
             FluxmiGemmGroup g = mk_group(l, l.kind ? (const void*)(attn8 + r0 * H) : (const void*)(attnbf + r0 * H), H, x + r0 * H, H, rows[st]);
             g.resid = x + r0 * H; g.ldr = H; g.gate = mods[st] + (long long)b * MC + 2 * H;
             g.a_pairs = ap;
+            g.W_pairs = pairs_of(e, li_p[st]);
             gs.push_back(g);
           }
         FLUXMI_TRY(run_gemm(gs, H, H, e->lin[li_p[0]].kind, e->lin[li_p[0]].in_fmt, FLUXMI_EPI_GATE_RESID, s));

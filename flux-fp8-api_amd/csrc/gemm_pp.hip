@@ -84,6 +84,10 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
   const long long a_row_b = (long long)G.lda * EB, w_row_b = (long long)P.K * EB;
   const bool a_pairs = FP8 && !SPLITK && G.a_pairs != 0;
   const int a_kstep = a_pairs ? 128 : 64;
+  // W in the row-pair layout when the caller has one (fluxmi_gemm_group_t.W_pairs, as in the persistent and the one-wave kernels)
+  const bool w_pairs = FP8 && !SPLITK && G.W_pairs != nullptr;
+  const int w_kstep = w_pairs ? 128 : 64;
+  const unsigned char* w_base = (const unsigned char*)(w_pairs ? G.W_pairs : G.W);
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
@@ -96,11 +100,11 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
 #pragma unroll
   for (int i = 0; i < IW; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-    srcW[i] = (const unsigned char*)G.W + ((long long)(n0 + row) * P.K) * EB + slot * 16 + (long long)k_begin * 64;
-    w_voff[i] = (unsigned)(row * w_row_b + slot * 16);
+    srcW[i] = w_pairs ? w_base + f8_act_off(n0 + row, P.K, slot * 16, 1) : w_base + ((long long)(n0 + row) * P.K) * EB + slot * 16 + (long long)k_begin * 64;
+    w_voff[i] = w_pairs ? (unsigned)((row >> 1) * 2 * w_row_b + (row & 1) * 64 + slot * 16) : (unsigned)(row * w_row_b + slot * 16);
   }
   const __amdgpu_buffer_rsrc_t ars = make_rsrc(G.A, (unsigned)min((long long)M * a_row_b, 0xffffffffLL));
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(G.W, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(w_base, (unsigned)min((long long)P.N * w_row_b, 0xffffffffLL));
   const unsigned a_soff0 = uni_u32((unsigned)(m0 * a_row_b)), w_soff0 = uni_u32((unsigned)(n0 * w_row_b));
   auto stage = [&](int kt, int slot) {
     unsigned char* dA = smem + slot * STAGE + wave * 1024;
@@ -109,13 +113,13 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
 #pragma unroll
       for (int i = 0; i < IA; ++i) dma16_buf(ars, dA + NT * 16 * i, a_voff[i], a_soff0 + kt * a_kstep);
 #pragma unroll
-      for (int i = 0; i < IW; ++i) dma16_buf(wrs, dW + NT * 16 * i, w_voff[i], w_soff0 + kt * 64);
+      for (int i = 0; i < IW; ++i) dma16_buf(wrs, dW + NT * 16 * i, w_voff[i], w_soff0 + kt * w_kstep);
     } else {
       const long long koff = (long long)kt * 64;
 #pragma unroll
       for (int i = 0; i < IA; ++i) glds16(srcA[i] + (long long)kt * a_kstep, dA + NT * 16 * i);
 #pragma unroll
-      for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, dW + NT * 16 * i);
+      for (int i = 0; i < IW; ++i) glds16(srcW[i] + (long long)kt * w_kstep, dW + NT * 16 * i);
     }
   };
 

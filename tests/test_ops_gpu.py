@@ -1209,9 +1209,11 @@ def test_gemm_persistent_row_pair_weights(ops, dev):
         assert torch.equal(x, y), f"output {i} differs with W_pairs"
 
 
-def test_gemm_one_wave_kernel_row_pair_weights(ops, dev):
-    """W_pairs through the one-wave-per-SIMD kernel (tile config 16: the step's mlp.2 / linear2 launches): gate * y + x in place, ragged rows,
-    two groups of which only ONE has a row-pair copy (a per-workgroup choice there); every byte equals the launch without copies."""
+@pytest.mark.parametrize("cfg", [16, 13])
+def test_gemm_one_wave_kernel_row_pair_weights(ops, dev, cfg):
+    """W_pairs through the one-wave-per-SIMD kernel (tile config 16: the step's mlp.2 / linear2 launches) and, since round 6, the ping-pong
+    kernel (13: the proj launches): gate * y + x in place, ragged rows, two groups of which only ONE has a row-pair copy (a per-workgroup
+    choice there); every byte equals the launch without copies."""
     from fluxmi import _lib
 
     torch.manual_seed(6)
@@ -1233,7 +1235,7 @@ def test_gemm_one_wave_kernel_row_pair_weights(ops, dev):
                 kw.update(W_pairs=wp.data_ptr())
             outs.append(o)
             groups.append(ops.make_group(a.data_ptr(), w.data_ptr(), None, one.data_ptr(), one.data_ptr(), o.data_ptr(), M, K, N, **kw))
-        ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_GATE_RESID, 16)
+        ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_GATE_RESID, cfg)
         torch.cuda.synchronize()
         return outs
 
