@@ -200,6 +200,10 @@ int fluxmi_gemm_dispatch(const FluxmiGemmGroup* gs_in, int n_in, int N, int K, i
     const long long tn = N / 256;
     long long T = 0;
     for (int m : ms) T += (long long)((m + 255) / 256) * tn;
+    // multi-round fp8 launches run on the PERSISTENT kernel, whose last, partial round costs what its tiles cost: peeling only pays when that
+    // round is thin.  Measured in-step after the row-pair activations (profiles/r06_act_pairs.txt section 5): Flux-dev 1024^2 mlp.0, 864 tiles
+    // = 3 rounds + 96 tiles (37 % of a round): the peel LOSES 0.4 % per step; 768^2, 528 tiles = 2 rounds + 16 tiles: it gains 1.9 %
+    if (is_fp8 && act_fmt == FLUXMI_E5M2 && tun.gemm_persist && T > 256 && T % 256 > 64) return 0;
     double best = (double)((T + 255) / 256) - 0.15;
     int best_k = 0;
     long long peeled = 0;
