@@ -153,17 +153,30 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
     t256 *= N / 256;
     if (t256 > 256) cfg = fluxmi_tuning().gemm_persist == 2 ? 19 : 18;  // 2: the timing build (probes: fluxmi_gemm_debug_buffer)
   }
-  // gate*y+x launches of the one-wave-per-SIMD kernel whose 256-row tiling fills less than one round of the 256 CUs (Flux-dev 768^2: M = 2816 ->
-  // 11 x 12 = 132 tiles on mlp.2 / linear2): 192-row tiles (config 17, same kernel, same bits) are three quarters of the work each, and
-  // 15 x 12 = 180 of them still run in one round.  Taken when rounds x tile work drops by more than 5 % (the smaller tile reads 8 % more
-  // fragment bytes per MFMA); fluxmi_tuning_t.gemm_tile192 = 0 turns it off.
+  // gate*y+x launches of the one-wave-per-SIMD kernel whose 256-row tiling fills less than one round of the 256 CUs: lower tiles of the same
+  // kernel (same bits).  Flux-dev 768^2 (M = 2816 -> 11 x 12 = 132 tiles on mlp.2 / linear2): 192-row tiles (config 17) are three quarters of
+  // the work each and 15 x 12 = 180 of them still run in one round (round 5, -13.6 % per launch).  Flux-dev 1024^2 linear2 (M = 4608 -> 216
+  // tiles): 224-row tiles (config 20, round 6: the four waves side by side along N) give 21 x 12 = 252 tiles = one round at 7/8 of the work
+  // (isolated, cold operands: 203.7 -> 181.0 us).  Cost = rounds x tile height x a per-height factor for the fragment bytes per MFMA (the
+  // 192-row 2 x 2 grid reads 8 % more, the 224-row 1 x 4 grid 29 % more but keeps all four SIMDs equally loaded); taken when it drops by more
+  // than 5 %.  fluxmi_tuning_t.gemm_tile192 = 0 turns both off.
   if (cfg == 16 && force_cfg < 0 && is_fp8 && act_fmt == FLUXMI_E5M2 && epi == FLUXMI_EPI_GATE_RESID && fluxmi_tuning().gemm_cfg < 0 &&
-      fluxmi_tuning().gemm_tile192 && fluxmi_gemm_tile_ok(N, K, is_fp8, 17)) {
-    long long t256 = 0, t192 = 0;
-    for (int i = 0; i < n; ++i) { t256 += (gs[i].M + 255) / 256; t192 += (gs[i].M + 191) / 192; }
-    t256 *= N / 256; t192 *= N / 256;
-    const double c256 = (double)((t256 + 255) / 256), c192 = (double)((t192 + 255) / 256) * 0.75 * 1.04;
-    if (c192 < 0.95 * c256) cfg = 17;
+      fluxmi_tuning().gemm_tile192) {
+    auto tiles_of = [&](int bm) {
+      long long t = 0;
+      for (int i = 0; i < n; ++i) t += (gs[i].M + bm - 1) / bm;
+      return t * (N / 256);
+    };
+    const double c256 = (double)((tiles_of(256) + 255) / 256);
+    double best = 0.95 * c256;
+    if (fluxmi_gemm_tile_ok(N, K, is_fp8, 17)) {
+      const double c = (double)((tiles_of(192) + 255) / 256) * 0.75 * 1.04;
+      if (c < best) { best = c; cfg = 17; }
+    }
+    if (fluxmi_gemm_tile_ok(N, K, is_fp8, 20)) {
+      const double c = (double)((tiles_of(224) + 255) / 256) * 0.875 * 1.03;
+      if (c < best) { best = c; cfg = 20; }
+    }
   }
   const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0);
   if (cfg < 0 || !split_ok) return fluxmi_launch_gemm_generic(p, is_fp8, act_fmt, s);

@@ -214,7 +214,9 @@ __device__ __forceinline__ void lds_epilogue(const FluxmiGemmGroup& G, v16f (&ac
   load_bias(0, braw[0]);
   // gate*y + x: the residual rows of phase 2 in batches of RB rows (row clamped instead of guarded: the load is unconditional, the store
   // is not); batch 0 is issued here and flies under phase 1, batch b+1 is issued before batch b is consumed
-  constexpr int RPP0 = 64 / CH, NIT = (TM * 32) / RPP0, RB = NIT < 8 ? NIT : 8;
+  constexpr int RPP0 = 64 / CH, NIT = (TM * 32) / RPP0;
+  constexpr int RB = NIT < 8 ? NIT : NIT % 8 == 0 ? 8 : NIT % 7 == 0 ? 7 : NIT % 6 == 0 ? 6 : NIT % 5 == 0 ? 5 : 4;  // batches must tile the NIT passes
+  static_assert(NIT % RB == 0, "residual batches must cover every pass");
   uint4 rres[2][EPI == FLUXMI_EPI_GATE_RESID ? RB : 1];
   uint4 graw = make_uint4(0, 0, 0, 0);
   auto load_resid = [&](int b, uint4 (&dst)[EPI == FLUXMI_EPI_GATE_RESID ? RB : 1]) {

@@ -28,24 +28,32 @@
 
 namespace {
 
-struct W1Frags { v8i fw[4]; v8i fa[4]; };
+template <int TN, int TM> struct W1FragsT { v8i fw[TN]; v8i fa[TM]; };
 
 // ESEL >= 0: the kernel is compiled for ONE epilogue (the hot ones get their own instantiation: with the run-time switch over six inlined
 // epilogues hipcc allocates registers for all of them at once and spilled ~110 ACCUMULATOR pairs to scratch right after the K loop -- on every
 // path, each reload behind an s_waitcnt vmcnt(0)); ESEL = -1 keeps the switch (cold epilogues)
-template <bool FP8, int ACT_FMT, int ESEL, int TM_ = 4>
+// WM_ (round 6): waves along M.  2 = the 2 x 2 wave grid above (wave tile TM*32 x 128).  1 = the four waves side by side along N, each owning
+// ALL TM*32 rows of the tile and 64 columns: tiles of 32 * TM rows for ANY TM -- tile config 20 = 224 x 256 (TM = 7) is the exact fit of the
+// step's linear2 launch (M = 4608: 21 row tiles x 12 = 252 tiles = ONE round of the 256 CUs at 7/8 of a 256-row tile's work, instead of
+// 216 tiles on 256 CUs); 14 MFMAs per K-step read 18 fragment halves (9/7 of the 2 x 2 grid's LDS bytes per MFMA).  Same K loop, same
+// MFMAs in the same order per output: every bit equals config 16's.
+template <bool FP8, int ACT_FMT, int ESEL, int TM_ = 4, int WM_ = 2>
 __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams P) {
-  constexpr int TM = TM_, TN = 4, BM = 2 * TM * 32, BN = 256, NT = 256, NS = 4;
-  constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
-  constexpr int NA = TM;        // LDS-DMA pieces of A per wave per K-step (BM rows x 4 chunks / 256 lanes), 4 of W
+  constexpr int TM = TM_, TN = WM_ == 2 ? 4 : 2, BM = WM_ * TM * 32, BN = 256, NT = 256, NS = 4;
+  constexpr int A_ROWS = ((BM + 63) / 64) * 64;  // LDS-DMA moves 64 rows per piece: a 224-row tile stages 256 (the last 32 are never read)
+  constexpr int A_BYTES = A_ROWS * 64, W_BYTES = BN * 64, STAGE = A_BYTES + W_BYTES;
+  constexpr int NA = A_ROWS / 64;  // LDS-DMA pieces of A per wave per K-step (64 rows x 4 chunks = 256 lanes each), 4 of W
   constexpr int LPT = NA + 4;   // pieces per wave per K-step
-  constexpr int NFR = 4 + TM;   // fragments per K-step: 4 W tiles + TM A tiles, two 16-byte halves each
+  constexpr int NFR = TN + TM;  // fragments per K-step: TN W tiles + TM A tiles, two 16-byte halves each
   constexpr int EB = FP8 ? 1 : 2;
+  using W1Frags = W1FragsT<TN, TM>;
+  static_assert(STAGE + (TM > TN ? TM : TN) * 2048 <= 65536, "ds_read immediates are 16 bits");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WM_ == 2 ? wave >> 1 : 0, wn = WM_ == 2 ? wave & 1 : wave;
   const int l31 = lane & 31, hi = lane >> 5;
 
   const int tiles_n = P.N / BN;
@@ -107,7 +115,7 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   unsigned a_lo[2], a_hi[2], w_lo[2], w_hi[2];
   {
     const int ra = wm * (TM * 32) + l31, ka = (ra >> 2) & 3;
-    const int rw = wn * 128 + l31, kw = (rw >> 2) & 3;
+    const int rw = wn * (TN * 32) + l31, kw = (rw >> 2) & 3;
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       a_lo[h2] = (unsigned)(h2 * 2 * STAGE + ra * 64 + (((hi * 2) ^ ka) << 4));
@@ -116,12 +124,12 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
       w_hi[h2] = (unsigned)(h2 * 2 * STAGE + A_BYTES + rw * 64 + (((hi * 2 + 1) ^ kw) << 4));
     }
   }
-  // half `hf` (0 = low 16 B, 1 = high 16 B) of fragment `f` (0..3 = W tiles, 4..4+TM-1 = A tiles) of ring slot `slot`
+  // half `hf` (0 = low 16 B, 1 = high 16 B) of fragment `f` (0..TN-1 = W tiles, TN..TN+TM-1 = A tiles) of ring slot `slot`
   auto read_half = [&](W1Frags& F, int slot, int f, int hf) {
-    const int h2 = slot >> 1, imm = (slot & 1) * STAGE + (f & 3) * 2048;
-    const unsigned base = f < 4 ? (hf ? w_hi[h2] : w_lo[h2]) : (hf ? a_hi[h2] : a_lo[h2]);
+    const int h2 = slot >> 1, imm = (slot & 1) * STAGE + (f < TN ? f : f - TN) * 2048;
+    const unsigned base = f < TN ? (hf ? w_hi[h2] : w_lo[h2]) : (hf ? a_hi[h2] : a_lo[h2]);
     const v4i v = *(const v4i*)(smem + base + imm);
-    v8i& dst = f < 4 ? F.fw[f] : F.fa[f - 4];
+    v8i& dst = f < TN ? F.fw[f] : F.fa[f - TN];
     dst[hf * 4 + 0] = v[0]; dst[hf * 4 + 1] = v[1]; dst[hf * 4 + 2] = v[2]; dst[hf * 4 + 3] = v[3];
   };
   auto mma = [&](const W1Frags& F, int i, int j) {
@@ -167,7 +175,7 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
     constexpr int NSLOT = TM * TN, NRD = 2 * NFR;
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-      mma(cur, s >> 2, s & 3);
+      mma(cur, s / TN, s % TN);
       fence();
       // next fragments: W halves first (needed by every MFMA row), then A
       read_half(nxt, SN, s >> 1, s & 1);
@@ -189,8 +197,8 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   const float qs = load_scale_u(G.q_scale);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the trailing don't-care refills must land before the ring is reused
   __builtin_amdgcn_s_barrier();
-  unsigned char* wbuf = smem + wave * (TM * 32 * 128 * 2);
-  const int mw = m0 + wm * (TM * 32), nw = n0 + wn * 128;
+  unsigned char* wbuf = smem + wave * (TM * 32 * TN * 32 * 2);
+  const int mw = m0 + wm * (TM * 32), nw = n0 + wn * (TN * 32);
   if constexpr (ESEL >= 0) {
     lds_epilogue<ESEL, ACT_FMT, TM, TN>(G, acc, s, qs, wbuf, mw, nw, M, lane);
   } else {
@@ -206,9 +214,9 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
   }
 }
 
-template <bool FP8, int ACT, int ESEL = -1, int TM_ = 4>
+template <bool FP8, int ACT, int ESEL = -1, int TM_ = 4, int WM_ = 2>
 int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
-  constexpr int BM = 64 * TM_, BN = 256;
+  constexpr int BM = 32 * WM_ * TM_, BN = 256, A_ROWS = ((BM + 63) / 64) * 64;
   int t = 0;
   for (int i = 0; i < p.n_groups; ++i) {
     p.g[i].m_tile_start = t;
@@ -221,8 +229,8 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
 #define W1_GROUP_M 6
 #endif
   p.group_m = W1_GROUP_M;
-  constexpr int SMEM = 4 * (BM + BN) * 64;
-  auto kern = gemm_w1_kernel<FP8, ACT, ESEL, TM_>;
+  constexpr int SMEM = 4 * (A_ROWS + BN) * 64;
+  auto kern = gemm_w1_kernel<FP8, ACT, ESEL, TM_, WM_>;
   static bool attr_set = false;
   if (!attr_set) {
     FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
@@ -231,8 +239,10 @@ int launch_w1(FluxmiGemmParams& p, hipStream_t s) {
   const int nblk = t * (p.N / BN);
   if (nblk == 0) return 0;
   // a launch that leaves CUs idle in its last round carries the pending weight prefetch on them (fluxmi_internal.h, FluxmiPrefetch)
+  // (the engine sizes pf.wgs for the 256-row tiling; a lower tile that fills the round leaves fewer idle CUs -- a handful of workgroups must not
+  // be left with the whole prefetch: 4 workgroups reading 66 MB took 340 us and ended the launch.  Then the prefetch is dropped.)
   const int idle = (256 - nblk % 256) % 256;
-  const int extra = p.pf.n > 0 ? std::min(p.pf.wgs, idle) : 0;
+  const int extra = (p.pf.n > 0 && idle >= p.pf.wgs) ? p.pf.wgs : 0;
   if (!extra) p.pf.n = 0;
   hipLaunchKernelGGL(kern, dim3(nblk + extra), dim3(256), SMEM, s, p);
   FLUXMI_LAUNCH_CHECK();
@@ -259,6 +269,20 @@ int fluxmi_launch_gemm_w1_192(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipS
   if (is_fp8) return launch_w1<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, 3>(p, s);
   if (p.epi == FLUXMI_EPI_GATE_RESID) return launch_w1<false, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, 3>(p, s);
   return launch_w1<false, FLUXMI_FMT_E5M2, FLUXMI_EPI_BF16, 3>(p, s);
+}
+
+// config 20 (round 6) = 224 x 256 tiles, the four waves side by side along N (wave tile 224 x 64): fp8 x e5m2 operands with the gate*y+x epilogue
+// -- the exact fit of Flux-dev 1024^2 linear2 (21 x 12 = 252 tiles for 256 CUs)
+int fluxmi_launch_gemm_w1_224(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {
+  FLUXMI_REQUIRE(is_fp8 && act_fmt == FLUXMI_FMT_E5M2 && p.epi == FLUXMI_EPI_GATE_RESID,
+                 "gemm tile config 20 (224x256 one-wave-per-SIMD tiles): fp8 x e5m2 operands with the gate*y+x epilogue (fp8 %d, epi %d)", is_fp8, p.epi);
+  for (int i = 0; i < p.n_groups; ++i) {
+    FLUXMI_REQUIRE(!p.g[i].vt_out && !p.g[i].k_out, "gemm tile config 20: no fused K / V^T outputs");
+    FLUXMI_REQUIRE((long long)p.g[i].M * p.g[i].lda < (1LL << 32) && (long long)p.N * p.K < (1LL << 32), "gemm_w1: operand larger than 4 GiB");
+  }
+  p.pf = fluxmi_take_prefetch();
+  if (!fluxmi_tuning().prefetch) p.pf.n = 0;
+  return launch_w1<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, 7, 1>(p, s);
 }
 
 // config 16 = 256x256, one wave per SIMD

@@ -516,6 +516,49 @@ def test_attention_is_batch_invariant_at_thin_last_rounds(ops, dev, B):
     assert torch.isfinite(whole.float()).all()
 
 
+@pytest.mark.parametrize("Ms", [(4608,), (2816,), (1000, 333), (4096, 512)])
+def test_gemm_tile_config_20_matches_16(ops, dev, Ms):
+    """Tile config 20 (round 6) = the one-wave-per-SIMD kernel with its four waves side by side along N (wave tile 224 x 64): 224 x 256 tiles, the
+    exact fit of Flux-dev 1024^2 linear2 (M = 4608: 21 x 12 = 252 tiles = one round of the 256 CUs).  Same K loop, same MFMAs in the same order per
+    output element: every byte must equal config 16's -- ragged last tiles (4608 = 20 x 224 + 128), two groups with their own weights, plain
+    and ROW-PAIR activations / weights.                                           float8_quantize.py:284-292, flux_model.py:484"""
+    from fluxmi import _lib
+
+    torch.manual_seed(33)
+    N, K = 3072, 15360 if len(Ms) == 1 else 8192
+    one = torch.tensor(1.0, device=dev)
+    a = [(torch.randn(M, K, device=dev) * 2).to(torch.float8_e5m2) for M in Ms]
+    w = [(torch.randn(N, K, device=dev) * 0.5).to(torch.float8_e4m3fn) for _ in Ms]
+    bias = torch.randn(N, device=dev).bfloat16()
+    gate = torch.randn(N, device=dev).bfloat16()
+    resid = [torch.randn(M, N, device=dev).bfloat16() for M in Ms]
+    sar = torch.tensor(0.013, device=dev)
+    even = all(M % 2 == 0 for M in Ms)
+    ap = [ops.pair_rows(x.view(torch.uint8)).view(torch.float8_e5m2) for x in a] if even else None
+    wp = [ops.pair_rows(x.view(torch.uint8)) for x in w]
+
+    def launch(cfg, pairs=False):
+        outs, groups = [], []
+        for gi, M in enumerate(Ms):
+            o = resid[gi].clone()
+            outs.append(o)
+            groups.append(ops.make_group((ap if pairs else a)[gi].data_ptr(), w[gi].data_ptr(), bias.data_ptr() if gi == 0 else None, sar.data_ptr(), one.data_ptr(),
+                                         o.data_ptr(), M, K, N, gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N, a_pairs=pairs,
+                                         W_pairs=wp[gi].data_ptr() if pairs else None))
+        ops.gemm_grouped(groups, N, K, True, E5M2, _lib.EPI_GATE_RESID, cfg)
+        torch.cuda.synchronize()
+        return [o.view(torch.int16).clone() for o in outs]
+
+    ref = launch(16)
+    for x, y in zip(ref, launch(20)):
+        assert torch.equal(x, y), f"tile config 20 differs from config 16 (Ms = {Ms})"
+    if even:
+        for x, y in zip(ref, launch(20, pairs=True)):
+            assert torch.equal(x, y), f"tile config 20 with row-pair operands differs from config 16 (Ms = {Ms})"
+    for x in ref:
+        assert torch.isfinite(x.view(torch.bfloat16).float()).all()
+
+
 @pytest.mark.parametrize("epi_name", ["bf16", "gate_resid"])
 def test_gemm_tile_config_17_bf16(ops, dev, epi_name):
     """Tile config 17 with bf16 operands (nn.Linear flows: Flux-schnell 256^2 linear1 at M = 512 -> 3 x 84 = 252 tiles of 192 rows instead of 168 of
