@@ -173,9 +173,14 @@ static int run_gemm_chunk(const FluxmiGemmGroup* gs, int n, int N, int K, int is
       const double c = (double)((tiles_of(192) + 255) / 256) * 0.75 * 1.04;
       if (c < best) { best = c; cfg = 17; }
     }
-    if (fluxmi_gemm_tile_ok(N, K, is_fp8, 20)) {
+    const bool lower = fluxmi_tuning().gemm_tile192 == 1;  // 2 = config 17 only (A/B of the round-6 heights)
+    if (lower && fluxmi_gemm_tile_ok(N, K, is_fp8, 20)) {
       const double c = (double)((tiles_of(224) + 255) / 256) * 0.875 * 1.03;
       if (c < best) { best = c; cfg = 20; }
+    }
+    if (lower && fluxmi_gemm_tile_ok(N, K, is_fp8, 21)) {  // 160-row tiles (768^2: 18 x 12 = 216 tiles)
+      const double c = (double)((tiles_of(160) + 255) / 256) * 0.625 * 1.08;
+      if (c < best) { best = c; cfg = 21; }
     }
   }
   const bool split_ok = epi != FLUXMI_EPI_SPLIT || cfg < 0 || (p.g[0].split_n % fluxmi_gemm_tile_bn(cfg) == 0);

@@ -87,6 +87,7 @@ void fluxmi_log_tuning(const char* why);
 int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg);
 int fluxmi_launch_gemm_w1_192(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);  // tile config 17 (gemm_w1.hip)
 int fluxmi_launch_gemm_w1_224(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);  // tile config 20 (gemm_w1.hip)
+int fluxmi_launch_gemm_w1_160(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);  // tile config 21 (gemm_w1.hip)
 int fluxmi_gemm_tile_bn(int cfg);
 int fluxmi_gemm_tile_bm(int cfg);
 int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int tile_cfg, hipStream_t s);

@@ -321,14 +321,14 @@ int launch_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
 int fluxmi_launch_gemm_pp(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hipStream_t s);
 int fluxmi_launch_gemm_w1(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
 
-int fluxmi_gemm_tile_bn(int cfg) { return cfg == 2 ? 128 : cfg == 15 ? 64 : (cfg == 13 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19 || cfg == 20) ? 256 : 0; }
-int fluxmi_gemm_tile_bm(int cfg) { return (cfg == 2 || cfg == 15) ? 128 : cfg == 17 ? 192 : cfg == 20 ? 224 : (cfg == 13 || cfg == 16 || cfg == 18 || cfg == 19) ? 256 : 0; }
+int fluxmi_gemm_tile_bn(int cfg) { return cfg == 2 ? 128 : cfg == 15 ? 64 : (cfg == 13 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19 || cfg == 20 || cfg == 21) ? 256 : 0; }
+int fluxmi_gemm_tile_bm(int cfg) { return (cfg == 2 || cfg == 15) ? 128 : cfg == 17 ? 192 : cfg == 20 ? 224 : cfg == 21 ? 160 : (cfg == 13 || cfg == 16 || cfg == 18 || cfg == 19) ? 256 : 0; }
 
 int fluxmi_gemm_tile_ok(int N, int K, int is_fp8, int cfg) {
   const int bn = fluxmi_gemm_tile_bn(cfg);
   if (!bn) return 0;
   const int kb = K * (is_fp8 ? 1 : 2);
-  const int kstep = (cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19 || cfg == 20) ? 256 : cfg == 13 ? 64 : 128;
+  const int kstep = (cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19 || cfg == 20 || cfg == 21) ? 256 : cfg == 13 ? 64 : 128;
   if ((cfg == 18 || cfg == 19) && kb < 512) return 0;
   return (N % bn == 0) && (kb % kstep == 0) && kb >= kstep;
 }
@@ -361,6 +361,7 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
   if (cfg == 16) return fluxmi_launch_gemm_w1(p, is_fp8, act_fmt, s);
   if (cfg == 17) return fluxmi_launch_gemm_w1_192(p, is_fp8, act_fmt, s);
   if (cfg == 20) return fluxmi_launch_gemm_w1_224(p, is_fp8, act_fmt, s);
+  if (cfg == 21) return fluxmi_launch_gemm_w1_160(p, is_fp8, act_fmt, s);
   if (cfg == 13) return fluxmi_launch_gemm_pp(p, is_fp8, act_fmt, cfg, s);
   if (is_fp8) {
     if (act_fmt == FLUXMI_FMT_E5M2) return launch_cfg<true, FLUXMI_FMT_E5M2>(p, cfg, s);

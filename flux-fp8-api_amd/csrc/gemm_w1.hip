@@ -181,7 +181,10 @@ __global__ void __launch_bounds__(256, 1) gemm_w1_kernel(const FluxmiGemmParams 
       read_half(nxt, SN, s >> 1, s & 1);
       if (s + NSLOT < NRD) read_half(nxt, SN, (s + NSLOT) >> 1, (s + NSLOT) & 1);
       if ((s & 1) == 0) dma_piece(s >> 1, SR, kt + 3);
-      if (s == NSLOT - 1 && (NSLOT >> 1) < LPT) dma_piece(NSLOT >> 1, SR, kt + 3);
+      if (s == NSLOT - 1) {  // the pieces the even slots did not cover (TM = 3: the seventh; the 1 x 4 wave grid with TM = 5: the sixth and seventh)
+#pragma unroll
+        for (int q = (NSLOT + 1) >> 1; q < LPT; ++q) dma_piece(q, SR, kt + 3);
+      }
       fence();
     }
   };
@@ -283,6 +286,19 @@ int fluxmi_launch_gemm_w1_224(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipS
   p.pf = fluxmi_take_prefetch();
   if (!fluxmi_tuning().prefetch) p.pf.n = 0;
   return launch_w1<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, 7, 1>(p, s);
+}
+// config 21 = the same wave layout on 160 x 256 tiles (wave tile 160 x 64): Flux-dev 768^2 mlp.2 / linear2 (M = 2816: 18 x 12 = 216 tiles of 5/8 of the
+// work instead of config 17's 180 tiles of 6/8)
+int fluxmi_launch_gemm_w1_160(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {
+  FLUXMI_REQUIRE(is_fp8 && act_fmt == FLUXMI_FMT_E5M2 && p.epi == FLUXMI_EPI_GATE_RESID,
+                 "gemm tile config 21 (160x256 one-wave-per-SIMD tiles): fp8 x e5m2 operands with the gate*y+x epilogue (fp8 %d, epi %d)", is_fp8, p.epi);
+  for (int i = 0; i < p.n_groups; ++i) {
+    FLUXMI_REQUIRE(!p.g[i].vt_out && !p.g[i].k_out, "gemm tile config 21: no fused K / V^T outputs");
+    FLUXMI_REQUIRE((long long)p.g[i].M * p.g[i].lda < (1LL << 32) && (long long)p.N * p.K < (1LL << 32), "gemm_w1: operand larger than 4 GiB");
+  }
+  p.pf = fluxmi_take_prefetch();
+  if (!fluxmi_tuning().prefetch) p.pf.n = 0;
+  return launch_w1<true, FLUXMI_FMT_E5M2, FLUXMI_EPI_GATE_RESID, 5, 1>(p, s);
 }
 
 // config 16 = 256x256, one wave per SIMD

@@ -40,7 +40,7 @@ int validate(const fluxmi_tuning_t& t) {
       {"gemm_splitk", t.gemm_splitk, 0, 1}, {"gemm_hybrid", t.gemm_hybrid, 0, 1}, {"gemm_esel", t.gemm_esel, 0, 1}, {"gemm_persist", t.gemm_persist, 0, 2},
       {"attn_var", t.attn_var, 0, 3},       {"attn_abl", t.attn_abl, 0, 15},      {"attn_f16k", t.attn_f16k, 0, 1}, {"qlut", t.qlut, 0, 1},
       {"roctx", t.roctx, 0, 1},             {"prefetch", t.prefetch, 0, 3},       {"w_pairs", t.w_pairs, 0, 1},     {"log", t.log, 0, 1},
-      {"attn_split", t.attn_split, 0, 2}, {"gemm_tile192", t.gemm_tile192, 0, 1}, {"a_pairs", t.a_pairs, 0, 1}};
+      {"attn_split", t.attn_split, 0, 2}, {"gemm_tile192", t.gemm_tile192, 0, 2}, {"a_pairs", t.a_pairs, 0, 1}};
   for (const auto& k : sw) FLUXMI_REQUIRE(k.v >= k.lo && k.v <= k.hi, "tuning: %s %d outside [%d, %d]", k.name, k.v, k.lo, k.hi);
   return 0;
 }
@@ -88,7 +88,7 @@ void init_from_env() {
     auto fix = [](int& v, int lo, int hi, int dflt) { if (v < lo || v > hi) v = dflt; };
     fix(t.gemm_splitk, 0, 1, 1); fix(t.gemm_hybrid, 0, 1, 1); fix(t.gemm_esel, 0, 1, 1); fix(t.gemm_persist, 0, 2, 1);
     fix(t.attn_var, 0, 3, 0); fix(t.attn_abl, 0, 15, 0); fix(t.attn_f16k, 0, 1, 1); fix(t.qlut, 0, 1, 1); fix(t.roctx, 0, 1, 0);
-    fix(t.prefetch, 0, 3, 1); fix(t.w_pairs, 0, 1, 1); fix(t.log, 0, 1, 0); fix(t.attn_split, 0, 2, 1); fix(t.gemm_tile192, 0, 1, 1); fix(t.a_pairs, 0, 1, 1);
+    fix(t.prefetch, 0, 3, 1); fix(t.w_pairs, 0, 1, 1); fix(t.log, 0, 1, 0); fix(t.attn_split, 0, 2, 1); fix(t.gemm_tile192, 0, 2, 1); fix(t.a_pairs, 0, 1, 1);
   }
   g_tuning = t;
   if (t.log) log_tuning(t, "environment");

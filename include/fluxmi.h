@@ -141,7 +141,9 @@ typedef struct fluxmi_tuning {
   int log;               /* FLUXMI_LOG           1: print the struct to stderr when it is resolved / set / an engine is created */
   int gemm_tile192;      /* FLUXMI_GEMM_TILE192  1 (default): gate*y+x launches of the one-wave-per-SIMD kernel (K >= 8192) whose 256-row tiles fill less
                                                  than one round of the CUs run on 192 x 256 tiles (tile config 17; same bits, 36 % more tiles of
-                                                 three quarters the work: Flux-dev 768^2 mlp.2 / linear2, 132 -> 180 tiles) */
+                                                 three quarters the work: Flux-dev 768^2 mlp.2 / linear2, 132 -> 180 tiles); round 6: also 224-row
+                                                 (config 20: 1024^2 linear2, 216 -> 252 tiles) and 160-row tiles (config 21: 768^2, 216 tiles), the
+                                                 four waves side by side along N; 2 = config 17 only (A/B), 0 = 256-row tiles only */
   int attn_split;        /* FLUXMI_ATTN_SPLIT    1 (default): attention launches whose last round of workgroups is THIN (at most 8 of an XCD's
                                                  32 CUs busy: 264 tasks on 256 CUs at Flux-dev 768^2) run that round's tasks as pieces of
                                                  their key range and merge the partial softmax states (fp32 log-sum-exp in a fixed order:

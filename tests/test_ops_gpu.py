@@ -550,11 +550,12 @@ def test_gemm_tile_config_20_matches_16(ops, dev, Ms):
         return [o.view(torch.int16).clone() for o in outs]
 
     ref = launch(16)
-    for x, y in zip(ref, launch(20)):
-        assert torch.equal(x, y), f"tile config 20 differs from config 16 (Ms = {Ms})"
-    if even:
-        for x, y in zip(ref, launch(20, pairs=True)):
-            assert torch.equal(x, y), f"tile config 20 with row-pair operands differs from config 16 (Ms = {Ms})"
+    for cfg in (20, 21):  # 21 = the same wave layout on 160-row tiles (768^2)
+        for x, y in zip(ref, launch(cfg)):
+            assert torch.equal(x, y), f"tile config {cfg} differs from config 16 (Ms = {Ms})"
+        if even:
+            for x, y in zip(ref, launch(cfg, pairs=True)):
+                assert torch.equal(x, y), f"tile config {cfg} with row-pair operands differs from config 16 (Ms = {Ms})"
     for x in ref:
         assert torch.isfinite(x.view(torch.bfloat16).float()).all()
 
