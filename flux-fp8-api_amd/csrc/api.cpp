@@ -411,6 +411,26 @@ int fluxmi_attention(const void* Q, const void* K, const void* VT, void* out, lo
 int fluxmi_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int upsample, void* stream) {
   return fluxmi_k_im2col3x3(x, col, B, H, W, C, upsample, (hipStream_t)stream);
 }
+int fluxmi_conv3x3(const void* x, const void* w2, const void* bias, const void* gate, const void* resid, void* out, int B, int H, int W, int C,
+                   int Cout, int upsample, void* stream) {
+  FLUXMI_REQUIRE(x && w2 && out && B >= 1 && H >= 1 && W >= 1, "conv3x3: NULL tensor or empty grid");
+  FLUXMI_REQUIRE(upsample == 1 || upsample == 2 || upsample == -2, "conv3x3: mode in {1, 2, -2}");
+  FLUXMI_REQUIRE(upsample != 2 || (H % 2 == 0 && W % 2 == 0), "conv3x3: upsampled output dims must be even");
+  FLUXMI_REQUIRE((long long)B * H * W < (1LL << 31), "conv3x3: more than 2^31 output pixels");
+  FLUXMI_REQUIRE(!resid || gate, "conv3x3: a residual needs the gate vector (ones for a plain add)");
+  FluxmiGemmParams p;
+  memset(&p, 0, sizeof(p));
+  FluxmiGemmGroup& g = p.g[0];
+  g.A = x; g.W = w2; g.bias = bias; g.C = out; g.gate = gate; g.resid = resid;
+  g.lda = C; g.ldc = Cout; g.ldr = Cout; g.M = B * H * W;
+  p.n_groups = 1; p.N = Cout; p.K = 9 * C; p.epi = resid ? FLUXMI_EPI_GATE_RESID : FLUXMI_EPI_BF16;
+  p.conv.zeros = fluxmi_zero_page();
+  p.conv.Hi = upsample == 2 ? H / 2 : upsample == -2 ? H * 2 : H;
+  p.conv.Wi = upsample == 2 ? W / 2 : upsample == -2 ? W * 2 : W;
+  p.conv.C = C; p.conv.Ho = H; p.conv.Wo = W;
+  p.conv.stride = upsample == -2 ? 2 : 1; p.conv.pad = upsample == -2 ? 0 : 1; p.conv.rshift = upsample == 2 ? 1 : 0;
+  return fluxmi_launch_gemm_conv(p, (hipStream_t)stream);
+}
 int fluxmi_groupnorm(const void* x, const void* gamma, const void* beta, void* y, float* work, int B, int P, int C, int swish, float eps,
                      void* stream) {
   return fluxmi_k_groupnorm(x, gamma, beta, y, work, B, P, C, swish, eps, (hipStream_t)stream);

@@ -33,6 +33,10 @@ struct FluxmiGemmParams {
   float* partial;
   unsigned long long* dbg;  // per-tile timestamps of the persistent kernel's timing build (tile config 19), else null
   FluxmiPrefetch pf;        // weights of later launches, read by pf.wgs extra workgroups behind the tiles (see FluxmiPrefetch)
+  // implicit 3x3 convolution (round 6, fluxmi_conv3x3 -> the 128x128 tile kernel only; C == 0: off): the A operand is never materialised --
+  // row r of group 0 is output pixel (b, yo, xo) of a [B, Ho, Wo] grid and K index (tap, c) reads x[b, (yo*stride + dy - pad) >> rshift,
+  // (xo*stride + dx - pad) >> rshift, c] of the NHWC input g[0].A (zero outside [0, Hi << rshift)): what fluxmi_im2col3x3 would have written
+  struct { const void* zeros; int Hi, Wi, C, Ho, Wo, stride, pad, rshift; } conv;
 };
 
 // ---- batched skinny GEMV (modulations + embedders, M = batch <= 8) ----------------------------
@@ -92,6 +96,8 @@ int fluxmi_gemm_tile_bn(int cfg);
 int fluxmi_gemm_tile_bm(int cfg);
 int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int tile_cfg, hipStream_t s);
 int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s);
+const void* fluxmi_zero_page();  // 256 zero bytes on the current device (vae.hip; allocated once per device, never under stream capture)
+int fluxmi_launch_gemm_conv(FluxmiGemmParams& p, hipStream_t s);  // bf16, tile config 2 with the implicit 3x3 gather (p.conv filled by the caller)
 int fluxmi_gemm_auto_cfg(const FluxmiGemmParams& p, int is_fp8);
 // persistent 256x256 ping-pong kernel (gemm_persist.hip, tile config 18; 19 = with per-tile timestamps)
 int fluxmi_gemm_persist_ok(const FluxmiGemmParams& p, int is_fp8, int act_fmt);

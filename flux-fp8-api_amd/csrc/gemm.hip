@@ -76,7 +76,11 @@ __device__ __forceinline__ void tile_epilogue(const FluxmiGemmGroup& G, v16f (&a
 // -------------------------------------------------------------------------------------------------
 // tiled MFMA kernel
 // -------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool FP8, int ACT_FMT>
+// CONV (round 6): implicit 3x3 convolution -- the A rows are output pixels and each 128-byte K-step (64 bf16 channels of ONE tap) is gathered from
+// the NHWC input by the LDS-DMA's own address computation (FluxmiGemmParams.conv), zero-padded through a zero page: the [pixels, 9 C] patch
+// matrix of fluxmi_im2col3x3 (2.4 - 4.8 GB per 1024^2 convolution of the FLUX VAE, written and read back) never exists.  Same K order and the
+// same MFMAs as the GEMM on the explicit patch matrix: identical bits.                     reference modules/autoencoder.py:55-120 (Conv2d 3x3)
+template <int BM, int BN, int WM, int WN, bool FP8, int ACT_FMT, bool CONV = false>
 __global__ void __launch_bounds__(WM* WN * 64) gemm_tile_kernel(const FluxmiGemmParams P) {
   constexpr int NT = WM * WN * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
@@ -112,10 +116,16 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_tile_kernel(const FluxmiGemm
   // ---- per-thread LDS-DMA source pointers (swizzle on the source side) -------------------------
   const unsigned char* srcA[IA];
   const unsigned char* srcW[IW];
+  int cv_y[IA], cv_x[IA], cv_b[IA], cv_s[IA];  // CONV: top-left source coordinate (before the tap offset), batch row base, 16-byte slot
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
     const int p = tid + NT * i, row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
     const int gr = min(m0 + row, M - 1);
+    if constexpr (CONV) {
+      const int hw = P.conv.Ho * P.conv.Wo;
+      const int b = gr / hw, rem = gr - b * hw, yo = rem / P.conv.Wo, xo = rem - yo * P.conv.Wo;
+      cv_y[i] = yo * P.conv.stride - P.conv.pad; cv_x[i] = xo * P.conv.stride - P.conv.pad; cv_b[i] = b * P.conv.Hi; cv_s[i] = slot * 16;
+    }
     // a_pairs (fp8 activations in the row-pair layout, fluxmi_gemm_group_t): the two 64-byte halves of this kernel's 128-byte K-step sit 128
     // bytes apart, consecutive K-steps 256
     srcA[i] = (FP8 && G.a_pairs) ? (const unsigned char*)G.A + f8_act_off(gr, G.lda, (slot >> 2) * 64 + (slot & 3) * 16, 1)
@@ -131,8 +141,22 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_tile_kernel(const FluxmiGemm
     unsigned char* dA = smem + buf * STAGE + wave * 1024;
     unsigned char* dW = dA + A_BYTES;
     const long long koff = (long long)kt * 128;
+    if constexpr (CONV) {
+      // K-step kt = channels [cb * 64, cb * 64 + 64) of tap (dy, dx): wave-uniform; the source pixel and its validity are per row
+      const int cpk = P.conv.C >> 6, tap = kt / cpk, cb = kt - tap * cpk, dy = tap / 3, dx = tap - dy * 3;
+      const int Hv = P.conv.Hi << P.conv.rshift, Wv = P.conv.Wi << P.conv.rshift;
 #pragma unroll
-    for (int i = 0; i < IA; ++i) glds16(srcA[i] + kt * a_kstep, dA + NT * 16 * i);
+      for (int i = 0; i < IA; ++i) {
+        const int yy = cv_y[i] + dy, xx = cv_x[i] + dx;
+        const bool ok = (unsigned)yy < (unsigned)Hv && (unsigned)xx < (unsigned)Wv;
+        const long long pix = (long long)(cv_b[i] + (yy >> P.conv.rshift)) * P.conv.Wi + (xx >> P.conv.rshift);
+        const unsigned char* src = ok ? (const unsigned char*)G.A + (pix * P.conv.C + cb * 64) * 2 + cv_s[i] : (const unsigned char*)P.conv.zeros + cv_s[i];
+        glds16(src, dA + NT * 16 * i);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < IA; ++i) glds16(srcA[i] + kt * a_kstep, dA + NT * 16 * i);
+    }
 #pragma unroll
     for (int i = 0; i < IW; ++i) glds16(srcW[i] + koff, dW + NT * 16 * i);
   };
@@ -304,6 +328,28 @@ int launch_tile(FluxmiGemmParams& p, hipStream_t s) {
 }
 
 template <bool FP8, int ACT>
+int launch_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s);
+
+int launch_conv_tile(FluxmiGemmParams& p, hipStream_t s) {
+  constexpr int BM = 128, BN = 128;
+  p.g[0].m_tile_start = 0;
+  p.tiles_m_total = (p.g[0].M + BM - 1) / BM;
+  p.group_m = 8;
+  constexpr int SMEM = 2 * (BM + BN) * 128;
+  auto kern = gemm_tile_kernel<BM, BN, 2, 2, false, FLUXMI_FMT_E5M2, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLUXMI_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_set = true;
+  }
+  const int nblk = p.tiles_m_total * (p.N / BN);
+  if (nblk == 0) return 0;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), SMEM, s, p);
+  FLUXMI_LAUNCH_CHECK();
+  return 0;
+}
+
+template <bool FP8, int ACT>
 int launch_cfg(FluxmiGemmParams& p, int cfg, hipStream_t s) {
   switch (cfg) {
     case 2: return launch_tile<128, 128, 2, 2, FP8, ACT>(p, s);  // two workgroups per CU: thin launches, N % 256 != 0
@@ -370,6 +416,14 @@ int fluxmi_launch_gemm(FluxmiGemmParams& p, int is_fp8, int act_fmt, int cfg, hi
   // bf16 operands; act_fmt only selects the fp8 format of quantising epilogues
   if (act_fmt == FLUXMI_FMT_E5M2) return launch_cfg<false, FLUXMI_FMT_E5M2>(p, cfg, s);
   return launch_cfg<false, FLUXMI_FMT_E4M3>(p, cfg, s);
+}
+
+int fluxmi_launch_gemm_conv(FluxmiGemmParams& p, hipStream_t s) {
+  FLUXMI_REQUIRE(p.n_groups == 1 && p.conv.C > 0 && p.conv.C % 64 == 0 && p.K == 9 * p.conv.C && p.N % 128 == 0 && p.conv.zeros,
+                 "conv3x3 (implicit): one group, C %% 64 == 0, K == 9 C, N %% 128 == 0 (C=%d N=%d K=%d)", p.conv.C, p.N, p.K);
+  FLUXMI_REQUIRE(p.epi == FLUXMI_EPI_BF16 || p.epi == FLUXMI_EPI_GATE_RESID, "conv3x3 (implicit): plain or residual epilogue");
+  FLUXMI_REQUIRE(!p.g[0].a_pairs && !p.g[0].c8_pairs && !p.g[0].vt_out && !p.g[0].k_out, "conv3x3 (implicit): no fused layouts");
+  return launch_conv_tile(p, s);
 }
 
 int fluxmi_launch_gemm_generic(FluxmiGemmParams& p, int is_fp8, int act_fmt, hipStream_t s) {

@@ -9,6 +9,9 @@
 // GroupNorm(32 groups, eps 1e-6, affine) runs in fp32 like autocast does and is fused with the swish that always follows it in a
 // ResnetBlock; the result is rounded to bf16 once -- exactly the cast autocast applies at the next convolution's input.
 // Softmax of the single 512-wide attention head: fp32 rows of  scale * S,  S = Q K^T from the GEMM in bf16.
+#include <map>
+#include <mutex>
+
 #include "common.h"
 #include "fluxmi_internal.h"
 
@@ -161,6 +164,24 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(const u16* __restrict
 int grid1d(long long n) { return (int)((n + 255) / 256 > 65535 * 16 ? 65535 * 16 : (n + 255) / 256); }
 
 }  // namespace
+
+// 256 zero bytes per device: the source of an implicit convolution's out-of-image taps (gemm.hip, CONV)
+const void* fluxmi_zero_page() {
+  static std::mutex mu;
+  static std::map<int, void*> pages;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = pages.find(dev);
+  if (it != pages.end()) return it->second;
+  void* p = nullptr;
+  if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  pages[dev] = p;
+  return p;
+}
 
 int fluxmi_k_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int up, hipStream_t s) {
   FLUXMI_REQUIRE(C % 8 == 0 && (up == 1 || up == 2 || up == -2), "im2col3x3: C %% 8 == 0, mode in {1, 2, -2}");

@@ -86,6 +86,7 @@ _SIGS = {
     "fluxmi_pair_rows": ([vp, vp, i32, i64, vp], i32),
     "fluxmi_unpair_rows": ([vp, vp, i32, i64, vp], i32),
     "fluxmi_im2col3x3": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "fluxmi_conv3x3": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "fluxmi_groupnorm": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, vp], i32),
     "fluxmi_softmax_rows": ([vp, vp, i32, i32, i64, C.c_float, vp], i32),
     "fluxmi_row_norm": ([vp, vp, vp, vp, i32, i32, i64, i64, C.c_float, i32, vp], i32),

@@ -310,6 +310,37 @@ def euler_(img: torch.Tensor, pred: torch.Tensor, dt: float) -> torch.Tensor:
 
 
 # ---- VAE decoder pieces (NHWC bf16) -------------------------------------------------------------------------------------
+def conv3x3_ok(cin: int, cout: int) -> bool:
+    """shapes fluxmi_conv3x3 (the implicit-GEMM 3x3 convolution) takes: 64-channel K-steps, 128-column tiles"""
+    return cin % 64 == 0 and cout % 128 == 0
+
+
+def conv3x3(x: torch.Tensor, w2: torch.Tensor, bias=None, upsample: int = 1, resid=None, gate=None) -> torch.Tensor:
+    """x [B, Hin, Win, C] bf16 (NHWC), w2 [Cout, 9*C] bf16 with K ordered (dy, dx, c) -> [B, H, W, Cout]: the 3x3 convolution as an IMPLICIT
+    GEMM (no patch matrix).  `upsample` as in im2col3x3; resid [B, H, W, Cout] (+ gate [Cout], default ones): out = resid + gate * y."""
+    _req(x, torch.bfloat16, "x")
+    _req(w2, torch.bfloat16, "w2")
+    x = x.contiguous()
+    B, Hi, Wi, Cc = x.shape
+    Cout = w2.shape[0]
+    if w2.shape[1] != 9 * Cc or not conv3x3_ok(Cc, Cout):
+        raise ValueError(f"conv3x3: needs w2 [Cout, 9*C], C % 64 == 0, Cout % 128 == 0 (C={Cc}, w2={tuple(w2.shape)})")
+    if upsample == -2:
+        if Hi % 2 or Wi % 2:
+            raise ValueError("conv3x3: the stride-2 mode needs even input dims")
+        H, W = Hi // 2, Wi // 2
+    else:
+        H, W = Hi * upsample, Wi * upsample
+    out = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=x.device)
+    if resid is not None:
+        _req(resid, torch.bfloat16, "resid")
+        resid = resid.contiguous()
+        if gate is None:
+            gate = torch.ones(Cout, dtype=torch.bfloat16, device=x.device)
+    call("fluxmi_conv3x3", _p(x), _p(w2.contiguous()), _p(bias), _p(gate), _p(resid), _p(out), B, H, W, Cc, Cout, upsample, _stream())
+    return out
+
+
 def im2col3x3(x: torch.Tensor, upsample: int = 1) -> torch.Tensor:
     """x [B, Hin, Win, C] bf16 -> patch matrix [B*H*W, 9*C], column order (dy, dx, c).  upsample = 1: H = Hin; 2: nearest 2x upsample
     first (H = 2*Hin); -2: stride-2 window with zero pad on the right/bottom only (H = Hin/2, the reference's Downsample)."""

@@ -148,6 +148,7 @@ class AutoEncoder(nn.Module):
         self.scale_factor, self.shift_factor = params.scale_factor, params.shift_factor
         self.encoder_loaded = True  # util.load_autoencoder clears it for decoder-only checkpoints
         self._wcache = {}
+        self.implicit_conv = True  # 3x3 convolutions as implicit GEMMs (fluxmi_conv3x3); False = im2col + GEMM (same bits, tests)
 
     # ---- weight preparation (once per module): conv weight -> GEMM weight [N, K] bf16, K ordered (dy, dx, cin) --------------------
     def _w(self, conv: nn.Conv2d):
@@ -172,6 +173,24 @@ class AutoEncoder(nn.Module):
         if pad:
             x = torch.nn.functional.pad(x, (0, pad))
         B, Hi, Wi, _ = x.shape
+        # round 6: implicit GEMM -- the tile kernel gathers each K-step from the NHWC input itself; the [pixels, 9 C] patch matrix (2.4 - 4.8 GB
+        # per 1024^2 convolution) exists only for the two convolutions whose channel counts do not tile (conv_in: 16 channels, conv_out: 3 outputs)
+        if self.implicit_conv and ops.conv3x3_ok(x.shape[-1], w2.shape[0]):
+            gate = self._ones(w2.shape[0], x.device) if resid is not None else None
+            return ops.conv3x3(x, w2, b, upsample, resid=resid, gate=gate)
+        if self.implicit_conv and resid is None and ops.conv3x3_ok(x.shape[-1], 128) and w2.shape[0] < 128:
+            # few output channels (decoder.conv_out: 128 -> 3 at full resolution): zero rows up to one 128-column tile, slice afterwards -- 268 MB of
+            # discarded outputs per 1024^2 image instead of a 2.4 GB patch matrix written and read back
+            key = ("pad128", id(conv))
+            ent = self._wcache.get(key)
+            if ent is None or ent[0] is not conv.weight or ent[1].device != w2.device:
+                wp = torch.zeros(128, w2.shape[1], dtype=w2.dtype, device=w2.device)
+                wp[: w2.shape[0]] = w2
+                bp = torch.zeros(128, dtype=b.dtype, device=b.device)
+                bp[: b.shape[0]] = b
+                ent = (conv.weight, wp, bp)
+                self._wcache[key] = ent
+            return ops.conv3x3(x, ent[1], ent[2], upsample)[..., : w2.shape[0]].contiguous()
         col = ops.im2col3x3(x, upsample)  # upsample: 1 | 2 (nearest 2x first) | -2 (stride 2, right/bottom zero pad)
         Ho, Wo = (Hi // 2, Wi // 2) if upsample == -2 else (Hi * upsample, Wi * upsample)
         return self._gemm(col, w2, b, resid).view(B, Ho, Wo, -1)

@@ -287,6 +287,13 @@ int fluxmi_attention_rawq(const void* qkv, long long ld_qkv, const void* pe, con
  * The convolution is then fluxmi_gemm_grouped(is_fp8=0) with the weight reordered to [Cout][dy][dx][Cin].
  *                                                                            modules/autoencoder.py:65-72,95-120,228,259 */
 int fluxmi_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int upsample, void* stream);
+/* The same convolution WITHOUT the patch matrix (ABI 5, round 6): out [B*H*W, Cout] = conv3x3(x) (+ bias) (+ resid when given: out = resid +
+ * gate * y with gate [Cout] bf16, normally ones) -- the 128x128 bf16 tile kernel gathers each 128-byte K-step (64 channels of one tap) from the
+ * NHWC input inside its LDS-DMA address computation and pads through a zero page; w2 [Cout][3][3][C] bf16.  Same K order, same MFMAs as the GEMM
+ * on fluxmi_im2col3x3's matrix: identical bits (tests/test_ops_gpu.py::test_conv3x3_implicit_equals_im2col_gemm).  Needs C %% 64 == 0 and
+ * Cout %% 128 == 0 (FLUX VAE: every 3x3 convolution except conv_in / conv_out).  `upsample` as above; (H, W) = the OUTPUT grid. */
+int fluxmi_conv3x3(const void* x, const void* w2, const void* bias, const void* gate, const void* resid, void* out, int B, int H, int W, int C,
+                   int Cout, int upsample, void* stream);
 /* GroupNorm(32 groups, affine) in fp32 + optional swish, rounded to bf16 once; x, y [B, P, C]; work: float[(B*ceil(P/4096)+B)*64].
  *                                                                                modules/autoencoder.py:19-20,28-30,62-70,256 */
 int fluxmi_groupnorm(const void* x, const void* gamma, const void* beta, void* y, float* work, int B, int P, int C, int swish, float eps,

@@ -1384,6 +1384,51 @@ def test_quant_lut_epilogue(ops, dev, K):
     assert torch.equal(o1, o2) and torch.equal(w1_.view(torch.uint8), w2_.view(torch.uint8))
 
 
+@pytest.mark.parametrize("B,Hi,Wi,C,Cout,up", [(1, 24, 40, 128, 128, 1), (2, 16, 24, 256, 128, 2), (1, 32, 32, 128, 256, -2), (1, 64, 64, 512, 512, 1),
+                                               (1, 9, 13, 64, 128, 1), (1, 5, 7, 128, 128, 2)])
+def test_conv3x3_implicit_equals_im2col_gemm(ops, dev, B, Hi, Wi, C, Cout, up):
+    """fluxmi_conv3x3 (round 6): the 3x3 convolution as an IMPLICIT GEMM -- the 128 x 128 tile kernel gathers every 128-byte K-step (64 channels of
+    one tap) from the NHWC input in its LDS-DMA address computation, out-of-image taps through a zero page -- must equal the GEMM on
+    fluxmi_im2col3x3's explicit patch matrix BIT FOR BIT (same K order, same MFMAs, same tile config): stride 1 / pad 1, the folded 2x nearest
+    upsample, the stride-2 right/bottom-padded window; odd sizes (ragged last tile), two images, plain and residual epilogues; and it matches
+    torch's conv2d to bf16 accuracy.                                          reference modules/autoencoder.py:55-120 (Conv2d 3x3)"""
+    from fluxmi import _lib
+
+    torch.manual_seed(17)
+    if up == -2:
+        Hi, Wi = Hi * 2, Wi * 2
+    x = torch.randn(B, Hi, Wi, C, device=dev).bfloat16()
+    w = (torch.randn(Cout, C, 3, 3, device=dev) * (9 * C) ** -0.5).bfloat16()
+    w2 = w.permute(0, 2, 3, 1).reshape(Cout, 9 * C).contiguous()  # [Cout][dy][dx][C]
+    bias = torch.randn(Cout, device=dev).bfloat16()
+    col = ops.im2col3x3(x, up)
+    ref = torch.empty(col.shape[0], Cout, dtype=torch.bfloat16, device=dev)
+    ops.linear(col, w2, bias, out=ref, tile_cfg=2)
+    got = ops.conv3x3(x, w2, bias, up)
+    H, W = got.shape[1], got.shape[2]
+    assert got.shape == (B, H, W, Cout) and ref.shape[0] == B * H * W
+    assert torch.equal(got.view(-1, Cout).view(torch.int16), ref.view(torch.int16)), \
+        f"implicit conv differs from im2col + GEMM: {(got.view(-1, Cout) != ref).float().mean().item():.2e} of the elements"
+    # residual epilogue: out = resid + 1 * y
+    resid = torch.randn(B, H, W, Cout, device=dev).bfloat16()
+    ones = torch.ones(Cout, dtype=torch.bfloat16, device=dev)
+    ref_r = torch.empty_like(ref)
+    ops.linear(col, w2, bias, epilogue=_lib.EPI_GATE_RESID, gate=ones, resid=resid.view(-1, Cout), out=ref_r, tile_cfg=2)
+    got_r = ops.conv3x3(x, w2, bias, up, resid=resid)
+    assert torch.equal(got_r.view(-1, Cout).view(torch.int16), ref_r.view(torch.int16))
+    # against torch (fp32 conv of the bf16 values), bf16 accuracy
+    xin = x.float().permute(0, 3, 1, 2)
+    if up == 2:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    if up == -2:
+        t = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w.float(), bias.float(), stride=2)
+    else:
+        t = F.conv2d(xin, w.float(), bias.float(), padding=1)
+    t = t.permute(0, 2, 3, 1)
+    err = (got.float() - t).abs().max().item()
+    assert err <= 2.0 ** -6 * max(1.0, t.abs().max().item()), f"implicit conv vs torch conv2d: max |err| {err:.3e}"
+
+
 def test_lora_fuse(ops, dev):
     """Config 5: dequant + B@A + requant on device (lora_loading.py:509-577,615-631 -> float8_quantize.py:209-212)."""
     torch.manual_seed(12)
