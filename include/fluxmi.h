@@ -405,7 +405,10 @@ int fluxmi_engine_get_buffer(fluxmi_engine_t* e, const char* name, void** ptr, l
  * block i at depth*12H + i*3H = shift|scale|gate, LastLayer.adaLN at depth*12H + single*3H = shift|scale).  kind 2 = LastLayer (index 0;
  * stages 0 LN+modulate of the img rows of x -> "fin", 1 bf16 Linear -> buffer "pred_s" [B, Li, in_channels]; flux_model.py:499-503).
  * mode 1 = fused kernels, 2 = unfused with frozen scales.
- * copy_buffer: device-to-device copy between a named workspace buffer and a caller buffer (to_engine != 0 writes the workspace). */
+ * copy_buffer: device-to-device copy between a named workspace buffer and a caller buffer (to_engine != 0 writes the workspace).  The fp8
+ * activation buffers "a8", "attn8", "h8", "cat8" are exchanged as PLAIN rows: while the engine keeps them in row pairs (fused mode,
+ * fluxmi_tuning_t.a_pairs, even L and Lt) the copy converts, and offset / bytes must then cover whole pairs of rows.  (The unfused modes
+ * stage plain rows into the same buffers: this hook serves mode-1 teacher forcing.) */
 int fluxmi_engine_run_block(fluxmi_engine_t* e, int kind, int index, int mode, int stage_from, int stage_to, void* stream);
 int fluxmi_engine_copy_buffer(fluxmi_engine_t* e, const char* name, long long offset, void* dev_ptr, long long bytes, int to_engine,
                               void* stream);
