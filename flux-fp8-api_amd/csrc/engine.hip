@@ -177,9 +177,13 @@ int ensure_pairs(E* e, hipStream_t s) {
   if (fluxmi_tuning().w_pairs) {
     auto want = [&](int li) {
       const fluxmi_linear_t& l = e->lin[li];
-      if (l.kind != 1 || !l.weight || l.N % 2 || l.K % 64) return;
+      // fp8 weights only.  (The kernels read row-pair copies of BF16 weights as well since round 6 -- tests/test_ops_gpu.py::
+      // test_gemm_bf16_row_pair_weights -- but for the bf16 flow they measured +1 %: Flux-schnell 256^2, 15.06 / 14.99 ms per step with copies,
+      // 15.21 / 15.17 without, for 23.8 GB of copies; its M = 512 launches are bound by the A side and by latency)
+      const size_t eb = 1;
+      if (l.kind != 1 || !l.weight || l.N % 2 || (l.K * eb) % 64) return;
       off[li] = (long long)total;
-      total += ((size_t)l.N * l.K + 255) & ~(size_t)255;
+      total += ((size_t)l.N * l.K * eb + 255) & ~(size_t)255;
     };
     // (proj: the ping-pong kernel, tile config 13, honours W_pairs since round 6, but copies of the proj weights measured nothing in the step --
     // 38.71 / 38.74 / 38.76 ms with, 38.71 / 38.75 / 38.71 without, profiles/r06_act_pairs.txt -- so they are not made)
@@ -216,7 +220,7 @@ int ensure_pairs(E* e, hipStream_t s) {
     e->pairs_bytes = total;
   }
   for (int li = 0; li < n; ++li)
-    if (off[li] >= 0) FLUXMI_TRY(fluxmi_k_pair_rows(e->lin[li].weight, e->pairs + off[li], e->lin[li].N, e->lin[li].K, s));
+    if (off[li] >= 0) FLUXMI_TRY(fluxmi_k_pair_rows(e->lin[li].weight, e->pairs + off[li], e->lin[li].N, (long long)e->lin[li].K * (e->lin[li].kind == 1 ? 1 : 2), s));
   e->pairs_off = off;
   e->pairs_dirty = false;
   return 0;
@@ -760,6 +764,7 @@ int single_block(E* e, const Ctx& c, int i, int mode, int trial, int s0, int s1,
     if (on(1)) {
       std::vector<FluxmiGemmGroup> gs;
       gs.push_back(mk_group(L1, L1.kind ? (const void*)a8 : (const void*)abf, H, lin1, 3 * H + Hm, B * L));
+      gs.back().W_pairs = pairs_of(e, l1);
       FLUXMI_TRY(run_gemm(gs, 3 * H + Hm, H, L1.kind, L1.in_fmt, FLUXMI_EPI_BF16, s));
     }
     if (on(2)) FLUXMI_TRY(fluxmi_k_qkv_rope(lin1, 3 * H + Hm, pe, ns[0], ns[1], ns[0], ns[1], nullptr, K, VT, B, L, e->Lp, heads, L, attn_f16k(), s));

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
   const bool a_pairs = FP8 && !SPLITK && G.a_pairs != 0;
   const int a_kstep = a_pairs ? 128 : 64;
   // W in the row-pair layout when the caller has one (fluxmi_gemm_group_t.W_pairs, as in the persistent and the one-wave kernels)
-  const bool w_pairs = FP8 && !SPLITK && G.W_pairs != nullptr;
+  const bool w_pairs = G.W_pairs != nullptr;  // fp8 or bf16 (row bytes K * EB), split-K or not (this launch uses per-lane pointers: VAR 2)
   const int w_kstep = w_pairs ? 128 : 64;
   const unsigned char* w_base = (const unsigned char*)(w_pairs ? G.W_pairs : G.W);
 #pragma unroll
@@ -100,7 +100,8 @@ __global__ void __launch_bounds__(512, 2) gemm_pp_kernel(const FluxmiGemmParams 
 #pragma unroll
   for (int i = 0; i < IW; ++i) {
     const int p = tid + NT * i, row = p >> 2, slot = (p & 3) ^ ((row >> 2) & 3);
-    srcW[i] = w_pairs ? w_base + f8_act_off(n0 + row, P.K, slot * 16, 1) : w_base + ((long long)(n0 + row) * P.K) * EB + slot * 16 + (long long)k_begin * 64;
+    srcW[i] = w_pairs ? w_base + f8_act_off(n0 + row, w_row_b, slot * 16, 1) + (long long)k_begin * 128
+                      : w_base + ((long long)(n0 + row) * P.K) * EB + slot * 16 + (long long)k_begin * 64;
     w_voff[i] = w_pairs ? (unsigned)((row >> 1) * 2 * w_row_b + (row & 1) * 64 + slot * 16) : (unsigned)(row * w_row_b + slot * 16);
   }
   const __amdgpu_buffer_rsrc_t ars = make_rsrc(G.A, (unsigned)min((long long)M * a_row_b, 0xffffffffLL));

@@ -1287,6 +1287,32 @@ def test_gemm_one_wave_kernel_row_pair_weights(ops, dev, cfg):
         assert torch.equal(x.view(torch.int16), y.view(torch.int16))
 
 
+@pytest.mark.parametrize("cfg", [13, 16, 17, 113 + 4])
+def test_gemm_bf16_row_pair_weights(ops, dev, cfg):
+    """Round 6: W_pairs for BF16 weights (row bytes K * 2): the bf16 flow's 64-byte-K-step kernels -- ping-pong (13), one-wave-per-SIMD (16 / 17) and the
+    split-K build of 13 -- read the row-pair copy and give the bits of the plain launch (Flux-schnell's M = 512 launches stream 24 - 132 MB of weights
+    each: half lines cost them as they cost the fp8 step).                                  flux_model.py:154-155 (nn.Linear), layout only"""
+    from fluxmi import _lib
+
+    torch.manual_seed(8)
+    M, N, K = 512, 3072, 6144
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+    wp = ops.pair_rows(w)
+    bias = torch.randn(N, device=dev).bfloat16()
+    gate = torch.randn(N, device=dev).bfloat16()
+    for epi in (_lib.EPI_BF16, _lib.EPI_GATE_RESID):
+        outs = []
+        for pairs in (False, True):
+            o = torch.randn(M, N, device=dev, generator=torch.Generator(device=dev).manual_seed(3)).bfloat16()
+            kw = dict(gate=gate.data_ptr(), resid=o.data_ptr(), ldr=N) if epi == _lib.EPI_GATE_RESID else {}
+            g = ops.make_group(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, None, o.data_ptr(), M, K, N, W_pairs=wp.data_ptr() if pairs else None, **kw)
+            ops.gemm_grouped([g], N, K, False, E5M2, epi, cfg)
+            torch.cuda.synchronize()
+            outs.append(o.view(torch.int16).clone())
+        assert torch.equal(outs[0], outs[1]), f"tile config {cfg}, epilogue {epi}: bf16 W_pairs changes the result"
+
+
 @pytest.mark.parametrize("k_f16", [False, True])
 @pytest.mark.parametrize("epi", ["bf16", "split"])
 def test_gemm_persistent_fused_k(ops, dev, k_f16, epi):
