@@ -1,3 +1,4 @@
+# all five BASELINE.json configs back to back on one lease (gpurun -- bash tools/gpu/all_configs.sh): one summary line per config, JSON lines under gpurun_out/r6x/
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/r6x
 for c in 1 2 3 4 5; do
   python bench.py --config $c --steps 20 --warmup 3 --no-pmc --no-cpu-baseline > gpurun_out/r6x/config$c.json 2> gpurun_out/r6x/config$c.err
