@@ -462,6 +462,30 @@ def test_full_depth_19_38(dev):
     ck.rows.append("  --  free-running residual stream vs the oracle after blocks 1, 10, 19 (double) / 20, 38, 57: "
                    + ", ".join(f"{drift[k]:.2e}" for k in (0, 9, 18, 19, 37, 56)))
     assert all(math.isfinite(v) for v in drift)
+    # (4) round 6: the stated PER-PIXEL tolerance at the full depth.  One Euler jump from t = T_FROZEN to 0 with each of the three predictions of this
+    # call (engine fp8 | oracle fp8 | oracle bf16 = the reference's bf16 flow path), unpack, decode with the real FLUX VAE geometry (engine latents:
+    # the native VAE; oracle latents: the oracle VAE under autocast), into_bytes' uint8 map: the engine's pixels must be no further from the
+    # reference-bf16 image than the reference's own fp8 image is, x 1.25 (mean |delta|) / - 1.94 dB (PSNR)   [tests/pixel_parity.py, flux_pipeline.py:619-663]
+    import pixel_parity as pp
+    import vae_oracle as vo
+    from modules.autoencoder import AutoEncoder, AutoEncoderParams
+
+    ae = AutoEncoder(AutoEncoderParams(**vo.FULL_PARAMS))
+    ae_sd = vo.synth_state_dict({k: v.shape for k, v in ae.state_dict().items()}, seed=7)
+    ae.load_state_dict(ae_sd, strict=True)
+    ae.to(dev)
+    Hh, Ww = case["height"], case["width"]
+    x0 = lambda pr: fo.unpack_latent((inp["img"].float() - fg.T_FROZEN * pr.float().cpu()).to(torch.bfloat16).float(), Hh, Ww)
+    with torch.inference_mode():
+        px_e = pp.to_uint8(ae.decode(x0(pred).to(dev)))
+        px_o8 = pp.to_uint8(vo.decode(ae_sd, vo.FULL_PARAMS, x0(o1), autocast=True))
+        px_o16 = pp.to_uint8(vo.decode(ae_sd, vo.FULL_PARAMS, x0(rb), autocast=True))
+    yard, m_e = pp.pixel_metrics(px_o8, px_o16), pp.pixel_metrics(px_e, px_o16)
+    ok = m_e["mean_abs"] <= 1.25 * yard["mean_abs"] and m_e["psnr_db"] >= yard["psnr_db"] - 1.94
+    ck.rows.append(f"  {'ok ' if ok else 'BAD'} {'per-pixel tolerance after 57 blocks (one Euler jump, real VAE)':58s} engine vs reference-bf16: {pp.fmt(m_e)}; "
+                   f"yardstick reference-fp8 vs reference-bf16: {pp.fmt(yard)}")
+    if not ok:
+        ck.fail.append("per-pixel tolerance at full depth")
     ck.done()
 
 
