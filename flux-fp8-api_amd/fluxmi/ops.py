@@ -363,7 +363,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, swish: b
     _req(x, torch.bfloat16, "x")
     x = x.contiguous()
     B, P, Cc = x.shape
-    work = torch.empty((B * ((P + 4095) // 4096) + B) * 64, dtype=torch.float32, device=x.device)
+    work = torch.empty((B * ((P + 511) // 512) + B) * 64, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
     call("fluxmi_groupnorm", _p(x), _p(gamma), _p(beta), _p(y), _p(work), B, P, Cc, int(swish), float(eps), _stream())
     return y

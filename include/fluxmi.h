@@ -294,7 +294,7 @@ int fluxmi_im2col3x3(const void* x, void* col, int B, int H, int W, int C, int u
  * Cout %% 128 == 0 (FLUX VAE: every 3x3 convolution except conv_in / conv_out).  `upsample` as above; (H, W) = the OUTPUT grid. */
 int fluxmi_conv3x3(const void* x, const void* w2, const void* bias, const void* gate, const void* resid, void* out, int B, int H, int W, int C,
                    int Cout, int upsample, void* stream);
-/* GroupNorm(32 groups, affine) in fp32 + optional swish, rounded to bf16 once; x, y [B, P, C]; work: float[(B*ceil(P/4096)+B)*64].
+/* GroupNorm(32 groups, affine) in fp32 + optional swish, rounded to bf16 once; x, y [B, P, C]; work: float[(B*ceil(P/512)+B)*64] (ABI 5: was ceil(P/4096)).
  *                                                                                modules/autoencoder.py:19-20,28-30,62-70,256 */
 int fluxmi_groupnorm(const void* x, const void* gamma, const void* beta, void* y, float* work, int B, int P, int C, int swish, float eps,
                      void* stream);
